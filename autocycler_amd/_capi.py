@@ -1,0 +1,180 @@
+"""ctypes binding of libautocycler_hip.so (include/autocycler_hip.h).
+
+There is no Python or CPU implementation behind these calls: if the HIP library has not been built
+(`python -c 'import __graft_entry__ as g; g.build()'` or `make -C autocycler_amd/csrc`) importing the
+package still works, but any graph build raises HipLibraryMissing."""
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libautocycler_hip.so"
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class AutocyclerError(RuntimeError):
+    """The text the reference would hand to quit_with_error (misc.rs:131-137)."""
+
+
+class SeqView(C.Structure):
+    _fields_ = [("fwd", C.c_char_p), ("length", C.c_uint32), ("id", C.c_uint16)]
+
+
+class Position(C.Structure):
+    _fields_ = [("pos", C.c_uint32), ("seq_id_and_strand", C.c_uint16)]
+
+
+class Link(C.Structure):
+    _fields_ = [("a", C.c_uint32), ("a_fwd", C.c_uint8), ("b", C.c_uint32), ("b_fwd", C.c_uint8)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("unitigs", C.c_uint32), ("links_one_way", C.c_uint64), ("total_length", C.c_uint64)]
+
+
+class Timings(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("h2d", "pack", "insert", "collect_sort", "degree", "segment", "minkey",
+                                          "rank", "paths", "links", "seqs", "d2h", "total_device", "host_tail",
+                                          "insert_kernel_ms")] + \
+               [(n, C.c_uint64) for n in ("insert_positions", "table_capacity", "n_distinct", "n_path_entries")] + \
+               [("simplify_passes", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+EXPORTS = ["ac_compress_build", "ac_compress_build_device", "ac_text_size", "ac_layout_text", "ac_kmer_count",
+           "ac_stats_pre", "ac_stats_post", "ac_unitig_count", "ac_unitig", "ac_unitig_positions", "ac_links",
+           "ac_path", "ac_timings_get", "ac_free", "ac_gfa_string", "ac_string_free", "ac_last_error",
+           "ac_device_count", "ac_max_kmer", "ac_version"]
+
+_libs = {}
+
+
+def load_library(path=None):
+    path = Path(path) if path else LIB_PATH
+    key = str(path)
+    if key in _libs:
+        return _libs[key]
+    if not path.exists():
+        raise HipLibraryMissing(f"{path} not found: build the HIP extension first (make -C autocycler_amd/csrc). "
+                                "There is no CPU fallback.")
+    lib = C.CDLL(key)
+    lib.ac_last_error.restype = C.c_char_p
+    lib.ac_version.restype = C.c_char_p
+    lib.ac_kmer_count.restype = C.c_uint64
+    lib.ac_kmer_count.argtypes = [C.c_void_p]
+    lib.ac_stats_pre.restype = Stats
+    lib.ac_stats_pre.argtypes = [C.c_void_p]
+    lib.ac_stats_post.restype = Stats
+    lib.ac_stats_post.argtypes = [C.c_void_p]
+    lib.ac_unitig_count.restype = C.c_uint32
+    lib.ac_unitig_count.argtypes = [C.c_void_p]
+    lib.ac_max_kmer.restype = C.c_uint32
+    lib.ac_text_size.restype = C.c_uint64
+    lib.ac_free.argtypes = [C.c_void_p]
+    lib.ac_string_free.argtypes = [C.c_void_p]
+    lib.ac_unitig.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+    lib.ac_unitig_positions.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.POINTER(Position)), C.POINTER(C.c_uint32)]
+    lib.ac_links.argtypes = [C.c_void_p, C.POINTER(C.POINTER(Link)), C.POINTER(C.c_uint64)]
+    lib.ac_path.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_uint32)]
+    lib.ac_timings_get.argtypes = [C.c_void_p, C.POINTER(Timings)]
+    _libs[key] = lib
+    return lib
+
+
+def _check(lib, rc):
+    if rc != 0:
+        raise AutocyclerError(lib.ac_last_error().decode(errors="replace"))
+
+
+class Graph:
+    """Owning handle of an ac_graph (the final UnitigGraph after simplify_structure)."""
+
+    def __init__(self, lib, handle, n_seqs):
+        self._lib, self._h, self.n_seqs = lib, handle, n_seqs
+
+    def close(self):
+        if self._h:
+            self._lib.ac_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def kmer_count(self):
+        return self._lib.ac_kmer_count(self._h)
+
+    def _stats(self, fn):
+        s = fn(self._h)
+        return dict(unitigs=s.unitigs, links=s.links_one_way, total_length=s.total_length)
+
+    @property
+    def stats_pre(self):
+        return self._stats(self._lib.ac_stats_pre)
+
+    @property
+    def stats_post(self):
+        return self._stats(self._lib.ac_stats_post)
+
+    @property
+    def unitig_count(self):
+        return self._lib.ac_unitig_count(self._h)
+
+    def unitig(self, idx):
+        p, n, d = C.c_void_p(), C.c_uint32(), C.c_double()
+        _check(self._lib, self._lib.ac_unitig(self._h, idx, C.byref(p), C.byref(n), C.byref(d)))
+        return C.string_at(p.value, n.value), d.value
+
+    def positions(self, idx, forward):
+        p, n = C.POINTER(Position)(), C.c_uint32()
+        _check(self._lib, self._lib.ac_unitig_positions(self._h, idx, 1 if forward else 0, C.byref(p), C.byref(n)))
+        return [(p[i].seq_id_and_strand & 0x7FFF, bool(p[i].seq_id_and_strand & 0x8000), p[i].pos) for i in range(n.value)]
+
+    def links(self):
+        p, n = C.POINTER(Link)(), C.c_uint64()
+        _check(self._lib, self._lib.ac_links(self._h, C.byref(p), C.byref(n)))
+        return [(p[i].a, bool(p[i].a_fwd), p[i].b, bool(p[i].b_fwd)) for i in range(n.value)]
+
+    def path(self, seq_index):
+        p, n = C.POINTER(C.c_int32)(), C.c_uint32()
+        _check(self._lib, self._lib.ac_path(self._h, seq_index, C.byref(p), C.byref(n)))
+        return p[:n.value]
+
+    def timings(self):
+        t = Timings()
+        _check(self._lib, self._lib.ac_timings_get(self._h, C.byref(t)))
+        return t.as_dict()
+
+    def gfa(self, filenames, headers):
+        n = self.n_seqs
+        fn = (C.c_char_p * n)(*[f.encode() for f in filenames])
+        hd = (C.c_char_p * n)(*[h.encode() for h in headers])
+        out, ln = C.c_void_p(), C.c_uint64()
+        _check(self._lib, self._lib.ac_gfa_string(self._h, fn, hd, C.byref(out), C.byref(ln)))
+        s = C.string_at(out.value, ln.value).decode()
+        self._lib.ac_string_free(out)
+        return s
+
+
+def compress_build(k, assembly_count, seqs, device=0, lib_path=None):
+    """seqs: iterable of (padded_forward_bytes, unpadded_length, seq_id).  Replaces compress.rs:42-44."""
+    lib = load_library(lib_path)
+    seqs = list(seqs)
+    arr = (SeqView * len(seqs))()
+    keep = []
+    for i, (fwd, length, sid) in enumerate(seqs):
+        b = bytes(fwd)
+        keep.append(b)
+        arr[i].fwd, arr[i].length, arr[i].id = b, length, sid
+    h = C.c_void_p()
+    _check(lib, lib.ac_compress_build(C.c_uint32(k), C.c_uint32(assembly_count), arr, C.c_uint32(len(seqs)),
+                                      C.c_int(device), C.byref(h)))
+    return Graph(lib, h, len(seqs))

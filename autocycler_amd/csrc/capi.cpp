@@ -1,0 +1,205 @@
+// C ABI of libautocycler_hip.so (include/autocycler_hip.h).  No CPU fallback: every build call runs the
+// HIP pipeline on a gfx950 device or fails.  (Under -DAC_EMU the very same entry points drive the serial
+// emulation; that library is built only by the CPU test-suite and is named libautocycler_emu.so.)
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/autocycler_hip.h"
+#include "graph_build.hpp"
+#include "host_tail.hpp"
+#include "gfa_writer.hpp"
+#include "device_rt.hpp"
+
+using namespace ac;
+
+static thread_local std::string g_err;
+
+struct ac_graph {
+    FinalGraph g;
+    BuildTimings tm;
+    std::vector<uint16_t> seq_ids;
+    std::vector<uint32_t> seq_lens;
+    bool positions_built = false;
+};
+
+template <class F> static int guarded(F&& f) {
+    try { f(); return 0; }
+    catch (const std::exception& e) { g_err = e.what(); return 1; }
+    catch (...) { g_err = "unknown internal error"; return 1; }
+}
+
+static void select_device(int device) {
+#ifndef AC_EMU
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        throw DeviceError("no HIP device available: the MI355X backend has no CPU fallback");
+    if (device < 0 || device >= n) throw DeviceError("invalid HIP device ordinal " + std::to_string(device));
+    AC_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    AC_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        throw DeviceError(std::string("device is ") + prop.gcnArchName + "; this library is built for gfx950 only");
+#else
+    (void)device;
+#endif
+}
+
+static void validate(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs) {
+    if (!seqs || n_seqs == 0) throw DeviceError("no sequences found in input assemblies");
+    if (k % 2 == 0) throw DeviceError("--kmer must be odd");
+    if (n_seqs > 32767) throw DeviceError("no more than 32767 input sequences are allowed");
+    for (uint32_t i = 0; i < n_seqs; i++) {
+        if (!seqs[i].fwd) throw DeviceError("null sequence pointer");
+        if (seqs[i].length < k) throw DeviceError("sequence shorter than k");
+    }
+}
+
+extern "C" {
+
+const char* ac_last_error(void) { return g_err.c_str(); }
+const char* ac_version(void) {
+#ifdef AC_EMU
+    return "autocycler_amd 0.1 (CPU emulation, tests only)";
+#else
+    return "autocycler_amd 0.1 (gfx950)";
+#endif
+}
+uint32_t ac_max_kmer(void) { int m = max_supported_k(); return (uint32_t)(m % 2 ? m : m - 1); }
+int ac_device_count(void) {
+#ifndef AC_EMU
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+#else
+    return 0;
+#endif
+}
+
+uint64_t ac_text_size(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs) {
+    uint64_t n = 1;
+    for (uint32_t i = 0; i < n_seqs; i++) n += (uint64_t)seqs[i].length + k - 1 + 1;
+    return n;
+}
+int ac_layout_text(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs, uint8_t* text, uint64_t* seq_off,
+                   uint16_t* seq_d1, uint16_t* seq_d2) {
+    return guarded([&] {
+        std::vector<SeqView> v(n_seqs);
+        for (uint32_t i = 0; i < n_seqs; i++) v[i] = SeqView{seqs[i].fwd, seqs[i].length};
+        std::vector<uint64_t> off; std::vector<uint32_t> len; std::vector<uint16_t> d1, d2;
+        std::vector<uint8_t> t = layout_text(v, k, &off, &len, &d1, &d2);
+        memcpy(text, t.data(), t.size());
+        for (uint32_t i = 0; i < n_seqs; i++) { seq_off[i] = off[i]; seq_d1[i] = d1[i]; seq_d2[i] = d2[i]; }
+    });
+}
+
+int ac_compress_build(uint32_t k, uint32_t assembly_count, const ac_seq_view* seqs, uint32_t n_seqs, int device,
+                      ac_graph** out) {
+    return guarded([&] {
+        validate(k, seqs, n_seqs);
+        select_device(device);
+        auto h = std::make_unique<ac_graph>();
+        std::vector<SeqView> v(n_seqs);
+        for (uint32_t i = 0; i < n_seqs; i++) {
+            v[i] = SeqView{seqs[i].fwd, seqs[i].length};
+            h->seq_ids.push_back(seqs[i].id);
+            h->seq_lens.push_back(seqs[i].length);
+        }
+        GraphBuilder b(k);
+        b.set_sequences_host(v);
+        RawGraph raw;
+        b.build(assembly_count, &raw);
+        h->tm = b.timings();
+        run_host_tail(raw, h->seq_ids, h->seq_lens, &h->g);
+        *out = h.release();
+    });
+}
+
+int ac_compress_build_device(uint32_t k, uint32_t assembly_count, const void* d_text, uint64_t n_text,
+                             const uint64_t* seq_off, const uint32_t* seq_len, const uint16_t* seq_ids,
+                             const uint16_t* seq_d1, const uint16_t* seq_d2, uint32_t n_seqs, int device,
+                             ac_graph** out) {
+    return guarded([&] {
+        if (!d_text || n_seqs == 0) throw DeviceError("no sequences found in input assemblies");
+        if (n_seqs > 32767) throw DeviceError("no more than 32767 input sequences are allowed");
+        select_device(device);
+        auto h = std::make_unique<ac_graph>();
+        std::vector<uint64_t> off(seq_off, seq_off + n_seqs);
+        std::vector<uint32_t> len(seq_len, seq_len + n_seqs);
+        std::vector<uint16_t> d1(seq_d1, seq_d1 + n_seqs), d2(seq_d2, seq_d2 + n_seqs);
+        h->seq_ids.assign(seq_ids, seq_ids + n_seqs);
+        h->seq_lens = len;
+        GraphBuilder b(k);
+        b.set_text_device((const uint8_t*)d_text, n_text, off, len, d1, d2);
+        RawGraph raw;
+        b.build(assembly_count, &raw);
+        h->tm = b.timings();
+        run_host_tail(raw, h->seq_ids, h->seq_lens, &h->g);
+        *out = h.release();
+    });
+}
+
+uint64_t ac_kmer_count(const ac_graph* g) { return g->g.n_kmers; }
+ac_stats ac_stats_pre(const ac_graph* g) { return ac_stats{g->g.pre.unitigs, g->g.pre.links_one_way, g->g.pre.total_length}; }
+ac_stats ac_stats_post(const ac_graph* g) { return ac_stats{g->g.post.unitigs, g->g.post.links_one_way, g->g.post.total_length}; }
+uint32_t ac_unitig_count(const ac_graph* g) { return (uint32_t)g->g.seqs.size(); }
+
+int ac_unitig(const ac_graph* g, uint32_t idx, const uint8_t** seq, uint32_t* len, double* depth) {
+    if (idx >= g->g.seqs.size()) { g_err = "unitig index out of range"; return 1; }
+    if (seq) *seq = (const uint8_t*)g->g.seqs[idx].data();
+    if (len) *len = (uint32_t)g->g.seqs[idx].size();
+    if (depth) *depth = g->g.depth[idx];
+    return 0;
+}
+int ac_unitig_positions(ac_graph* g, uint32_t idx, int forward, const ac_position** positions, uint32_t* n) {
+    if (idx >= g->g.seqs.size()) { g_err = "unitig index out of range"; return 1; }
+    return guarded([&] {
+        if (!g->positions_built) { build_positions(&g->g, g->seq_ids, g->seq_lens); g->positions_built = true; }
+        auto& v = forward ? g->g.fwd_positions[idx] : g->g.rev_positions[idx];
+        static_assert(sizeof(ac_position) == sizeof(Position), "layout");
+        *positions = (const ac_position*)v.data();
+        *n = (uint32_t)v.size();
+    });
+}
+int ac_links(const ac_graph* g, const ac_link** links, uint64_t* n) {
+    static_assert(sizeof(ac_link) == sizeof(Link), "layout");
+    *links = (const ac_link*)g->g.links.data();
+    *n = g->g.links.size();
+    return 0;
+}
+int ac_path(const ac_graph* g, uint32_t seq_index, const int32_t** signed_unitigs, uint32_t* n) {
+    if ((size_t)seq_index + 1 >= g->g.path_off.size()) { g_err = "sequence index out of range"; return 1; }
+    uint64_t b = g->g.path_off[seq_index], e = g->g.path_off[seq_index + 1];
+    *signed_unitigs = g->g.path.data() + b;
+    *n = (uint32_t)(e - b);
+    return 0;
+}
+int ac_timings_get(const ac_graph* g, ac_timings* o) {
+    const BuildTimings& t = g->tm;
+    o->h2d = t.h2d; o->pack = t.pack; o->insert = t.insert; o->collect_sort = t.collect_sort; o->degree = t.degree;
+    o->segment = t.segment; o->minkey = t.minkey; o->rank = t.rank; o->paths = t.paths; o->links = t.links; o->seqs = t.seqs;
+    o->d2h = t.d2h; o->total_device = t.total_device; o->host_tail = g->g.tail_seconds;
+    o->insert_kernel_ms = t.insert_kernel_ms; o->insert_positions = t.insert_positions;
+    o->table_capacity = t.table_capacity; o->n_distinct = t.n_distinct; o->n_path_entries = t.n_path_entries;
+    o->simplify_passes = (uint32_t)g->g.simplify_passes;
+    return 0;
+}
+void ac_free(ac_graph* g) { delete g; }
+
+int ac_gfa_string(const ac_graph* g, const char* const* filenames, const char* const* headers, char** out, uint64_t* out_len) {
+    return guarded([&] {
+        std::vector<SeqMeta> meta(g->seq_ids.size());
+        for (size_t i = 0; i < meta.size(); i++) meta[i] = SeqMeta{g->seq_ids[i], g->seq_lens[i], filenames[i], headers[i]};
+        std::string s = gfa_string(g->g, meta);
+        char* p = (char*)malloc(s.size() + 1);
+        if (!p) throw DeviceError("out of memory");
+        memcpy(p, s.data(), s.size()); p[s.size()] = 0;
+        *out = p;
+        if (out_len) *out_len = s.size();
+    });
+}
+void ac_string_free(char* p) { free(p); }
+
+}  // extern "C"

@@ -1,0 +1,299 @@
+// Thin device runtime used by the graph-build pipeline: buffers, copies, a functor launcher and the
+// plain device primitives (radix sort, scan, reduce-by-key, merge sort) from rocPRIM.
+// HIP build: hipMalloc / hipLaunchKernelGGL / rocPRIM on one stream of one gfx950 device.
+// AC_EMU build (tests only): malloc / serial loops / std:: algorithms.
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "kmer_ops.hpp"
+
+#ifndef AC_EMU
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#endif
+
+namespace ac {
+
+struct DeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#ifndef AC_EMU
+#define AC_HIP_CHECK(expr)                                                                              \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            throw ::ac::DeviceError(std::string("HIP error: ") + hipGetErrorString(_e) + " at " + __FILE__ + ":" + \
+                                    std::to_string(__LINE__) + " (" #expr ")");                        \
+    } while (0)
+typedef hipStream_t stream_t;
+#else
+typedef int stream_t;
+#endif
+
+// ---- atomics --------------------------------------------------------------------------------------
+#ifdef AC_EMU
+inline u64 atomic_cas64(u64* p, u64 expected, u64 desired) { u64 old = *p; if (old == expected) *p = desired; return old; }
+inline void atomic_min64(u64* p, u64 v) { if (v < *p) *p = v; }
+inline u32 atomic_add32(u32* p, u32 v) { u32 o = *p; *p += v; return o; }
+inline u64 atomic_add64(u64* p, u64 v) { u64 o = *p; *p += v; return o; }
+inline void atomic_or32(u32* p, u32 v) { *p |= v; }
+inline void atomic_min32(u32* p, u32 v) { if (v < *p) *p = v; }
+inline void atomic_max32(u32* p, u32 v) { if (v > *p) *p = v; }
+#else
+__device__ inline u64 atomic_cas64(u64* p, u64 expected, u64 desired) {
+    return (u64)atomicCAS((unsigned long long*)p, (unsigned long long)expected, (unsigned long long)desired);
+}
+__device__ inline void atomic_min64(u64* p, u64 v) { atomicMin((unsigned long long*)p, (unsigned long long)v); }
+__device__ inline u32 atomic_add32(u32* p, u32 v) { return atomicAdd(p, v); }
+__device__ inline u64 atomic_add64(u64* p, u64 v) { return (u64)atomicAdd((unsigned long long*)p, (unsigned long long)v); }
+__device__ inline void atomic_or32(u32* p, u32 v) { atomicOr(p, v); }
+__device__ inline void atomic_min32(u32* p, u32 v) { atomicMin(p, v); }
+__device__ inline void atomic_max32(u32* p, u32 v) { atomicMax(p, v); }
+#endif
+
+// ---- buffers --------------------------------------------------------------------------------------
+template <class T>
+class DBuf {
+  public:
+    DBuf() {}
+    explicit DBuf(size_t n, bool zero = false) { alloc(n, zero); }
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
+    DBuf(DBuf&& o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+    DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { release(); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; } return *this; }
+    ~DBuf() { release(); }
+    void alloc(size_t n, bool zero = false) {
+        release();
+        n_ = n;
+        size_t bytes = (n ? n : 1) * sizeof(T);
+#ifdef AC_EMU
+        p_ = (T*)malloc(bytes);
+        if (!p_) throw DeviceError("emu malloc failed");
+        if (zero) memset(p_, 0, bytes);
+#else
+        AC_HIP_CHECK(hipMalloc((void**)&p_, bytes));
+        if (zero) AC_HIP_CHECK(hipMemsetAsync(p_, 0, bytes, 0));
+#endif
+    }
+    void fill_bytes(int byte, stream_t s = 0) {
+        size_t bytes = n_ * sizeof(T);
+#ifdef AC_EMU
+        memset(p_, byte, bytes);
+#else
+        AC_HIP_CHECK(hipMemsetAsync(p_, byte, bytes, s));
+#endif
+    }
+    void release() {
+        if (p_) {
+#ifdef AC_EMU
+            free(p_);
+#else
+            (void)hipFree(p_);
+#endif
+        }
+        p_ = nullptr; n_ = 0;
+    }
+    T* ptr() { return p_; }
+    const T* ptr() const { return p_; }
+    size_t size() const { return n_; }
+    size_t bytes() const { return n_ * sizeof(T); }
+
+  private:
+    T* p_ = nullptr;
+    size_t n_ = 0;
+};
+
+inline void copy_h2d(void* d, const void* h, size_t bytes, stream_t s = 0) {
+    if (!bytes) return;
+#ifdef AC_EMU
+    memcpy(d, h, bytes);
+#else
+    AC_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
+#endif
+}
+inline void copy_d2h(void* h, const void* d, size_t bytes, stream_t s = 0) {
+    if (!bytes) return;
+#ifdef AC_EMU
+    memcpy(h, d, bytes);
+#else
+    AC_HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s));
+    AC_HIP_CHECK(hipStreamSynchronize(s));
+#endif
+}
+inline void copy_d2d(void* dst, const void* src, size_t bytes, stream_t s = 0) {
+    if (!bytes) return;
+#ifdef AC_EMU
+    memmove(dst, src, bytes);
+#else
+    AC_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+#endif
+}
+inline void stream_sync(stream_t s = 0) {
+#ifndef AC_EMU
+    AC_HIP_CHECK(hipStreamSynchronize(s));
+#endif
+}
+template <class T> std::vector<T> to_host(const DBuf<T>& b, size_t n, stream_t s = 0) {
+    std::vector<T> v(n);
+    copy_d2h(v.data(), b.ptr(), n * sizeof(T), s);
+    return v;
+}
+template <class T> T read_scalar(const T* dptr, stream_t s = 0) {
+    T v;
+    copy_d2h(&v, dptr, sizeof(T), s);
+    return v;
+}
+
+// ---- functor launcher -----------------------------------------------------------------------------
+// One logical thread per index, 256-thread workgroups (4 wavefronts); every launch in the pipeline
+// has >> 256 workgroups at the benchmark sizes, so the 256 CUs / 8 XCDs fill from the grid alone.
+#ifndef AC_EMU
+template <class F>
+__global__ void __launch_bounds__(256) functor_kernel(u64 n, F f) {
+    u64 tid = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (tid < n) f(tid);
+}
+#endif
+template <class F> void launch(u64 n, const F& f, stream_t s = 0) {
+    if (n == 0) return;
+#ifdef AC_EMU
+    for (u64 i = 0; i < n; i++) f(i);
+#else
+    u64 blocks = (n + 255) / 256;
+    if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+    hipLaunchKernelGGL(functor_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, s, n, f);
+    AC_HIP_CHECK(hipGetLastError());
+#endif
+}
+
+// ---- device primitives ----------------------------------------------------------------------------
+// Stable LSD radix sort of (u64 key, u32 value) pairs on key bits [0, end_bit).
+inline void sort_pairs_u64_u32(DBuf<u64>& keys, DBuf<u32>& vals, size_t n, int end_bit, stream_t s = 0) {
+    if (n <= 1) return;
+#ifdef AC_EMU
+    std::vector<size_t> idx(n);
+    for (size_t i = 0; i < n; i++) idx[i] = i;
+    u64* k = keys.ptr(); u32* v = vals.ptr();
+    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return k[a] < k[b]; });
+    std::vector<u64> k2(n); std::vector<u32> v2(n);
+    for (size_t i = 0; i < n; i++) { k2[i] = k[idx[i]]; v2[i] = v[idx[i]]; }
+    memcpy(k, k2.data(), n * 8); memcpy(v, v2.data(), n * 4);
+    (void)end_bit;
+#else
+    DBuf<u64> k2(n); DBuf<u32> v2(n);
+    size_t tmp_bytes = 0;
+    AC_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, 0, end_bit, s));
+    DBuf<u8> tmp(tmp_bytes);
+    AC_HIP_CHECK(rocprim::radix_sort_pairs(tmp.ptr(), tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, 0, end_bit, s));
+    AC_HIP_CHECK(hipStreamSynchronize(s));
+    keys = std::move(k2);
+    vals = std::move(v2);
+#endif
+}
+inline void sort_pairs_u64_i32(DBuf<u64>& keys, DBuf<int32_t>& vals, size_t n, int end_bit, stream_t s = 0) {
+    if (n <= 1) return;
+#ifdef AC_EMU
+    std::vector<size_t> idx(n);
+    for (size_t i = 0; i < n; i++) idx[i] = i;
+    u64* k = keys.ptr(); int32_t* v = vals.ptr();
+    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return k[a] < k[b]; });
+    std::vector<u64> k2(n); std::vector<int32_t> v2(n);
+    for (size_t i = 0; i < n; i++) { k2[i] = k[idx[i]]; v2[i] = v[idx[i]]; }
+    memcpy(k, k2.data(), n * 8); memcpy(v, v2.data(), n * 4);
+    (void)end_bit;
+#else
+    DBuf<u64> k2(n); DBuf<int32_t> v2(n);
+    size_t tmp_bytes = 0;
+    AC_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, 0, end_bit, s));
+    DBuf<u8> tmp(tmp_bytes);
+    AC_HIP_CHECK(rocprim::radix_sort_pairs(tmp.ptr(), tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, 0, end_bit, s));
+    AC_HIP_CHECK(hipStreamSynchronize(s));
+    keys = std::move(k2);
+    vals = std::move(v2);
+#endif
+}
+
+inline void inclusive_scan_u32(const u32* in, u32* out, size_t n, stream_t s = 0) {
+    if (!n) return;
+#ifdef AC_EMU
+    u32 acc = 0;
+    for (size_t i = 0; i < n; i++) { acc += in[i]; out[i] = acc; }
+#else
+    size_t tmp_bytes = 0;
+    AC_HIP_CHECK(rocprim::inclusive_scan(nullptr, tmp_bytes, in, out, n, rocprim::plus<u32>(), s));
+    DBuf<u8> tmp(tmp_bytes);
+    AC_HIP_CHECK(rocprim::inclusive_scan(tmp.ptr(), tmp_bytes, in, out, n, rocprim::plus<u32>(), s));
+    AC_HIP_CHECK(hipStreamSynchronize(s));
+#endif
+}
+inline void exclusive_scan_u64(const u64* in, u64* out, size_t n, stream_t s = 0) {
+    if (!n) return;
+#ifdef AC_EMU
+    u64 acc = 0;
+    for (size_t i = 0; i < n; i++) { u64 v = in[i]; out[i] = acc; acc += v; }
+#else
+    size_t tmp_bytes = 0;
+    AC_HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, (u64)0, n, rocprim::plus<u64>(), s));
+    DBuf<u8> tmp(tmp_bytes);
+    AC_HIP_CHECK(rocprim::exclusive_scan(tmp.ptr(), tmp_bytes, in, out, (u64)0, n, rocprim::plus<u64>(), s));
+    AC_HIP_CHECK(hipStreamSynchronize(s));
+#endif
+}
+
+// Segmented reduction of `vals` over runs of equal consecutive `seg` ids (ids are 0,1,2,... in order,
+// so run r reduces into out[r]).
+template <class V, class Op>
+inline void reduce_by_segment(const u32* seg, const V* vals, size_t n, V* out, size_t n_segments, Op op, stream_t s = 0) {
+    if (!n) return;
+#ifdef AC_EMU
+    size_t r = 0;
+    for (size_t i = 0; i < n;) {
+        V acc = vals[i];
+        size_t j = i + 1;
+        while (j < n && seg[j] == seg[i]) { acc = op(acc, vals[j]); j++; }
+        out[r++] = acc;
+        i = j;
+    }
+    if (r != n_segments) throw DeviceError("reduce_by_segment: segment count mismatch");
+#else
+    DBuf<u32> uniq(n_segments);
+    DBuf<u32> cnt(1);
+    size_t tmp_bytes = 0;
+    AC_HIP_CHECK(rocprim::reduce_by_key(nullptr, tmp_bytes, seg, vals, n, uniq.ptr(), out, cnt.ptr(), op, rocprim::equal_to<u32>(), s));
+    DBuf<u8> tmp(tmp_bytes);
+    AC_HIP_CHECK(rocprim::reduce_by_key(tmp.ptr(), tmp_bytes, seg, vals, n, uniq.ptr(), out, cnt.ptr(), op, rocprim::equal_to<u32>(), s));
+    u32 c = read_scalar(cnt.ptr(), s);
+    if (c != n_segments) throw DeviceError("reduce_by_segment: segment count mismatch");
+#endif
+}
+
+// Sort (key struct, u32 value) pairs with a comparator.
+template <class K, class Cmp>
+inline void sort_by_key_cmp(DBuf<K>& keys, DBuf<u32>& vals, size_t n, Cmp cmp, stream_t s = 0) {
+    if (n <= 1) return;
+#ifdef AC_EMU
+    std::vector<size_t> idx(n);
+    for (size_t i = 0; i < n; i++) idx[i] = i;
+    K* k = keys.ptr(); u32* v = vals.ptr();
+    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return cmp(k[a], k[b]); });
+    std::vector<K> k2(n); std::vector<u32> v2(n);
+    for (size_t i = 0; i < n; i++) { k2[i] = k[idx[i]]; v2[i] = v[idx[i]]; }
+    memcpy(k, k2.data(), n * sizeof(K)); memcpy(v, v2.data(), n * 4);
+#else
+    DBuf<K> k2(n); DBuf<u32> v2(n);
+    size_t tmp_bytes = 0;
+    AC_HIP_CHECK(rocprim::merge_sort(nullptr, tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, cmp, s));
+    DBuf<u8> tmp(tmp_bytes);
+    AC_HIP_CHECK(rocprim::merge_sort(tmp.ptr(), tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, cmp, s));
+    AC_HIP_CHECK(hipStreamSynchronize(s));
+    keys = std::move(k2);
+    vals = std::move(v2);
+#endif
+}
+
+}  // namespace ac

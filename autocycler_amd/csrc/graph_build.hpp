@@ -1,0 +1,76 @@
+// Device graph build for the `autocycler compress` hot path: k-mer set -> unitigs -> links -> paths.
+// Replaces KmerGraph::add_sequences (kmer_graph.rs:86-134), UnitigGraph::build_unitigs_from_kmer_graph
+// + simplify_seqs + create_links' neighbour discovery + trim_overlaps (unitig_graph.rs:176-293) and the
+// per-sequence path walk (unitig_graph.rs:407-465).  Output is the compacted graph in *seed order*
+// (reference's initial unitig numbering: rank of each unitig's smallest k-mer, unitig_graph.rs:176-226
+// with kmer_graph.rs:168-173); the order-dependent tail (link push order, renumber, expand_repeats) is
+// host_tail.cpp.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace ac {
+
+struct SeqView {          // one padded, end-repaired forward sequence as at compress.rs:41
+    const uint8_t* fwd;   // length + k - 1 bytes over ".ACGT"
+    uint32_t length;      // unpadded length (number of forward k-mers)
+};
+
+struct RawGraph {
+    uint32_t k = 0;
+    uint64_t n_kmers = 0;               // KmerGraph.kmers.len(): both strands (compress.rs:152)
+    uint32_t n_unitigs = 0;
+    std::vector<uint32_t> len;          // per unitig (seed order): k-mer count == trimmed length
+    std::vector<uint32_t> depth;        // occurrences (unitig.rs:149-156: always integral)
+    std::vector<uint32_t> minpos_fwd;   // min p.pos over forward_positions / reverse_positions
+    std::vector<uint32_t> minpos_rev;   //   (all graph_simplification.rs:164-181 ever asks of them)
+    std::vector<uint64_t> seq_off;      // n_unitigs + 1
+    std::string seqs;                   // concatenated trimmed forward sequences
+    std::vector<uint8_t> link_cnt;      // [2*u + side]: side 0 = forward strand end, 1 = reverse strand end
+    std::vector<int32_t> links;         // [(2*u + side)*5 + j]: signed seed numbers (+: forward strand)
+    std::vector<uint64_t> path_off;     // n_seqs + 1
+    std::vector<int32_t> path;          // signed seed numbers per sequence, in order (unitig_graph.rs:447-465)
+};
+
+struct BuildTimings {                   // seconds; device stages are bracketed by stream syncs
+    double h2d = 0, pack = 0, insert = 0, collect_sort = 0, degree = 0, segment = 0, minkey = 0, rank = 0,
+           paths = 0, links = 0, seqs = 0, d2h = 0, total_device = 0;
+    double insert_kernel_ms = 0;        // event-timed duration of the dominant kernel (k-mer insert)
+    uint64_t insert_positions = 0;      // text positions streamed by that launch
+    uint64_t table_capacity = 0;
+    uint64_t n_distinct = 0;
+    uint64_t n_path_entries = 0;
+};
+
+class GraphBuilder {
+  public:
+    explicit GraphBuilder(uint32_t k);
+    ~GraphBuilder();
+    // Host entry: lays the sequences out as one text ('$' separators), copies it to the device.
+    void set_sequences_host(const std::vector<SeqView>& seqs);
+    // Device entry: `d_text` is an ASCII text already resident in HBM with the same layout:
+    // text[0] = '$', then for each sequence its padded bytes followed by one '$'.
+    // off[s] = index of the first padded byte of sequence s.  d1/d2 = leading/trailing dot counts.
+    void set_text_device(const uint8_t* d_text, uint64_t n_text, const std::vector<uint64_t>& off,
+                         const std::vector<uint32_t>& len, const std::vector<uint16_t>& d1,
+                         const std::vector<uint16_t>& d2);
+    // The timed region: packed text -> RawGraph (host).
+    void build(uint32_t assembly_count_hint, RawGraph* out);
+    const BuildTimings& timings() const { return tm_; }
+    uint64_t n_text() const;
+    uint64_t n_bases() const;   // sum of unpadded lengths
+
+  private:
+    struct Impl;
+    Impl* impl_;
+    BuildTimings tm_;
+};
+
+// Builds the text layout used by both entries.  Returns the text; fills off/len/d1/d2.
+std::vector<uint8_t> layout_text(const std::vector<SeqView>& seqs, uint32_t k, std::vector<uint64_t>* off,
+                                 std::vector<uint32_t>* len, std::vector<uint16_t>* d1, std::vector<uint16_t>* d2);
+
+int max_supported_k();
+
+}  // namespace ac

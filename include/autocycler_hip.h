@@ -1,0 +1,101 @@
+/* autocycler_hip.h — C ABI of libautocycler_hip.so, the MI355X (gfx950) drop-in for the hot path of
+ * `autocycler compress` (rrwick/Autocycler v0.7.0).
+ *
+ * The reference has no FFI or plugin interface; the seam is cut in src/compress.rs:42-44:
+ *
+ *     let kmer_graph = build_kmer_graph(k_size, assembly_count, &sequences);   // KmerGraph::add_sequences, kmer_graph.rs:86-134
+ *     let mut unitig_graph = build_unitig_graph(kmer_graph);                   // UnitigGraph::from_kmer_graph, unitig_graph.rs:36-48
+ *     simplify_unitig_graph(&mut unitig_graph, &sequences);                    // simplify_structure, graph_simplification.rs:26-40
+ *
+ * ac_compress_build() replaces those three calls; the accessors hand back exactly what the consumers
+ * (save_gfa unitig_graph.rs:317-331, save_metrics compress.rs:181-189, print_basic_graph_info
+ * unitig_graph.rs:509-516) read.  INTEGRATION.md shows the Rust `extern "C"` block and the patch.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types.  Every function returning int returns 0 on
+ * success and non-zero on failure; ac_last_error() then holds the text the Rust shim should pass to
+ * quit_with_error (misc.rs:131-137).  The library never exits, aborts or unwinds across the ABI.
+ * Inputs are only read during the call (the reference's raw pointers into Sequence buffers,
+ * kmer_graph.rs:30,115, need not outlive it).  Results are owned by the handle until ac_free().
+ * There is no CPU fallback: without a usable gfx950 device every build call fails with an error.
+ */
+#ifndef AUTOCYCLER_HIP_H
+#define AUTOCYCLER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ac_graph ac_graph; /* opaque: the final unitig graph (UnitigGraph after simplify_structure) */
+
+/* One loaded sequence as `load_sequences` returns it (compress.rs:98-133, sequence.rs:19-59). */
+typedef struct {
+    const uint8_t* fwd; /* Sequence::forward_seq: padded + end-repaired, length + k - 1 bytes over ".ACGT" */
+    uint32_t length;    /* Sequence::length (unpadded) */
+    uint16_t id;        /* Sequence::id (1-based; gaps allowed, compress.rs:111,120) */
+} ac_seq_view;
+
+typedef struct { uint32_t pos; uint16_t seq_id_and_strand; } ac_position; /* position.rs:18-22; strand = bit 15 */
+typedef struct { uint32_t a; uint8_t a_fwd; uint32_t b; uint8_t b_fwd; } ac_link;
+typedef struct { uint32_t unitigs; uint64_t links_one_way; uint64_t total_length; } ac_stats;
+
+/* Seconds spent in each stage of the last build (device stages are bracketed by stream syncs). */
+typedef struct {
+    double h2d, pack, insert, collect_sort, degree, segment, minkey, rank, paths, links, seqs, d2h;
+    double total_device; /* pack .. d2h */
+    double host_tail;    /* link order + renumber + expand_repeats + renumber on the host */
+    double insert_kernel_ms;    /* HIP-event duration of the dominant kernel (k-mer insert), last launch */
+    uint64_t insert_positions;  /* text positions that launch streamed */
+    uint64_t table_capacity, n_distinct, n_path_entries;
+    uint32_t simplify_passes;
+} ac_timings;
+
+/* Replaces compress.rs:42-44.  k: --kmer (odd).  assembly_count: the reference's capacity hint
+ * (kmer_graph.rs:40), used the same way (initial table sizing).  device: HIP device ordinal. */
+int ac_compress_build(uint32_t k, uint32_t assembly_count, const ac_seq_view* seqs, uint32_t n_seqs, int device,
+                      ac_graph** out);
+
+/* Same, for a text that is already resident in device memory (benchmarks, multi-GPU shards):
+ * d_text[0] = '$', then for every sequence its padded bytes followed by one '$'; n_text bytes in total.
+ * seq_off[s] = index of the first padded byte of sequence s (host array). */
+int ac_compress_build_device(uint32_t k, uint32_t assembly_count, const void* d_text, uint64_t n_text,
+                             const uint64_t* seq_off, const uint32_t* seq_len, const uint16_t* seq_ids,
+                             const uint16_t* seq_d1, const uint16_t* seq_d2, uint32_t n_seqs, int device,
+                             ac_graph** out);
+
+/* Host helper: lay sequences out as the text described above.  text must hold ac_text_size() bytes. */
+uint64_t ac_text_size(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs);
+int ac_layout_text(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs, uint8_t* text, uint64_t* seq_off,
+                   uint16_t* seq_d1, uint16_t* seq_d2);
+
+uint64_t ac_kmer_count(const ac_graph*);                 /* KmerGraph.kmers.len(), both strands (compress.rs:152) */
+ac_stats ac_stats_pre(const ac_graph*);                  /* print_basic_graph_info after from_kmer_graph (compress.rs:165) */
+ac_stats ac_stats_post(const ac_graph*);                 /* ... and after simplify_structure (compress.rs:177) */
+uint32_t ac_unitig_count(const ac_graph*);
+/* Unitig idx (0-based, final order; Unitig::number == idx + 1): forward_seq, length, depth. */
+int ac_unitig(const ac_graph*, uint32_t idx, const uint8_t** seq, uint32_t* len, double* depth);
+/* Unitig::forward_positions / reverse_positions as from_gfa_lines rebuilds them (unitig_graph.rs:151-174). */
+int ac_unitig_positions(ac_graph*, uint32_t idx, int forward, const ac_position** positions, uint32_t* n);
+int ac_links(const ac_graph*, const ac_link** links, uint64_t* n);   /* get_links_for_gfa order (unitig_graph.rs:333-350) */
+/* get_unitig_path_for_sequence_i32 (unitig_graph.rs:467-472) of the seq_index-th input sequence. */
+int ac_path(const ac_graph*, uint32_t seq_index, const int32_t** signed_unitigs, uint32_t* n);
+int ac_timings_get(const ac_graph*, ac_timings* out);
+void ac_free(ac_graph*);
+
+/* The GFA text save_gfa would write (unitig_graph.rs:317-331): H, S*, L*, P* lines.  filenames/headers:
+ * Sequence::filename / contig_header per input sequence (FN:Z / HD:Z tags).  Free with ac_string_free. */
+int ac_gfa_string(const ac_graph*, const char* const* filenames, const char* const* headers, char** out,
+                  uint64_t* out_len);
+void ac_string_free(char*);
+
+const char* ac_last_error(void);
+int ac_device_count(void);       /* number of visible HIP devices (0 if none / no driver) */
+uint32_t ac_max_kmer(void);      /* largest --kmer this build supports */
+const char* ac_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,13 @@
+"""Builds and locates the serial CPU emulation of the kernels (tests only; see csrc/Makefile `emu`)."""
+import subprocess
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+EMU = ROOT / "tests" / "_emu" / "libautocycler_emu.so"
+
+
+def emu_path():
+    srcs = list((ROOT / "autocycler_amd" / "csrc").glob("*.[ch]*")) + [ROOT / "include" / "autocycler_hip.h"]
+    if not EMU.exists() or any(s.stat().st_mtime > EMU.stat().st_mtime for s in srcs):
+        subprocess.check_call(["make", "-C", str(ROOT / "autocycler_amd" / "csrc"), "emu"], stdout=subprocess.DEVNULL)
+    return EMU

@@ -1,0 +1,53 @@
+"""GPU parity tests proper: libautocycler_hip.so (through the C ABI) against the oracle on the same seeded
+inputs — GFA text byte-for-byte plus every printed statistic."""
+import pytest
+
+import parity_util
+import seqgen
+from test_oracle_kats import FIXED
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_lib():
+    import autocycler_amd
+    lib = autocycler_amd.load_library()       # raises HipLibraryMissing: the product has no fallback
+    assert lib.ac_device_count() >= 1, "no HIP device visible"
+
+
+@pytest.mark.parametrize("k", [3, 5, 9, 13, 51])
+def test_fixed_seqs(k):   # tests.rs:131-148 inputs
+    parity_util.check_case(k, [FIXED[c] for c in "abcde"], ["a.fasta", "b.fna", "c.fa", "d.fasta.gz", "e.fna.gz"], list("abcde"))
+
+
+@pytest.mark.parametrize("k", [5, 11, 31, 51])
+@pytest.mark.parametrize("seed", range(24))
+def test_adversarial_cases(k, seed):
+    seqs, fn, hd = seqgen.make_case(seed, k)
+    parity_util.check_case(k, seqs, fn, hd, repair=True)
+    parity_util.check_case(k, seqs, fn, hd, repair=False)
+
+
+@pytest.mark.parametrize("k", [27, 29, 59, 61, 91, 93, 123])
+def test_key_word_boundaries(k):
+    for seed in (1, 2, 6, 7):
+        seqs, fn, hd = seqgen.make_case(seed, k)
+        parity_util.check_case(k, seqs, fn, hd)
+
+
+def _synth_case(n, genome, plasmid, sub, indel, seed):
+    from autocycler_amd import synth
+    seqs, fn, hd = [], [], []
+    for i, contigs in enumerate(synth.make_assemblies(n, genome=genome, plasmid=plasmid, sub=sub, indel=indel, seed=seed)):
+        for header, s in contigs:
+            seqs.append(s.tobytes().decode()); fn.append(f"assembly_{i:04d}.fasta"); hd.append(header)
+    return seqs, fn, hd
+
+
+@pytest.mark.parametrize("k", [51, 101])
+def test_synthetic_assemblies_medium(k):
+    # scaled-down replica of configs B / D': 8 assemblies of a 200 kbp genome with planted repeats
+    seqs, fn, hd = _synth_case(8, 200_000, 8_000, 1e-3, 1e-4, 4242)
+    g, gfa, _ = parity_util.check_case(k, seqs, fn, hd)
+    assert g.stats_post["unitigs"] > 100

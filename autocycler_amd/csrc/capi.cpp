@@ -10,6 +10,10 @@
 #include "graph_build.hpp"
 #include "host_tail.hpp"
 #include "gfa_writer.hpp"
+#include "host_io.hpp"
+#include <filesystem>
+#include <fstream>
+#include <chrono>
 #include "device_rt.hpp"
 
 using namespace ac;
@@ -22,6 +26,16 @@ struct ac_graph {
     std::vector<uint16_t> seq_ids;
     std::vector<uint32_t> seq_lens;
     bool positions_built = false;
+};
+
+struct ac_seqs {
+    LoadResult lr;
+    std::vector<ac_seq_view> views;
+    void make_views() {
+        views.resize(lr.seqs.size());
+        for (size_t i = 0; i < views.size(); i++)
+            views[i] = ac_seq_view{(const uint8_t*)lr.seqs[i].forward_seq.data(), lr.seqs[i].length, lr.seqs[i].id};
+    }
 };
 
 template <class F> static int guarded(F&& f) {
@@ -201,5 +215,100 @@ int ac_gfa_string(const ac_graph* g, const char* const* filenames, const char* c
     });
 }
 void ac_string_free(char* p) { free(p); }
+
+// ---- host side: load_sequences / end repair / whole command ---------------------------------------------
+int ac_seqs_load(const char* assemblies_dir, uint32_t k, uint32_t max_contigs, int threads, ac_seqs** out) {
+    return guarded([&] {
+        auto h = std::make_unique<ac_seqs>();
+        h->lr = load_sequences(assemblies_dir, k, max_contigs, threads);
+        h->make_views();
+        *out = h.release();
+    });
+}
+int ac_seqs_from_raw(uint32_t k, uint32_t n, const uint8_t* const* seqs, const uint32_t* lens, const char* const* filenames,
+                     const char* const* headers, uint32_t assembly_count, int repair, int threads, ac_seqs** out) {
+    return guarded([&] {
+        auto h = std::make_unique<ac_seqs>();
+        if (n > 32767) throw UserError("no more than 32767 input sequences are allowed");
+        for (uint32_t i = 0; i < n; i++) {
+            LoadedSeq s;
+            s.id = (uint16_t)(i + 1);
+            s.filename = filenames ? filenames[i] : ("assembly_" + std::to_string(i) + ".fasta");
+            s.contig_header = headers ? headers[i] : ("contig_" + std::to_string(i + 1));
+            pad_sequence(&s, std::string((const char*)seqs[i], lens[i]), k);
+            h->lr.seqs.push_back(std::move(s));
+        }
+        h->lr.assembly_count = assembly_count;
+        h->lr.total_contigs_seen = n;
+        auto t0 = std::chrono::steady_clock::now();
+        if (repair) sequence_end_repair(h->lr.seqs, k, threads);
+        h->lr.repair_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        h->make_views();
+        *out = h.release();
+    });
+}
+uint32_t ac_seqs_count(const ac_seqs* s) { return (uint32_t)s->lr.seqs.size(); }
+uint32_t ac_seqs_assembly_count(const ac_seqs* s) { return s->lr.assembly_count; }
+const ac_seq_view* ac_seqs_views(const ac_seqs* s) { return s->views.data(); }
+int ac_seqs_get(const ac_seqs* s, uint32_t i, ac_seq_view* view, const char** filename, const char** header) {
+    if (i >= s->lr.seqs.size()) { g_err = "sequence index out of range"; return 1; }
+    if (view) *view = s->views[i];
+    if (filename) *filename = s->lr.seqs[i].filename.c_str();
+    if (header) *header = s->lr.seqs[i].contig_header.c_str();
+    return 0;
+}
+double ac_seqs_repair_seconds(const ac_seqs* s) { return s->lr.repair_seconds; }
+int ac_seqs_metrics_yaml(const ac_seqs* s, uint32_t unitig_count, uint64_t unitig_total_length, char** out) {
+    return guarded([&] {
+        std::string y = metrics_yaml(s->lr, unitig_count, unitig_total_length);
+        char* p = (char*)malloc(y.size() + 1);
+        if (!p) throw DeviceError("out of memory");
+        memcpy(p, y.data(), y.size() + 1);
+        *out = p;
+    });
+}
+void ac_seqs_free(ac_seqs* s) { delete s; }
+
+int ac_compress_seqs(uint32_t k, const ac_seqs* s, int device, ac_graph** out) {
+    return ac_compress_build(k, s->lr.assembly_count, s->views.data(), (uint32_t)s->views.size(), device, out);
+}
+
+// compress.rs:32-50: the whole `autocycler compress` command.  times[4] = load, repair, graph (hot path), write.
+int ac_compress_dir(const char* assemblies_dir, const char* autocycler_dir, uint32_t k, uint32_t max_contigs, int threads,
+                    int device, ac_graph** graph_out, double* times) {
+    return guarded([&] {
+        namespace fs = std::filesystem;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        check_compress_settings(assemblies_dir, autocycler_dir, k, threads);
+        std::error_code ec;
+        fs::create_directories(autocycler_dir, ec);
+        if (ec) throw UserError(std::string("failed to create directory ") + autocycler_dir + "\n" + ec.message());
+        ac_seqs s;
+        s.lr = load_sequences(assemblies_dir, k, max_contigs, threads);
+        s.make_views();
+        double t0 = now();
+        ac_graph* g = nullptr;
+        if (ac_compress_build(k, s.lr.assembly_count, s.views.data(), (uint32_t)s.views.size(), device, &g) != 0)
+            throw DeviceError(g_err);
+        std::unique_ptr<ac_graph> guard(g);
+        double t1 = now();
+        std::vector<SeqMeta> meta(s.lr.seqs.size());
+        for (size_t i = 0; i < meta.size(); i++) meta[i] = SeqMeta{s.lr.seqs[i].id, s.lr.seqs[i].length, s.lr.seqs[i].filename, s.lr.seqs[i].contig_header};
+        {
+            std::string gfa = gfa_string(g->g, meta);
+            std::ofstream f(fs::path(autocycler_dir) / "input_assemblies.gfa", std::ios::binary);
+            f.write(gfa.data(), (std::streamsize)gfa.size());
+            if (!f) throw UserError("failed to write input_assemblies.gfa");
+        }
+        {
+            std::string y = metrics_yaml(s.lr, g->g.post.unitigs, g->g.post.total_length);
+            std::ofstream f(fs::path(autocycler_dir) / "input_assemblies.yaml", std::ios::binary);
+            f.write(y.data(), (std::streamsize)y.size());
+        }
+        double t2 = now();
+        if (times) { times[0] = s.lr.load_seconds; times[1] = s.lr.repair_seconds; times[2] = t1 - t0; times[3] = t2 - t1; }
+        if (graph_out) *graph_out = guard.release();
+    });
+}
 
 }  // extern "C"

@@ -1,0 +1,349 @@
+// See host_io.hpp.
+#include "host_io.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <map>
+#include <set>
+#include <thread>
+#include <unordered_map>
+
+namespace fs = std::filesystem;
+
+namespace ac {
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static bool has_suffix(const std::string& s, const char* suf) {
+    size_t n = strlen(suf);
+    return s.size() >= n && memcmp(s.data() + s.size() - n, suf, n) == 0;
+}
+
+// misc.rs:65-96.  `a && b || c || d` in the reference makes any file whose stem ends in .fna/.fa qualify.
+std::vector<std::string> find_all_assemblies(const std::string& dir) {
+    std::error_code ec;
+    fs::directory_iterator it(dir, ec);
+    if (ec) throw UserError("unable to read directory " + dir + "\n" + ec.message());
+    std::vector<std::string> found;
+    for (const auto& entry : it) {
+        const fs::path& p = entry.path();
+        if (!fs::is_regular_file(p)) continue;
+        std::string ext = p.extension().string(), stem = p.stem().string();
+        bool ok = ext == ".fasta" || ext == ".fna" || ext == ".fa" || (ext == ".gz" && has_suffix(stem, ".fasta")) ||
+                  has_suffix(stem, ".fna") || has_suffix(stem, ".fa");
+        if (ok) found.push_back(p.string());
+    }
+    std::sort(found.begin(), found.end());
+    if (found.empty()) throw UserError("no assemblies found in " + dir);
+    return found;
+}
+
+static std::string slurp(const std::string& filename) {
+    unsigned char magic[2] = {0, 0};
+    {
+        FILE* f = fopen(filename.c_str(), "rb");
+        if (!f) throw UserError("unable to open " + filename);
+        size_t n = fread(magic, 1, 2, f);
+        fclose(f);
+        if (n < 2) magic[0] = 0;
+    }
+    std::string data;
+    if (magic[0] == 0x1f && magic[1] == 0x8b) {   // gzip, multi-member like flate2's MultiGzDecoder (misc.rs:323)
+        gzFile g = gzopen(filename.c_str(), "rb");
+        if (!g) throw UserError("unable to load " + filename);
+        gzbuffer(g, 1 << 20);
+        std::vector<char> buf(1 << 20);
+        int r;
+        while ((r = gzread(g, buf.data(), (unsigned)buf.size())) > 0) data.append(buf.data(), (size_t)r);
+        gzclose(g);
+        if (r < 0) throw UserError("unable to load " + filename);
+    } else {
+        std::ifstream in(filename, std::ios::binary | std::ios::ate);
+        if (!in) throw UserError("unable to load " + filename);
+        std::streamsize sz = in.tellg();
+        in.seekg(0);
+        data.resize((size_t)sz);
+        in.read(&data[0], sz);
+    }
+    return data;
+}
+
+// misc.rs:145-195,282-355
+std::vector<std::array<std::string, 3>> load_fasta(const std::string& filename) {
+    std::error_code ec;
+    auto sz = fs::file_size(filename, ec);
+    if (!ec && sz == 0) throw UserError(filename + " is an empty file");
+    std::string data = slurp(filename);
+    std::vector<std::array<std::string, 3>> recs;
+    bool have = false;
+    std::string name, header, seq;
+    auto finish = [&] {
+        for (char& c : seq) if (c >= 'a' && c <= 'z') c = (char)(c - 32);
+        recs.push_back({name, header, std::move(seq)});
+        seq.clear();
+    };
+    size_t pos = 0, n = data.size();
+    while (pos < n) {
+        const char* nl = (const char*)memchr(data.data() + pos, '\n', n - pos);
+        size_t eol = nl ? (size_t)(nl - data.data()) : n;
+        size_t end = eol;
+        if (end > pos && data[end - 1] == '\r') end--;
+        if (end > pos) {
+            if (data[pos] == '>') {
+                if (have) finish();
+                header.assign(data, pos + 1, end - pos - 1);
+                size_t a = 0;
+                while (a < header.size() && isspace((unsigned char)header[a])) a++;
+                size_t b = a;
+                while (b < header.size() && !isspace((unsigned char)header[b])) b++;
+                if (b == a) throw UserError(filename + " is not correctly formatted");
+                name.assign(header, a, b - a);
+                have = true;
+            } else {
+                if (!have) throw UserError(filename + " is not correctly formatted");
+                seq.append(data, pos, end - pos);
+            }
+        }
+        pos = eol + 1;
+    }
+    if (have) finish();
+    if (recs.empty()) throw UserError(filename + " contains no sequences");
+    std::set<std::string> names;
+    for (auto& r : recs) {
+        if (r[0].empty()) throw UserError(filename + " has an unnamed sequence");
+        if (r[2].empty()) throw UserError(filename + " has an empty sequence");
+    }
+    for (auto& r : recs)
+        if (!names.insert(r[0]).second) throw UserError(filename + " has a duplicate name: " + r[0]);
+    return recs;
+}
+
+// sequence.rs:31-59
+void pad_sequence(LoadedSeq* s, const std::string& seq, uint32_t k) {
+    for (char c : seq)
+        if (c != 'A' && c != 'C' && c != 'G' && c != 'T') throw UserError(s->filename + " contains non-ACGT characters");
+    uint32_t h = k / 2;
+    s->forward_seq.clear();
+    s->forward_seq.reserve(seq.size() + 2 * h);
+    s->forward_seq.append(h, '.');
+    s->forward_seq.append(seq);
+    s->forward_seq.append(h, '.');
+    s->length = (uint32_t)seq.size();
+}
+
+static inline char comp_char(char c) {
+    switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; case '.': return '.'; default: return 'N'; }
+}
+
+// compress.rs:202-270.  The reference compiles, per sequence, the first and the last k-1 padded characters
+// ('.' = wildcard) into regexes and scans every forward and reverse sequence with each (4·S·B byte steps).
+// Here all 2S literal halves are indexed once and every haystack is scanned once with a rolling hash; the
+// per-pattern leftmost-non-overlapping rule of find_iter and find_best_match's ordering (fewest dots, most
+// frequent, alphabetically first) are applied exactly.
+void sequence_end_repair(std::vector<LoadedSeq>& seqs, uint32_t k, int threads) {
+    const size_t m = k - 1, h = k / 2;
+    if (m == 0 || seqs.empty()) return;
+    const size_t S = seqs.size();
+    // snapshot of all forward + reverse padded sequences (compress.rs:209)
+    std::vector<std::string> hay(2 * S);
+    for (size_t i = 0; i < S; i++) {
+        hay[2 * i] = seqs[i].forward_seq;
+        std::string& r = hay[2 * i + 1];
+        const std::string& f = seqs[i].forward_seq;
+        r.resize(f.size());
+        for (size_t j = 0; j < f.size(); j++) r[j] = comp_char(f[f.size() - 1 - j]);
+    }
+    // pattern 2i = start of sequence i (h dots + literal), 2i+1 = end (literal + h dots).  m == 2h for odd k;
+    // for even k (not reachable from the CLI) the literal is m - h long.
+    const size_t lit = m - h;
+    auto literal_of = [&](size_t pid) -> const char* {
+        const std::string& f = hay[2 * (pid / 2)];
+        return (pid & 1) ? f.data() + f.size() - m : f.data() + h;
+    };
+    const uint64_t B = 0x9E3779B97F4A7C15ULL | 1;
+    uint64_t Bpow = 1;
+    for (size_t i = 1; i < lit; i++) Bpow *= B;
+    auto hash_of = [&](const char* p) { uint64_t x = 0; for (size_t i = 0; i < lit; i++) x = x * B + (unsigned char)p[i]; return x; };
+    std::unordered_map<uint64_t, std::vector<uint32_t>> index;
+    index.reserve(4 * S);
+    const size_t FB = 22;
+    std::vector<uint64_t> filter((1u << FB) / 64, 0);
+    for (size_t pid = 0; pid < 2 * S; pid++) {
+        uint64_t x = hash_of(literal_of(pid));
+        index[x].push_back((uint32_t)pid);
+        uint64_t b = x >> (64 - FB);
+        filter[b >> 6] |= 1ULL << (b & 63);
+    }
+    typedef std::map<std::string, uint32_t> Tally;
+    int T = std::max(1, std::min<int>(threads, (int)(2 * S)));
+    std::vector<std::vector<Tally>> tallies(T, std::vector<Tally>(2 * S));
+    std::atomic<size_t> next_hay{0};
+    auto worker = [&](int tid) {
+        std::vector<Tally>& tl = tallies[tid];
+        std::vector<size_t> next_free(2 * S, 0), stamp(2 * S, (size_t)-1);
+        for (size_t hi; (hi = next_hay.fetch_add(1)) < 2 * S;) {
+            const std::string& H = hay[hi];
+            if (H.size() < m) continue;
+            uint64_t x = hash_of(H.data());
+            for (size_t j = 0;; j++) {
+                uint64_t b = x >> (64 - FB);
+                if (filter[b >> 6] >> (b & 63) & 1) {
+                    auto it = index.find(x);
+                    if (it != index.end())
+                        for (uint32_t pid : it->second) {
+                            if (memcmp(literal_of(pid), H.data() + j, lit) != 0) continue;
+                            // pattern start i: end patterns begin with the literal, start patterns h bytes earlier
+                            if (!(pid & 1) && j < h) continue;
+                            size_t i = (pid & 1) ? j : j - h;
+                            if (i + m > H.size()) continue;
+                            if (stamp[pid] != hi) { stamp[pid] = hi; next_free[pid] = 0; }
+                            if (i < next_free[pid]) continue;           // overlaps the previous match of this regex
+                            next_free[pid] = i + m;
+                            tl[pid][H.substr(i, m)]++;
+                        }
+                }
+                if (j + lit >= H.size()) break;
+                x = (x - (unsigned char)H[j] * Bpow) * B + (unsigned char)H[j + lit];
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; t++) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto& t : pool) t.join();
+    for (size_t pid = 0; pid < 2 * S; pid++) {
+        Tally all;
+        for (int t = 0; t < T; t++) for (auto& kv : tallies[t][pid]) all[kv.first] += kv.second;
+        if (all.empty()) throw std::logic_error("There should be at least one match");
+        const std::string* best = nullptr; size_t best_dots = 0; uint32_t best_cnt = 0;
+        for (auto& kv : all) {   // std::map iterates alphabetically: the first of equals wins the tie
+            size_t dots = (size_t)std::count(kv.first.begin(), kv.first.end(), '.');
+            if (!best || dots < best_dots || (dots == best_dots && kv.second > best_cnt)) { best = &kv.first; best_dots = dots; best_cnt = kv.second; }
+        }
+        std::string& f = seqs[pid / 2].forward_seq;
+        if (pid & 1) f.replace(f.size() - m, m, *best); else f.replace(0, m, *best);
+    }
+}
+
+// compress.rs:84-133
+LoadResult load_sequences(const std::string& assemblies_dir, uint32_t k, uint32_t max_contigs, int threads) {
+    LoadResult lr;
+    double t0 = now_s();
+    std::vector<std::string> assemblies = find_all_assemblies(assemblies_dir);
+    size_t seq_id = 0;
+    for (const std::string& assembly : assemblies) {
+        AssemblyDetails det;
+        det.filename = assembly;                                   // full path (metrics.rs:85)
+        std::string base = fs::path(assembly).filename().string();
+        for (auto& rec : load_fasta(assembly)) {
+            if (rec[2].size() < k) continue;                        // skipped silently, consumes no id
+            if (++seq_id > 32767) throw UserError("no more than 32767 input sequences are allowed");
+            LoadedSeq s;
+            s.id = (uint16_t)seq_id;
+            s.filename = base;
+            {   // header whitespace runs -> single spaces (compress.rs:115)
+                const std::string& hd = rec[1];
+                size_t i = 0;
+                while (i < hd.size()) {
+                    while (i < hd.size() && isspace((unsigned char)hd[i])) i++;
+                    size_t j = i;
+                    while (j < hd.size() && !isspace((unsigned char)hd[j])) j++;
+                    if (j > i) { if (!s.contig_header.empty()) s.contig_header.push_back(' '); s.contig_header.append(hd, i, j - i); }
+                    i = j;
+                }
+            }
+            pad_sequence(&s, rec[2], k);
+            size_t sp = s.contig_header.find(' ');
+            det.contigs.push_back({s.contig_header.substr(0, sp), sp == std::string::npos ? "" : s.contig_header.substr(sp + 1), s.length});
+            std::string lower = s.contig_header;
+            for (char& c : lower) c = (char)tolower((unsigned char)c);
+            if (lower.find("autocycler_ignore") == std::string::npos) lr.seqs.push_back(std::move(s));
+        }
+        lr.details.push_back(std::move(det));
+    }
+    lr.assembly_count = (uint32_t)assemblies.size();
+    lr.total_contigs_seen = (uint32_t)seq_id;
+    if (lr.seqs.empty()) throw UserError("no sequences found in input assemblies");
+    double mean = (double)lr.seqs.size() / (double)assemblies.size();
+    if (mean > (double)max_contigs) {
+        char buf[32]; snprintf(buf, sizeof buf, "%.1f", mean);
+        throw UserError(std::string("the mean number of contigs per input assembly (") + buf + ") exceeds the allowed threshold (" +
+                        std::to_string(max_contigs) + "). Are your input assemblies fragmented or contaminated?");
+    }
+    double t1 = now_s();
+    sequence_end_repair(lr.seqs, k, threads);
+    lr.load_seconds = t1 - t0;
+    lr.repair_seconds = now_s() - t1;
+    return lr;
+}
+
+// serde_yaml 0.9 block style of InputAssemblyMetrics (metrics.rs:65-107).  No reference test pins these bytes.
+static std::string yaml_str(const std::string& s) {
+    bool plain = !s.empty() && !isspace((unsigned char)s.front()) && !isspace((unsigned char)s.back());
+    static const char* reserved[] = {"true", "false", "null", "~", "True", "False", "Null", "TRUE", "FALSE", "NULL", "y", "n", "yes", "no", "on", "off", ".nan", ".inf", "-.inf"};
+    for (auto r : reserved) if (s == r) plain = false;
+    if (plain && strchr("-?:,[]{}#&*!|>'\"%@`", s.front()) && !((s.front() == '-' || s.front() == '?' || s.front() == ':') && s.size() > 1 && !isspace((unsigned char)s[1]))) plain = false;
+    for (size_t i = 0; plain && i < s.size(); i++) {
+        unsigned char c = (unsigned char)s[i];
+        if (c < 0x20 || c == 0x7f) plain = false;
+        if (c == ':' && (i + 1 == s.size() || s[i + 1] == ' ')) plain = false;
+        if (c == '#' && i > 0 && s[i - 1] == ' ') plain = false;
+    }
+    if (plain) { char* e = nullptr; strtod(s.c_str(), &e); if (e && *e == 0) plain = false; }
+    if (plain) return s;
+    std::string q = "'";
+    for (char c : s) { if (c == '\'') q += "''"; else q.push_back(c); }
+    return q + "'";
+}
+std::string metrics_yaml(const LoadResult& lr, uint32_t unitig_count, uint64_t unitig_total_length) {
+    uint64_t total = 0;
+    for (auto& s : lr.seqs) total += s.length;
+    std::string y;
+    y += "input_assemblies_count: " + std::to_string(lr.assembly_count) + "\n";
+    y += "input_assemblies_total_contigs: " + std::to_string(lr.seqs.size()) + "\n";
+    y += "input_assemblies_total_length: " + std::to_string(total) + "\n";
+    y += "compressed_unitig_count: " + std::to_string(unitig_count) + "\n";
+    y += "compressed_unitig_total_length: " + std::to_string(unitig_total_length) + "\n";
+    if (lr.details.empty()) return y + "input_assembly_details: []\n";
+    y += "input_assembly_details:\n";
+    for (auto& a : lr.details) {
+        y += "- filename: " + yaml_str(a.filename) + "\n";
+        if (a.contigs.empty()) { y += "  contigs: []\n"; continue; }
+        y += "  contigs:\n";
+        for (auto& c : a.contigs) {
+            y += "  - name: " + yaml_str(c.name) + "\n";
+            y += "    description: " + yaml_str(c.description) + "\n";
+            y += "    length: " + std::to_string(c.length) + "\n";
+        }
+    }
+    return y;
+}
+
+// compress.rs:53-62
+void check_compress_settings(const std::string& assemblies_dir, const std::string& autocycler_dir, uint32_t k, int threads) {
+    if (!fs::exists(assemblies_dir)) throw UserError("directory does not exist: " + assemblies_dir);
+    if (!fs::is_directory(assemblies_dir)) throw UserError(assemblies_dir + " is not a directory");
+    if (fs::exists(autocycler_dir) && !fs::is_directory(autocycler_dir)) throw UserError(autocycler_dir + " exists but is not a directory");
+    if (k < 11) throw UserError("--kmer cannot be less than 11");
+    if (k > 501) throw UserError("--kmer cannot be greater than 501");
+    if (k % 2 == 0) throw UserError("--kmer must be odd");
+    if (threads < 1) throw UserError("--threads cannot be less than 1");
+    if (threads > 100) throw UserError("--threads cannot be greater than 100");
+}
+
+std::string format_duration(double seconds) {
+    uint64_t us = (uint64_t)(seconds * 1e6);
+    char buf[64];
+    snprintf(buf, sizeof buf, "%llu:%02llu:%02llu.%06llu", (unsigned long long)(us / 1000000 / 3600),
+             (unsigned long long)(us / 1000000 / 60 % 60), (unsigned long long)(us / 1000000 % 60), (unsigned long long)(us % 1000000));
+    return buf;
+}
+
+}  // namespace ac

@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Benchmark of the `autocycler compress` hot path on MI355X.
+
+Metric (BASELINE.json): Mbp/s through compress -> unitig graph (k=51), workload config C = 96 x ~5 Mbp synthetic
+assemblies on one GPU.  A "step" is one full pass of the replaced region (compress.rs:42-44): padded,
+end-repaired sequences resident in HBM -> final unitig graph (segments, links in L-line order, paths) resident in
+host RAM, including the order-dependent host tail.  Input generation, padding and end repair happen before
+the timed region (they are upstream of the seam).
+
+    python bench.py [--gpus N --steps K --warmup W] [--assemblies 96 --genome 5000000 --kmer 51]
+
+N > 1: launched by torch.distributed.run, one rank per GPU.  The path shards by input assembly: every rank
+builds the graph of its own 96-assembly set (independent compress jobs, weak scaling, no data-path collective);
+RCCL is used only for the barrier / max-over-ranks timing.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+A_K = lambda k: 1 + 2 * (8 * ((2 * k + 63) // 64) + 8)   # algorithmic bytes per input bp
+HBM_PEAK = 8.0e12
+
+
+def make_inputs(args, rank):
+    import numpy as np
+    from autocycler_amd import synth
+    asm = synth.make_assemblies(args.assemblies, genome=args.genome, plasmid=args.plasmid, sub=args.sub, indel=args.indel,
+                                seed=51_000 + 1000 * rank)
+    seqs, fn, hd = [], [], []
+    for i, contigs in enumerate(asm):
+        for header, s in contigs:
+            seqs.append(np.ascontiguousarray(s)); fn.append(f"assembly_{i:04d}.fasta"); hd.append(header)
+    return seqs, fn, hd
+
+
+def prepare(lib, k, seqs, fn, hd, n_assemblies, threads):
+    """Sequence::new_with_seq + sequence_end_repair on the host (upstream of the timed region)."""
+    from autocycler_amd import _capi
+    n = len(seqs)
+    ptrs = (C.c_void_p * n)(*[s.ctypes.data for s in seqs])
+    lens = (C.c_uint32 * n)(*[len(s) for s in seqs])
+    f = (C.c_char_p * n)(*[x.encode() for x in fn])
+    h = (C.c_char_p * n)(*[x.encode() for x in hd])
+    out = C.c_void_p()
+    rc = lib.ac_seqs_from_raw(C.c_uint32(k), C.c_uint32(n), ptrs, lens, f, h, C.c_uint32(n_assemblies), C.c_int(1),
+                              C.c_int(threads), C.byref(out))
+    if rc:
+        raise RuntimeError(lib.ac_last_error().decode())
+    return out
+
+
+def cpu_baseline(k, sample_assemblies, sample_genome):
+    """The oracle (C++ restatement of the reference CPU path, hot stages on 1 core like the reference) timed on
+    a bounded sample of the same workload model."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib as O
+    from autocycler_amd import synth
+    asm = synth.make_assemblies(sample_assemblies, genome=sample_genome, plasmid=sample_genome // 50, seed=51_000)
+    seqs, fn, hd = [], [], []
+    for i, contigs in enumerate(asm):
+        for header, s in contigs:
+            seqs.append(s.tobytes().decode()); fn.append(f"assembly_{i:04d}.fasta"); hd.append(header)
+    s = O.Seqs.from_raw(k, seqs, filenames=fn, headers=hd, repair=True, threads=os.cpu_count() or 1)
+    _, _, tm = s.compress(k)
+    hot = tm["kmer_graph"] + tm["unitig_graph"] + tm["simplify"]
+    bases = sum(len(x) for x in seqs)
+    return {"value": bases / 1e6 / hot, "unit": "Mbp/s", "cores": 1, "kind": "port",
+            "sample": f"{sample_assemblies} x {sample_genome} bp synthetic assemblies (same generator), k={k}: "
+                      f"k-mer graph {tm['kmer_graph']:.2f}s + unitig graph {tm['unitig_graph']:.2f}s + simplify {tm['simplify']:.2f}s "
+                      f"on 1 core (the reference's hot stages are single-threaded); C++ restatement, not the autocycler binary"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--assemblies", type=int, default=96)
+    ap.add_argument("--genome", type=int, default=5_000_000)
+    ap.add_argument("--plasmid", type=int, default=100_000)
+    ap.add_argument("--sub", type=float, default=1e-4)
+    ap.add_argument("--indel", type=float, default=1e-5)
+    ap.add_argument("--kmer", type=int, default=51)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=str, default="4x1000000")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from autocycler_amd import _capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    lib = _capi.load_library()          # raises if the HIP extension is missing: no fallback
+    lib.ac_seqs_views.restype = C.POINTER(_capi.SeqView)
+    lib.ac_seqs_count.restype = C.c_uint32
+    lib.ac_seqs_free.argtypes = [C.c_void_p]
+    lib.ac_seqs_repair_seconds.restype = C.c_double
+    k = args.kmer
+
+    t0 = time.time()
+    seqs, fn, hd = make_inputs(args, rank)
+    t_gen = time.time() - t0
+    h_seqs = prepare(lib, k, seqs, fn, hd, args.assemblies, threads=os.cpu_count() or 1)
+    del seqs
+    n = lib.ac_seqs_count(h_seqs)
+    views = lib.ac_seqs_views(h_seqs)
+    n_text = lib.ac_text_size(C.c_uint32(k), views, C.c_uint32(n))
+    import numpy as np
+    text = np.empty(n_text, dtype=np.uint8)
+    off = (C.c_uint64 * n)(); d1 = (C.c_uint16 * n)(); d2 = (C.c_uint16 * n)()
+    if lib.ac_layout_text(C.c_uint32(k), views, C.c_uint32(n), text.ctypes.data_as(C.c_void_p), off, d1, d2):
+        raise RuntimeError(lib.ac_last_error().decode())
+    lens = (C.c_uint32 * n)(*[views[i].length for i in range(n)])
+    ids = (C.c_uint16 * n)(*[views[i].id for i in range(n)])
+    bases = sum(lens)
+    t_repair = lib.ac_seqs_repair_seconds(h_seqs)
+    t1 = time.time()
+    d_text = torch.from_numpy(text).to(dev)      # inputs resident in HBM before the timed region
+    torch.cuda.synchronize()
+    t_h2d = time.time() - t1
+
+    def step():
+        h = C.c_void_p()
+        rc = lib.ac_compress_build_device(C.c_uint32(k), C.c_uint32(args.assemblies), C.c_void_p(d_text.data_ptr()),
+                                          C.c_uint64(n_text), off, lens, ids, d1, d2, C.c_uint32(n), C.c_int(local_rank), C.byref(h))
+        if rc:
+            raise RuntimeError(lib.ac_last_error().decode())
+        return _capi.Graph(lib, h, n)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step().close()
+    barrier()
+    t_start = time.perf_counter()
+    tms = []
+    g = None
+    for _ in range(args.steps):
+        if g is not None:
+            g.close()
+        g = step()
+        tms.append(g.timings())
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        b = torch.tensor([bases], dtype=torch.float64, device=dev)
+        dist.all_reduce(b, op=dist.ReduceOp.SUM)
+        total_bases = float(b.item())
+    else:
+        total_bases = float(bases)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_bases / 1e6 / (elapsed / args.steps)
+        ins_ms = sum(t["insert_kernel_ms"] for t in tms) / len(tms)
+        alg_bytes = A_K(k) * bases
+        achieved = alg_bytes / (ins_ms * 1e-3)
+        stage = {key: sum(t[key] for t in tms) / len(tms) for key in
+                 ("pack", "insert", "collect_sort", "degree", "segment", "minkey", "rank", "paths", "links", "seqs", "d2h",
+                  "total_device", "host_tail")}
+        line = {
+            "metric": "Mbp/sec through compress->unitig GFA (k=%d)" % k,
+            "value": value, "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{args.assemblies} x ~{args.genome / 1e6:g} Mbp synthetic assemblies per GPU (+plasmid {args.plasmid} bp, "
+                                   f"sub {args.sub:g}, indel {args.indel:g}), k={k}, 1 species; BASELINE.json configs[2]",
+                       "bases_per_gpu": bases, "sequences_per_gpu": n, "sharding": "by assembly set, one compress job per GPU",
+                       "timed_region": "padded+repaired sequences in HBM -> final unitig graph in host RAM (device build + host tail)"},
+            "roofline": {"bound": "hbm", "kernel": "functor_kernel<InsertFunctor<W>> (k-mer table insert)",
+                         "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": ins_ms,
+                         "whole_path_frac": alg_bytes / (elapsed / args.steps) / HBM_PEAK},
+            "stages_s": stage,
+            "graph": {**g.stats_post, "kmers": g.kmer_count, "distinct_canonical": tms[-1]["n_distinct"],
+                      "path_entries": tms[-1]["n_path_entries"], "table_capacity": tms[-1]["table_capacity"],
+                      "simplify_passes": tms[-1]["simplify_passes"]},
+            "prep_s": {"generate": t_gen, "end_repair": t_repair, "h2d": t_h2d, "h2d_GBps": n_text / t_h2d / 1e9},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            a, b2 = args.cpu_sample.split("x")
+            line["cpu_baseline"] = cpu_baseline(k, int(a), int(b2))
+        print(json.dumps(line))
+    if g is not None:
+        g.close()
+    lib.ac_seqs_free(h_seqs)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

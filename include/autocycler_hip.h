@@ -90,6 +90,29 @@ int ac_gfa_string(const ac_graph*, const char* const* filenames, const char* con
                   uint64_t* out_len);
 void ac_string_free(char*);
 
+/* ---- host side around the hot path ("boundary" and "next" rows of SURVEY.md §8) -------------------------------
+ * ac_seqs mirrors what load_sequences returns (compress.rs:98-133): padded, end-repaired Sequences + the
+ * per-assembly details for the YAML metrics.  The Rust CLI keeps its own loader; these serve the standalone
+ * CLI (autocycler-compress), the tests and the benchmarks. */
+typedef struct ac_seqs ac_seqs;
+int ac_seqs_load(const char* assemblies_dir, uint32_t k, uint32_t max_contigs, int threads, ac_seqs** out);
+/* Sequence::new_with_seq (sequence.rs:31-59) for ids 1..n + optional sequence_end_repair (compress.rs:202-236). */
+int ac_seqs_from_raw(uint32_t k, uint32_t n, const uint8_t* const* seqs, const uint32_t* lens,
+                     const char* const* filenames, const char* const* headers, uint32_t assembly_count, int repair,
+                     int threads, ac_seqs** out);
+uint32_t ac_seqs_count(const ac_seqs*);
+uint32_t ac_seqs_assembly_count(const ac_seqs*);
+const ac_seq_view* ac_seqs_views(const ac_seqs*);
+int ac_seqs_get(const ac_seqs*, uint32_t i, ac_seq_view* view, const char** filename, const char** header);
+double ac_seqs_repair_seconds(const ac_seqs*);
+int ac_seqs_metrics_yaml(const ac_seqs*, uint32_t unitig_count, uint64_t unitig_total_length, char** out); /* metrics.rs:65-107 */
+void ac_seqs_free(ac_seqs*);
+int ac_compress_seqs(uint32_t k, const ac_seqs*, int device, ac_graph** out);
+/* The whole command (compress.rs:32-50): writes input_assemblies.gfa / .yaml into autocycler_dir.
+ * times[4] = load, end repair, graph build (hot path), write (seconds).  graph_out may be NULL. */
+int ac_compress_dir(const char* assemblies_dir, const char* autocycler_dir, uint32_t k, uint32_t max_contigs,
+                    int threads, int device, ac_graph** graph_out, double* times);
+
 const char* ac_last_error(void);
 int ac_device_count(void);       /* number of visible HIP devices (0 if none / no driver) */
 uint32_t ac_max_kmer(void);      /* largest --kmer this build supports */

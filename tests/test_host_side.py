@@ -1,0 +1,128 @@
+"""Host logic around the hot path (CPU): loader, end repair, whole-command driver, YAML, C-ABI surface."""
+import ctypes as C
+import gzip
+import re
+from pathlib import Path
+
+import pytest
+
+import emu_lib
+import oracle_lib as O
+import seqgen
+from autocycler_amd import _capi
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def emu():
+    lib = _capi.load_library(emu_lib.emu_path())
+    lib.ac_seqs_views.restype = C.POINTER(_capi.SeqView)
+    lib.ac_seqs_count.restype = C.c_uint32
+    lib.ac_seqs_free.argtypes = [C.c_void_p]
+    return lib
+
+
+def test_header_symbols_exported_by_product_library():
+    """The C-ABI library loads (no GPU needed) and exports every function include/autocycler_hip.h declares."""
+    header = (ROOT / "include" / "autocycler_hip.h").read_text()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)   # prototypes only
+    declared = set(re.findall(r"\b(ac_[a-z0-9_]+)\s*\(", header))
+    assert {"ac_compress_build", "ac_compress_build_device", "ac_links", "ac_path", "ac_compress_dir"} <= declared
+    lib = _capi.load_library()      # raises HipLibraryMissing if the extension was not built
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert set(_capi.EXPORTS) <= declared
+    assert b"gfx950" in lib.ac_version()
+
+
+def test_product_library_has_no_cpu_fallback():
+    """Without a GPU the build call must fail loudly instead of computing on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from autocycler_amd import AutocyclerError, compress_build
+    with pytest.raises(AutocyclerError, match="no HIP device|no CPU fallback|HIP error"):
+        compress_build(9, 1, [(b"....ACGTACGTACGTAC....", 14, 1)])
+
+
+def _prepare(lib, k, seqs, fn, hd, repair):
+    n = len(seqs)
+    bufs = [s.encode() for s in seqs]
+    out = C.c_void_p()
+    rc = lib.ac_seqs_from_raw(C.c_uint32(k), C.c_uint32(n), (C.c_char_p * n)(*bufs), (C.c_uint32 * n)(*[len(b) for b in bufs]),
+                              (C.c_char_p * n)(*[x.encode() for x in fn]), (C.c_char_p * n)(*[x.encode() for x in hd]),
+                              C.c_uint32(len(set(fn))), C.c_int(repair), C.c_int(3), C.byref(out))
+    assert rc == 0, lib.ac_last_error()
+    v = lib.ac_seqs_views(out)
+    res = [C.string_at(v[i].fwd, v[i].length + k - 1) for i in range(n)]
+    lib.ac_seqs_free(out)
+    return res
+
+
+@pytest.mark.parametrize("k", [3, 5, 11, 21, 51])
+def test_end_repair_matches_reference_semantics(emu, k):
+    """Indexed one-pass end repair == the literal regex scan of compress.rs:202-270 (oracle)."""
+    for seed in range(40):
+        seqs, fn, hd = seqgen.make_case(seed, k)
+        want = [q["fwd"] for q in O.Seqs.from_raw(k, seqs, filenames=fn, headers=hd, repair=True).all()]
+        assert _prepare(emu, k, seqs, fn, hd, 1) == want
+
+
+def _write_dir(d, k):
+    seqs, fn, hd = seqgen.make_case(10, k)
+    files = {}
+    for s, f, h in zip(seqs, fn, hd):
+        files.setdefault(f, []).append((h, s))
+    names = []
+    for i, (f, recs) in enumerate(sorted(files.items())):
+        text = "".join(f">{h}\t extra  words\n{s[:len(s)//2]}\n{s[len(s)//2:].lower()}\n" for h, s in recs)
+        if i == 0:
+            text += ">tiny\nACG\n>skipme autocycler_ignore\n" + "ACGT" * (k) + "\n"
+        name = f if i % 2 == 0 else f + ".gz"
+        if name.endswith(".gz"):
+            with gzip.open(d / name, "wt") as fh:
+                fh.write(text)
+        else:
+            (d / name).write_text(text)
+        names.append(name)
+    (d / "notes.txt").write_text("not an assembly\n")
+    return names
+
+
+@pytest.mark.parametrize("k", [11, 51])
+def test_compress_dir_matches_oracle(emu, tmp_path, k):
+    """compress.rs:32-50 end to end: same GFA bytes and same YAML as the oracle's whole-command restatement."""
+    src = tmp_path / "asm"
+    src.mkdir()
+    _write_dir(src, k)
+    out_o, out_p = tmp_path / "o", tmp_path / "p"
+    O.compress_dir(src, out_o, k=k)
+    times = (C.c_double * 4)()
+    rc = emu.ac_compress_dir(str(src).encode(), str(out_p).encode(), C.c_uint32(k), C.c_uint32(25), C.c_int(4), C.c_int(0), None, times)
+    assert rc == 0, emu.ac_last_error()
+    assert (out_p / "input_assemblies.gfa").read_bytes() == (out_o / "input_assemblies.gfa").read_bytes()
+    assert (out_p / "input_assemblies.yaml").read_text() == (out_o / "input_assemblies.yaml").read_text()
+    # the reference's own properties (tests.rs:108-127) on the product's file
+    g = (out_p / "input_assemblies.gfa").read_text()
+    assert O.gfa_resave(g) == g
+    assert len(O.decompress(g)) == len([l for l in g.splitlines() if l.startswith("P")])
+
+
+def test_compress_dir_user_errors(emu, tmp_path):
+    def run(src, out, k=51, threads=8):
+        rc = emu.ac_compress_dir(str(src).encode(), str(out).encode(), C.c_uint32(k), C.c_uint32(25), C.c_int(threads), C.c_int(0), None, None)
+        return rc, emu.ac_last_error().decode()
+    src = tmp_path / "asm"
+    src.mkdir()
+    assert run(tmp_path / "missing", tmp_path / "o")[1].startswith("directory does not exist")
+    assert "no assemblies found" in run(src, tmp_path / "o")[1]
+    (src / "a.fasta").write_text(">a\n" + "ACGT" * 30 + "\n")
+    assert run(src, tmp_path / "o", k=9)[1] == "--kmer cannot be less than 11"
+    assert run(src, tmp_path / "o", k=503)[1] == "--kmer cannot be greater than 501"
+    assert run(src, tmp_path / "o", k=52)[1] == "--kmer must be odd"
+    assert run(src, tmp_path / "o", threads=0)[1] == "--threads cannot be less than 1"
+    (src / "b.fasta").write_text(">b\nACGTNNACGT" * 20 + "\n")
+    assert "contains non-ACGT characters" in run(src, tmp_path / "o", k=11)[1]
+    (src / "b.fasta").write_text("")
+    assert "is an empty file" in run(src, tmp_path / "o", k=11)[1]

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Per-kernel statistics from a rocprofv3 rocpd SQLite database (the `--kernel-trace --stats` output of
+ROCm 7.2): calls, total / average / min / max duration, share of GPU kernel time.  Writes a CSV summary.
+
+    python tools/rocpd_stats.py gpurun_out/prof/x_results.db > profiles/r01_kernel_stats.csv"""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = name.replace("ac::", "")
+    return name
+
+
+def main(path):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [c[1] for c in cur.execute("pragma table_info('kernels')")]
+    rows = cur.execute("select name, start, end from kernels").fetchall() if "name" in cols else []
+    agg = {}
+    for name, start, end in rows:
+        a = agg.setdefault(short(name), [0, 0, 1 << 62, 0])
+        d = end - start
+        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    total = sum(a[1] for a in agg.values()) or 1
+    print("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs")
+    for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"\"{name}\",{a[0]},{a[1]},{a[1] / a[0]:.0f},{100.0 * a[1] / total:.2f},{a[2]},{a[3]}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

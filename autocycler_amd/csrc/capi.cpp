@@ -3,6 +3,7 @@
 // emulation; that library is built only by the CPU test-suite and is named libautocycler_emu.so.)
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -19,6 +20,7 @@
 using namespace ac;
 
 static thread_local std::string g_err;
+static std::mutex g_build_mutex;   // one build at a time per process: the device / pinned arenas are shared
 
 struct ac_graph {
     FinalGraph g;
@@ -113,6 +115,7 @@ int ac_compress_build(uint32_t k, uint32_t assembly_count, const ac_seq_view* se
                       ac_graph** out) {
     return guarded([&] {
         validate(k, seqs, n_seqs);
+        std::lock_guard<std::mutex> lock(g_build_mutex);
         select_device(device);
         auto h = std::make_unique<ac_graph>();
         std::vector<SeqView> v(n_seqs);
@@ -138,6 +141,7 @@ int ac_compress_build_device(uint32_t k, uint32_t assembly_count, const void* d_
     return guarded([&] {
         if (!d_text || n_seqs == 0) throw DeviceError("no sequences found in input assemblies");
         if (n_seqs > 32767) throw DeviceError("no more than 32767 input sequences are allowed");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
         select_device(device);
         auto h = std::make_unique<ac_graph>();
         std::vector<uint64_t> off(seq_off, seq_off + n_seqs);
@@ -198,6 +202,7 @@ int ac_timings_get(const ac_graph* g, ac_timings* o) {
     o->insert_kernel_ms = t.insert_kernel_ms; o->insert_positions = t.insert_positions;
     o->table_capacity = t.table_capacity; o->n_distinct = t.n_distinct; o->n_path_entries = t.n_path_entries;
     o->simplify_passes = (uint32_t)g->g.simplify_passes;
+    o->insert_launches = t.insert_launches; o->insert_real = t.insert_real;
     return 0;
 }
 void ac_free(ac_graph* g) { delete g; }

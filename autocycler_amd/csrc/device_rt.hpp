@@ -57,46 +57,100 @@ __device__ inline void atomic_max32(u32* p, u32 v) { atomicMax(p, v); }
 #endif
 
 // ---- buffers --------------------------------------------------------------------------------------
+// Device memory comes from a persistent bump arena (one per process, on the device selected by the C ABI):
+// a build makes ~40 allocations, and hipMalloc/hipFree (the latter synchronises the device) would cost more
+// than the kernels.  The arena is reset at the start of every build, grows by whole blocks, and coalesces to
+// one block on the next reset; MI355X has 288 GB of HBM, so the arena simply stays resident between builds
+// (ac_release_memory() in the C ABI frees it).
+class Arena {
+  public:
+    static Arena& device() { static Arena a(false); return a; }
+    static Arena& pinned_host() { static Arena a(true); return a; }
+    void* alloc(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes == 0) bytes = 256;
+        if (blocks_.empty() || blocks_.back().used + bytes > blocks_.back().cap) {
+            size_t cap = std::max(bytes, grow_);
+            Block b; b.cap = cap; b.used = 0; b.p = raw_alloc(cap);
+            blocks_.push_back(b);
+        }
+        Block& b = blocks_.back();
+        void* r = (char*)b.p + b.used;
+        b.used += bytes;
+        peak_ = std::max(peak_, total_used());
+        return r;
+    }
+    // Start of a build: everything handed out so far is dead.
+    void reset() {
+        if (blocks_.size() > 1) {   // coalesce: next build gets one block big enough for the last one
+            size_t total = 0;
+            for (auto& b : blocks_) { total += b.cap; raw_free(b.p); }
+            blocks_.clear();
+            Block b; b.cap = total; b.used = 0; b.p = raw_alloc(total);
+            blocks_.push_back(b);
+        } else if (!blocks_.empty()) {
+            blocks_.back().used = 0;
+        }
+    }
+    void release_all() {
+        for (auto& b : blocks_) raw_free(b.p);
+        blocks_.clear();
+    }
+    size_t total_used() const { size_t t = 0; for (auto& b : blocks_) t += b.used; return t; }
+    size_t capacity() const { size_t t = 0; for (auto& b : blocks_) t += b.cap; return t; }
+    void set_grow(size_t g) { grow_ = g; }
+
+  private:
+    struct Block { void* p; size_t cap, used; };
+    explicit Arena(bool host) : host_(host) {}
+    void* raw_alloc(size_t bytes) {
+#ifdef AC_EMU
+        void* p = malloc(bytes);
+        if (!p) throw DeviceError("emu malloc failed");
+        return p;
+#else
+        void* p = nullptr;
+        if (host_) AC_HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+        else AC_HIP_CHECK(hipMalloc(&p, bytes));
+        return p;
+#endif
+    }
+    void raw_free(void* p) {
+#ifdef AC_EMU
+        free(p);
+#else
+        if (host_) (void)hipHostFree(p); else (void)hipFree(p);
+#endif
+    }
+    bool host_;
+    std::vector<Block> blocks_;
+    size_t grow_ = (size_t)64 << 20;
+    size_t peak_ = 0;
+};
+
 template <class T>
-class DBuf {
+class DBuf {   // a typed slice of the device arena (no ownership: the arena reset frees everything)
   public:
     DBuf() {}
     explicit DBuf(size_t n, bool zero = false) { alloc(n, zero); }
     DBuf(const DBuf&) = delete;
     DBuf& operator=(const DBuf&) = delete;
     DBuf(DBuf&& o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
-    DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { release(); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; } return *this; }
-    ~DBuf() { release(); }
+    DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; } return *this; }
     void alloc(size_t n, bool zero = false) {
-        release();
         n_ = n;
         size_t bytes = (n ? n : 1) * sizeof(T);
-#ifdef AC_EMU
-        p_ = (T*)malloc(bytes);
-        if (!p_) throw DeviceError("emu malloc failed");
-        if (zero) memset(p_, 0, bytes);
-#else
-        AC_HIP_CHECK(hipMalloc((void**)&p_, bytes));
-        if (zero) AC_HIP_CHECK(hipMemsetAsync(p_, 0, bytes, 0));
-#endif
+        p_ = (T*)Arena::device().alloc(bytes);
+        if (zero) fill_bytes(0);
     }
     void fill_bytes(int byte, stream_t s = 0) {
         size_t bytes = n_ * sizeof(T);
+        if (!bytes) return;
 #ifdef AC_EMU
         memset(p_, byte, bytes);
 #else
         AC_HIP_CHECK(hipMemsetAsync(p_, byte, bytes, s));
 #endif
-    }
-    void release() {
-        if (p_) {
-#ifdef AC_EMU
-            free(p_);
-#else
-            (void)hipFree(p_);
-#endif
-        }
-        p_ = nullptr; n_ = 0;
     }
     T* ptr() { return p_; }
     const T* ptr() const { return p_; }
@@ -116,14 +170,26 @@ inline void copy_h2d(void* d, const void* h, size_t bytes, stream_t s = 0) {
     AC_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
 #endif
 }
-inline void copy_d2h(void* h, const void* d, size_t bytes, stream_t s = 0) {
+inline void copy_d2h_async(void* h, const void* d, size_t bytes, stream_t s = 0) {
     if (!bytes) return;
 #ifdef AC_EMU
     memcpy(h, d, bytes);
 #else
     AC_HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s));
+#endif
+}
+inline void copy_d2h(void* h, const void* d, size_t bytes, stream_t s = 0) {
+    if (!bytes) return;
+    copy_d2h_async(h, d, bytes, s);
+#ifndef AC_EMU
     AC_HIP_CHECK(hipStreamSynchronize(s));
 #endif
+}
+// Device -> pinned host arena (valid until the next build resets the arena); no sync.
+template <class T> T* to_pinned_async(const T* d, size_t n, stream_t s = 0) {
+    T* h = (T*)Arena::pinned_host().alloc((n ? n : 1) * sizeof(T));
+    copy_d2h_async(h, d, n * sizeof(T), s);
+    return h;
 }
 inline void copy_d2d(void* dst, const void* src, size_t bytes, stream_t s = 0) {
     if (!bytes) return;
@@ -159,10 +225,23 @@ __global__ void __launch_bounds__(256) functor_kernel(u64 n, F f) {
     if (tid < n) f(tid);
 }
 #endif
+#ifdef AC_EMU
+inline int emu_order() { const char* e = getenv("AC_EMU_ORDER"); return e ? atoi(e) : 0; }
+#endif
 template <class F> void launch(u64 n, const F& f, stream_t s = 0) {
     if (n == 0) return;
 #ifdef AC_EMU
-    for (u64 i = 0; i < n; i++) f(i);
+    // The serial emulation can visit the logical threads in three orders (AC_EMU_ORDER=0/1/2: ascending,
+    // descending, pseudo-random) so the tests can check that no result depends on scheduling.
+    int order = emu_order();
+    if (order == 1) { for (u64 i = n; i-- > 0;) f(i); }
+    else if (order == 2) {
+        std::vector<u64> perm(n);
+        for (u64 i = 0; i < n; i++) perm[i] = i;
+        u64 st = 0x9E3779B97F4A7C15ULL ^ n;
+        for (u64 i = n; i > 1; i--) { st = st * 6364136223846793005ULL + 1442695040888963407ULL; std::swap(perm[i - 1], perm[(st >> 33) % i]); }
+        for (u64 i = 0; i < n; i++) f(perm[i]);
+    } else { for (u64 i = 0; i < n; i++) f(i); }
 #else
     u64 blocks = (n + 255) / 256;
     if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
@@ -190,7 +269,6 @@ inline void sort_pairs_u64_u32(DBuf<u64>& keys, DBuf<u32>& vals, size_t n, int e
     AC_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, 0, end_bit, s));
     DBuf<u8> tmp(tmp_bytes);
     AC_HIP_CHECK(rocprim::radix_sort_pairs(tmp.ptr(), tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, 0, end_bit, s));
-    AC_HIP_CHECK(hipStreamSynchronize(s));
     keys = std::move(k2);
     vals = std::move(v2);
 #endif
@@ -212,7 +290,6 @@ inline void sort_pairs_u64_i32(DBuf<u64>& keys, DBuf<int32_t>& vals, size_t n, i
     AC_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, 0, end_bit, s));
     DBuf<u8> tmp(tmp_bytes);
     AC_HIP_CHECK(rocprim::radix_sort_pairs(tmp.ptr(), tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, 0, end_bit, s));
-    AC_HIP_CHECK(hipStreamSynchronize(s));
     keys = std::move(k2);
     vals = std::move(v2);
 #endif
@@ -228,7 +305,18 @@ inline void inclusive_scan_u32(const u32* in, u32* out, size_t n, stream_t s = 0
     AC_HIP_CHECK(rocprim::inclusive_scan(nullptr, tmp_bytes, in, out, n, rocprim::plus<u32>(), s));
     DBuf<u8> tmp(tmp_bytes);
     AC_HIP_CHECK(rocprim::inclusive_scan(tmp.ptr(), tmp_bytes, in, out, n, rocprim::plus<u32>(), s));
-    AC_HIP_CHECK(hipStreamSynchronize(s));
+#endif
+}
+inline void exclusive_scan_u32(const u32* in, u32* out, size_t n, stream_t s = 0) {
+    if (!n) return;
+#ifdef AC_EMU
+    u32 acc = 0;
+    for (size_t i = 0; i < n; i++) { u32 v = in[i]; out[i] = acc; acc += v; }
+#else
+    size_t tmp_bytes = 0;
+    AC_HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, (u32)0, n, rocprim::plus<u32>(), s));
+    DBuf<u8> tmp(tmp_bytes);
+    AC_HIP_CHECK(rocprim::exclusive_scan(tmp.ptr(), tmp_bytes, in, out, (u32)0, n, rocprim::plus<u32>(), s));
 #endif
 }
 inline void exclusive_scan_u64(const u64* in, u64* out, size_t n, stream_t s = 0) {
@@ -241,7 +329,6 @@ inline void exclusive_scan_u64(const u64* in, u64* out, size_t n, stream_t s = 0
     AC_HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, (u64)0, n, rocprim::plus<u64>(), s));
     DBuf<u8> tmp(tmp_bytes);
     AC_HIP_CHECK(rocprim::exclusive_scan(tmp.ptr(), tmp_bytes, in, out, (u64)0, n, rocprim::plus<u64>(), s));
-    AC_HIP_CHECK(hipStreamSynchronize(s));
 #endif
 }
 
@@ -290,7 +377,6 @@ inline void sort_by_key_cmp(DBuf<K>& keys, DBuf<u32>& vals, size_t n, Cmp cmp, s
     AC_HIP_CHECK(rocprim::merge_sort(nullptr, tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, cmp, s));
     DBuf<u8> tmp(tmp_bytes);
     AC_HIP_CHECK(rocprim::merge_sort(tmp.ptr(), tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, cmp, s));
-    AC_HIP_CHECK(hipStreamSynchronize(s));
     keys = std::move(k2);
     vals = std::move(v2);
 #endif

@@ -24,7 +24,7 @@ static double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static const int CH = 64;          // text positions per thread in the streaming kernels
+
 
 static const int MAX_PROBES = 1 << 14;
 
@@ -92,42 +92,65 @@ template <int W> AC_HD int claimant_match(const TextCtx& t, u64 v, const Key<W>&
     return yf ? 2 : 1;
 }
 
-struct FindResult { u64 slot; int claimant_flipped; bool found; };
+struct FindResult { u64 pos; int claimant_flipped; bool found; };
 
 template <int W> AC_HD FindResult table_find(const TextCtx& t, const Table& tb, const Key<W>& ukey, bool isdot) {
     u64 h = key_hash<W>(ukey);
     u64 tag = slot_make(h, isdot, 0);
     u64 s = h & tb.cap_mask;
-    FindResult r; r.found = false; r.slot = 0; r.claimant_flipped = 0;
+    FindResult r; r.found = false; r.pos = 0; r.claimant_flipped = 0;
     for (int probes = 0; probes < MAX_PROBES; probes++) {
         u64 v = tb.slots[s];
         if (v == SLOT_EMPTY) return r;
         if (slot_tag_eq(v, tag)) {
             int m = claimant_match<W>(t, v, ukey);
-            if (m) { r.found = true; r.slot = s; r.claimant_flipped = (m == 2); return r; }
+            if (m) { r.found = true; r.pos = slot_pos(v); r.claimant_flipped = (m == 2); return r; }
         }
         s = (s + 1) & tb.cap_mask;
     }
     return r;
 }
 
-// Lookup of an extended k-mer in text orientation.  rel_same: the query reads the same way as the
-// stored smallest occurrence does in the text.
-template <int W> AC_HD bool find_xk(const TextCtx& t, const Table& tb, const XKmer<W>& x, u64* slot, bool* rel_same) {
+// Lookup of an extended k-mer in text orientation.  *pos = the k-mer's smallest ("novel") text position;
+// rel_same: the query reads the same way as that smallest occurrence does in the text.
+template <int W> AC_HD bool find_xk(const TextCtx& t, const Table& tb, const XKmer<W>& x, u64* pos, bool* rel_same) {
     bool flipped;
     Key<W> uk = xk_canonical<W>(x, t.k, &flipped);
     FindResult r = table_find<W>(t, tb, uk, x.ld > 0 || x.td > 0);
     if (!r.found) return false;
-    *slot = r.slot;
+    *pos = r.pos;
     *rel_same = ((r.claimant_flipped != 0) == flipped);
     return true;
 }
 
+// Rank support over the novel-position bitmap: index of a novel position in the sorted novel list.
+struct Novel {
+    const u64* bm;        // bit p set <=> p is the smallest occurrence of its canonical k-mer
+    const u32* wprefix;   // number of set bits before word w
+};
+AC_HD int popc64(u64 x) {
+#ifdef AC_EMU
+    return __builtin_popcountll(x);
+#else
+    return __popcll(x);
+#endif
+}
+AC_HD u32 novel_rank(const Novel& nv, u64 pos) {
+    u64 w = pos >> 6;
+    int b = (int)(pos & 63);
+    u64 below = b ? (nv.bm[w] & ((1ULL << b) - 1)) : 0;
+    return nv.wprefix[w] + (u32)popc64(below);
+}
+
+static const u64 NOREF = ~0ULL;
+
 // Insert with "smallest text position wins" semantics.  Stale (cached) reads of a slot can only show
 // an older state of a monotone word (EMPTY -> pos -> smaller pos of the same key), so every decision
 // taken on them stays valid; claiming is decided by the CAS alone.
-template <int W> AC_D void table_insert(const TextCtx& t, const Table& tb, const Key<W>& ukey, bool isdot, u64 p,
-                                        u32* n_claimed, u32* err) {
+// Returns the position q < p of an EARLIER occurrence of the same canonical k-mer if the slot showed one
+// (*same = it reads in the same orientation as the occurrence at p), else NOREF.
+template <int W> AC_D u64 table_insert(const TextCtx& t, const Table& tb, const Key<W>& ukey, bool isdot, bool flipped, u64 p,
+                                       u32* claimed, u32* err, bool* same) {
     u64 h = key_hash<W>(ukey);
     u64 mine = slot_make(h, isdot, p);
     u64 s = h & tb.cap_mask;
@@ -135,119 +158,144 @@ template <int W> AC_D void table_insert(const TextCtx& t, const Table& tb, const
         u64 v = tb.slots[s];
         if (v == SLOT_EMPTY) {
             u64 old = atomic_cas64(&tb.slots[s], SLOT_EMPTY, mine);
-            if (old == SLOT_EMPTY) { atomic_add32(n_claimed, 1u); return; }
+            if (old == SLOT_EMPTY) { (*claimed)++; return NOREF; }
             v = old;
         }
         if (slot_tag_eq(v, mine)) {
-            if (slot_pos(v) == p) return;
-            if (claimant_match<W>(t, v, ukey)) {
-                if (slot_pos(v) > p) atomic_min64(&tb.slots[s], mine);
-                return;
+            if (slot_pos(v) == p) return NOREF;
+            int m = claimant_match<W>(t, v, ukey);
+            if (m) {
+                if (slot_pos(v) > p) { atomic_min64(&tb.slots[s], mine); return NOREF; }
+                *same = ((m == 2) == flipped);
+                return slot_pos(v);
             }
         }
         s = (s + 1) & tb.cap_mask;
     }
     atomic_or32(err, 1u);
+    return NOREF;
 }
+
+struct alignas(16) V16 { u32 a, b, c, d; };
 
 // ---- K1: ASCII text -> 2-bit words + mask ------------------------------------------------------------
+// One thread per 32 text bytes (two 16-byte loads; a wavefront reads 2 KB contiguously), writing one
+// 64-bit word of bases and the matching 32-bit half of a mask word.
 struct PackFunctor {
-    const u8* text; u64 n_text; u64* bits; u64* mask;
+    const u8* text; u64 n_text; u64* bits; u32* mask32;
     AC_HD void operator()(u64 tid) const {
-        u64 base = tid * 64;
-        u64 w0 = 0, w1 = 0, m = 0;
-        for (int i = 0; i < 64; i++) {
-            u64 p = base + (u64)i;
-            u32 c = 0, bad = 1;
-            if (p < n_text) {
-                u32 ch = text[p];
-                bad = !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
-                c = bad ? 0u : (((ch >> 1) ^ (ch >> 2)) & 3u);
-            }
-            if (i < 32) w0 |= (u64)c << (62 - 2 * i); else w1 |= (u64)c << (62 - 2 * (i - 32));
-            m |= (u64)bad << i;
-        }
-        bits[2 * tid] = w0; bits[2 * tid + 1] = w1; mask[tid] = m;
-    }
-};
-
-// Shared streaming skeleton: thread handles CH consecutive text positions with rolling fwd/rc words.
-// Visitor is called for every *valid* k-mer start p with either a real k-mer (isdot=false: canonical
-// key + flipped) or a dot k-mer (isdot=true).
-template <int W, class Visitor> AC_D void stream_chunk(const TextCtx& t, u64 tid, Visitor& vis) {
-    const int k = t.k;
-    u64 p0 = tid * (u64)CH;
-    if (t.n_text < (u64)k || p0 > t.n_text - (u64)k) return;
-    u64 p1 = p0 + (u64)CH;
-    if (p1 > t.n_text - (u64)k + 1) p1 = t.n_text - (u64)k + 1;
-    Key<W> km = key_kmask<W>(k);
-    Key<W> fwd = text_extract<W>(t.bits, p0, k);
-    Key<W> rc = key_rc<W>(fwd, k);
-    int bad = 0;
-    if (text_mask_count(t.mask, p0, k) > 0) {
-        for (int j = k - 1; j >= 0; j--) if (text_mask(t.mask, p0 + (u64)j)) { bad = j + 1; break; }
-    }
-    for (u64 p = p0; p < p1; p++) {
-        if (p != p0) {
-            u64 e = p + (u64)k - 1;
-            u32 c = text_code(t.bits, e);
-            u32 m = text_mask(t.mask, e);
-            key_roll_fwd<W>(fwd, c, km);
-            key_roll_rc<W>(rc, c, k);
-            bad = m ? k : (bad > 0 ? bad - 1 : 0);
-        }
-        if (bad == 0) {
-            bool flipped = key_lt<W>(rc, fwd);
-            Key<W> uk = flipped ? rc : fwd;
-            uk.w[0] |= (u64)255 << 56;
-            vis.kmer(p, uk, false, flipped);
+        u64 base = tid * 32;
+        u64 w = 0; u32 m = 0;
+        alignas(16) u8 buf[32];
+        if (base + 32 <= n_text && ((uintptr_t)(text + base) & 15) == 0) {
+            const V16* src = (const V16*)(text + base);
+            *(V16*)(buf) = src[0];
+            *(V16*)(buf + 16) = src[1];
         } else {
-            XKmer<W> x;
-            if (!xkmer_at<W>(t, p, &x)) continue;   // window crosses a separator
-            bool flipped;
-            Key<W> uk = xk_canonical<W>(x, k, &flipped);
-            vis.kmer(p, uk, true, flipped);
+            for (int i = 0; i < 32; i++) buf[i] = (base + (u64)i < n_text) ? text[base + (u64)i] : (u8)'$';
         }
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            u32 ch = buf[i];
+            u32 bad = !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
+            u32 c = bad ? 0u : (((ch >> 1) ^ (ch >> 2)) & 3u);
+            w |= (u64)c << (62 - 2 * i);
+            m |= bad << i;
+        }
+        bits[tid] = w; mask32[tid] = m;
     }
-}
-
-// ---- K2: insert every k-mer occurrence (kmer_graph.rs:103-133) ---------------------------------------
-template <int W> struct InsertVisitor {
-    TextCtx t; Table tb; u32* n_claimed; u32* err;
-    AC_D void kmer(u64 p, const Key<W>& uk, bool isdot, bool) { table_insert<W>(t, tb, uk, isdot, p, n_claimed, err); }
 };
+
+// ---- K2: run-following insert of every k-mer occurrence (kmer_graph.rs:103-133) -----------------------
+// The table only has to end up holding, for every canonical k-mer, its SMALLEST text position.  A position p
+// whose k-mer equals the k-mer at an earlier position q can therefore be skipped.  After a real insert at p
+// has met an earlier occurrence q, position p+1+i is skippable as long as base[p+k+i] agrees with the base
+// that extends q the same way (base[q+k+i], or comp(base[q-1-i]) when p reads q's reverse complement): both
+// windows are then identical real k-mers and q+1+i < p+1+i.  The smallest occurrence of a k-mer never has an
+// earlier one, so it is always inserted for real, which is all the final table state depends on.
+// Each thread owns `chunk` consecutive positions of [p_begin, p_end); the host launches the kernel over
+// geometrically growing prefixes of the text so that later phases find the earlier ones in the table.
+struct InsertStats { u64 real; u64 claimed; };
 template <int W> struct InsertFunctor {
-    TextCtx t; Table tb; u32* n_claimed; u32* err;
+    TextCtx t; Table tb; u64 p_begin, p_end; u32 chunk; InsertStats* stats; u32* err;
     AC_D void operator()(u64 tid) const {
-        InsertVisitor<W> v{t, tb, n_claimed, err};
-        stream_chunk<W>(t, tid, v);
+        const int k = t.k;
+        u64 p0 = p_begin + tid * (u64)chunk;
+        if (p0 >= p_end) return;
+        u64 p1 = p0 + (u64)chunk;
+        if (p1 > p_end) p1 = p_end;
+        u32 claimed = 0, real = 0;
+        u64 p = p0;
+        while (p < p1) {
+            real++;
+            if (text_mask_count(t.mask, p, k) == 0) {
+                Key<W> fwd = text_extract<W>(t.bits, p, k);
+                Key<W> rc = key_rc<W>(fwd, k);
+                bool flipped = key_lt<W>(rc, fwd);
+                Key<W> uk = flipped ? rc : fwd;
+                uk.w[0] |= (u64)255 << 56;
+                bool same = false;
+                u64 q = table_insert<W>(t, tb, uk, false, flipped, p, &claimed, err, &same);
+                if (q != NOREF) {
+                    u64 maxlen = p1 - 1 - p;
+                    u64 run = same ? match_run_fwd(t.bits, t.mask, p + (u64)k, q + (u64)k, maxlen)
+                                   : match_run_rev(t.bits, t.mask, p + (u64)k, q - 1, maxlen);
+                    p += run;
+                }
+            } else {
+                XKmer<W> x;
+                if (xkmer_at<W>(t, p, &x)) {    // else: the window crosses a separator
+                    bool flipped, same;
+                    Key<W> uk = xk_canonical<W>(x, k, &flipped);
+                    table_insert<W>(t, tb, uk, true, flipped, p, &claimed, err, &same);
+                }
+            }
+            p++;
+        }
+        InsertStats* st = stats + ((tid >> 6) & 255);
+        atomic_add64(&st->real, (u64)real);
+        if (claimed) atomic_add64(&st->claimed, (u64)claimed);
     }
 };
 
-// ---- K3: table scan -> (novel position, slot) ----------------------------------------------------------
-struct CollectFunctor {
-    const u64* slots; u64* out_pos; u32* out_slot; u32* counter;
+// ---- K3: novel-position bitmap -> sorted novel list + rank support ---------------------------------------
+struct MarkFunctor {
+    const u64* slots; u32* bm32;
     AC_D void operator()(u64 s) const {
         u64 v = slots[s];
         if (v == SLOT_EMPTY) return;
-        u32 i = atomic_add32(counter, 1u);
-        out_pos[i] = slot_pos(v);
-        out_slot[i] = (u32)s;
+        u64 pos = slot_pos(v);
+        atomic_or32(&bm32[pos >> 5], 1u << (pos & 31));
     }
 };
-struct Slot2NFunctor {
-    const u32* nslot; u32* slot2n;
-    AC_HD void operator()(u64 i) const { slot2n[nslot[i]] = (u32)i; }
+struct PopcFunctor {
+    const u64* bm; u32* cnt;
+    AC_HD void operator()(u64 w) const { cnt[w] = (u32)popc64(bm[w]); }
+};
+struct FillNovelFunctor {
+    const u64* bm; const u32* wprefix; u64* npos;
+    AC_HD void operator()(u64 w) const {
+        u64 x = bm[w];
+        u32 i = wprefix[w];
+        while (x) {
+            u64 low = x & (~x + 1);
+            npos[i++] = w * 64 + (u64)popc64(low - 1);
+            x ^= low;
+        }
+    }
 };
 
 // ---- K5: out/in degrees per distinct k-mer (kmer_graph.rs:136-166) -------------------------------------
-template <int W> AC_D int count_successors(const TextCtx& t, const Table& tb, const XKmer<W>& x, int max_c) {
+// `known` (0..4 or -1): a successor symbol already known to be in the set (the k-mer that follows / precedes
+// this one in the text), counted without a probe.
+template <int W> AC_D int count_successors(const TextCtx& t, const Table& tb, const XKmer<W>& x, int max_c, int known) {
     int n = 0;
     for (int c = 0; c < max_c; c++) {
         XKmer<W> y;
         if (!xk_next<W>(x, t.k, c, &y)) continue;
-        u64 slot; bool rel;
-        if (find_xk<W>(t, tb, y, &slot, &rel)) n++;
+        if (c == known) { n++; continue; }
+        u64 pos; bool rel;
+        if (find_xk<W>(t, tb, y, &pos, &rel)) n++;
     }
     return n;
 }
@@ -256,28 +304,33 @@ template <int W> struct DegreeFunctor {
     AC_D void operator()(u64 i) const {
         XKmer<W> x;
         u64 p = npos[i];
-        if (text_mask_count(t.mask, p, t.k) == 0) { x.fwd = text_extract<W>(t.bits, p, t.k); x.ld = 0; x.td = 0; }
-        else if (!xkmer_at<W>(t, p, &x)) return;
+        int known_out = -1, known_in = -1;
+        if (text_mask_count(t.mask, p, t.k) == 0) {
+            x.fwd = text_extract<W>(t.bits, p, t.k); x.ld = 0; x.td = 0;
+            // an unmasked neighbour base means the neighbouring window is a real k-mer of the same sequence
+            if (!text_mask(t.mask, p + (u64)t.k)) known_out = (int)text_code(t.bits, p + (u64)t.k);
+            if (!text_mask(t.mask, p - 1)) known_in = 3 - (int)text_code(t.bits, p - 1);
+        } else if (!xkmer_at<W>(t, p, &x)) return;
         int max_c = any_dots ? 5 : 4;
-        int out = count_successors<W>(t, tb, x, max_c);
+        int out = count_successors<W>(t, tb, x, max_c, known_out);
         XKmer<W> r = xk_rc<W>(x, t.k);
-        int in = count_successors<W>(t, tb, r, max_c);
-        kinfo[i] = (u32)out | ((u32)in << KI_IN_SHIFT);
+        int in = count_successors<W>(t, tb, r, max_c, known_in);
+        kinfo[i] |= (u32)out | ((u32)in << KI_IN_SHIFT);
     }
 };
 
 // ---- K6: first_position flags (kmer_graph.rs:57-60): first forward k-mer of each sequence and the RC of
 // its last forward k-mer sit at pos 0 of a strand.
 template <int W> struct FirstFunctor {
-    TextCtx t; Table tb; const u32* slot2n; u32* kinfo;
+    TextCtx t; Table tb; Novel nv; u32* kinfo;
     AC_D void operator()(u64 s) const {
         for (int which = 0; which < 2; which++) {
             u64 p = t.seq_off[s] + (which ? (u64)t.seq_len[s] - 1 : 0);
             XKmer<W> x;
             if (!xkmer_at<W>(t, p, &x)) continue;
-            u64 slot; bool rel_same;
-            if (!find_xk<W>(t, tb, x, &slot, &rel_same)) continue;
-            u32 j = slot2n[slot];
+            u64 pos; bool rel_same;
+            if (!find_xk<W>(t, tb, x, &pos, &rel_same)) continue;
+            u32 j = novel_rank(nv, pos);
             // which==0: first(X) holds;  which==1: first(rc X) holds.
             bool flag_on_T = (which == 0) ? rel_same : !rel_same;
             atomic_or32(&kinfo[j], flag_on_T ? KI_FIRST_T : KI_FIRST_RCT);
@@ -335,6 +388,7 @@ template <int W> struct UnitigMetaFunctor {
     const u32* order; const u32* ustart; const u64* npos; const MinVal<W>* sorted_min; u32 n_unitigs; u64 n_novel;
     u32* rank; u32* ulen; u64* ulen64; u64* ustartpos; u8* uorient;
     AC_HD void operator()(u64 r) const {
+        if (r == n_unitigs) { ulen64[r] = 0; return; }   // sentinel so the exclusive scan yields the total too
         u32 u = order[r];
         rank[u] = (u32)r;
         u32 a = ustart[u];
@@ -346,84 +400,116 @@ template <int W> struct UnitigMetaFunctor {
     }
 };
 
-// ---- K10: paths, depth and min positions -----------------------------------------------------------------
-template <int W> struct PathVisitor {
-    TextCtx t; Table tb; const u32* slot2n; const u32* head; const u32* scan; const u32* rank; const u8* uorient;
-    const u32* ulen; u64 n_novel;
-    u64* ent_pos; int32_t* ent_val; u64 ent_cap; u32* ent_count; u32* depth; u32* minpos_fwd; u32* minpos_rev;
-    AC_D void kmer(u64 p, const Key<W>& uk, bool isdot, bool flipped) {
-        FindResult fr = table_find<W>(t, tb, uk, isdot);
-        if (!fr.found) return;
-        bool rel_same = ((fr.claimant_flipped != 0) == flipped);
-        u32 j = slot2n[fr.slot];
-        bool is_head = head[j] != 0;
-        bool is_tail = (j + 1 == n_novel) || head[j + 1] != 0;
-        if (!((rel_same && is_head) || (!rel_same && is_tail))) return;
-        u32 r = rank[scan[j] - 1];
-        bool strand = rel_same ? (uorient[r] != 0) : (uorient[r] == 0);
-        u32 i = atomic_add32(ent_count, 1u);
-        if ((u64)i < ent_cap) { ent_pos[i] = p; ent_val[i] = strand ? (int32_t)(r + 1) : -(int32_t)(r + 1); }
-        atomic_add32(&depth[r], 1u);
-        u32 s, f;
-        if (locate(t, p, &s, &f)) {
-            u32 other = t.seq_len[s] - ulen[r] - f;   // position of the same occurrence on the opposite strand
-            if (strand) { atomic_min32(&minpos_fwd[r], f); atomic_min32(&minpos_rev[r], other); }
-            else { atomic_min32(&minpos_rev[r], f); atomic_min32(&minpos_fwd[r], other); }
-        }
-    }
-};
-template <int W> struct PathFunctor {
-    PathVisitor<W> v;
-    AC_D void operator()(u64 tid) const {
-        PathVisitor<W> vis = v;
-        stream_chunk<W>(v.t, tid, vis);
-    }
-};
-struct PathOffFunctor {   // first entry index of each sequence in the position-sorted entry list
-    const u64* ent_pos; u64 n_ent; const u64* seq_off; u32 n_seqs; u64 n_text; u64* path_off;
-    AC_HD void operator()(u64 s) const {
-        u64 target = (s < n_seqs) ? seq_off[s] : n_text;
-        u64 lo = 0, hi = n_ent;
-        while (lo < hi) { u64 mid = (lo + hi) >> 1; if (ent_pos[mid] < target) lo = mid + 1; else hi = mid; }
-        path_off[s] = lo;
-    }
+// Everything a kernel needs to turn a novel index into (unitig in seed order, strand, offsets).
+struct UnitigCtx {
+    const u32* head; const u32* scan; const u32* rank; const u8* uorient; const u32* ustart; const u32* ulen;
+    u32 n_unitigs; u64 n_novel;
 };
 
 // ---- K11: links (unitig_graph.rs:234-287: a's (k-1)-suffix == b's (k-1)-prefix  <=>  b's first k-mer is
-// a successor of a's last k-mer) --------------------------------------------------------------------------
+// a successor of a's last k-mer), stored BY SUCCESSOR SYMBOL so the path kernel can walk them ----------------
 template <int W> struct LinksFunctor {
-    TextCtx t; Table tb; const u32* slot2n; const u32* head; const u32* scan; const u32* rank; const u8* uorient;
-    const u32* order; const u32* ustart; const u64* npos; u32 n_unitigs; u64 n_novel; int any_dots;
-    u8* link_cnt; int32_t* links; u32* err;
+    TextCtx t; Table tb; Novel nv; UnitigCtx uc; const u32* order; const u64* npos; int any_dots;
+    int32_t* links; u32* err;
     AC_D void operator()(u64 idx) const {
         u32 r = (u32)(idx >> 1);
         int side = (int)(idx & 1);           // 0: forward strand's end, 1: reverse strand's end
         u32 u = order[r];
-        u32 ia = ustart[u];
-        u32 ib = ((u + 1 < n_unitigs) ? ustart[u + 1] : (u32)n_novel) - 1;
-        bool o = uorient[r] != 0;
+        u32 ia = uc.ustart[u];
+        u32 ib = ((u + 1 < uc.n_unitigs) ? uc.ustart[u + 1] : (u32)uc.n_novel) - 1;
+        bool o = uc.uorient[r] != 0;
         // forward strand's last k-mer: o ? B : rc(A);  reverse strand's last k-mer: o ? rc(A) : B
         bool use_b = (side == 0) ? o : !o;
         XKmer<W> e;
         if (!xkmer_at<W>(t, npos[use_b ? ib : ia], &e)) { atomic_or32(err, 2u); return; }
         if (!use_b) e = xk_rc<W>(e, t.k);
-        int n = 0;
         int max_c = any_dots ? 5 : 4;
-        for (int c = 0; c < max_c; c++) {
+        for (int c = 0; c < 5; c++) {
+            int32_t val = 0;
             XKmer<W> y;
-            if (!xk_next<W>(e, t.k, c, &y)) continue;
-            u64 slot; bool rel_same;
-            if (!find_xk<W>(t, tb, y, &slot, &rel_same)) continue;
-            u32 j = slot2n[slot];
-            u32 rv = rank[scan[j] - 1];
-            bool strand = rel_same ? (uorient[rv] != 0) : (uorient[rv] == 0);
-            bool is_head = head[j] != 0;
-            bool is_tail = (j + 1 == n_novel) || head[j + 1] != 0;
-            if (!(rel_same ? is_head : is_tail)) atomic_or32(err, 4u);   // successor of an end must start a unitig strand
-            links[idx * 5 + n] = strand ? (int32_t)(rv + 1) : -(int32_t)(rv + 1);
-            n++;
+            u64 pos; bool rel_same;
+            if (c < max_c && xk_next<W>(e, t.k, c, &y) && find_xk<W>(t, tb, y, &pos, &rel_same)) {
+                u32 j = novel_rank(nv, pos);
+                u32 rv = uc.rank[uc.scan[j] - 1];
+                bool strand = rel_same ? (uc.uorient[rv] != 0) : (uc.uorient[rv] == 0);
+                bool is_head = uc.head[j] != 0;
+                bool is_tail = (j + 1 == uc.n_novel) || uc.head[j + 1] != 0;
+                if (!(rel_same ? is_head : is_tail)) atomic_or32(err, 4u);   // successor of an end must start a unitig strand
+                val = strand ? (int32_t)(rv + 1) : -(int32_t)(rv + 1);
+            }
+            links[idx * 5 + (u64)c] = val;
         }
-        link_cnt[idx] = (u8)n;
+    }
+};
+
+// ---- K10: paths, depth and min positions (find_starting_unitig / get_next_unitig, unitig_graph.rs:407-465;
+// simplify_seqs positions, unitig.rs:136-147) ------------------------------------------------------------------
+// Every occurrence of a unitig's first k-mer is followed by the whole unitig, so a sequence
+// path is walked unitig by unitig: ONE table lookup locates the walker inside its first unitig, after that the
+// next unitig is links[(current strand end)][next text symbol] — an L2-resident gather, no hashing.  Thread tid
+// owns the unitig heads that fall into text positions [tid*PC, (tid+1)*PC); pass 1 counts them, an exclusive
+// scan turns counts into offsets, pass 2 writes them, so entries come out in text order without a sort.
+template <int W, bool WRITE> struct PathWalkFunctor {
+    TextCtx t; Table tb; Novel nv; UnitigCtx uc; const int32_t* links; u32 pc;
+    u64* cnt;                 // pass 1: out (entries per thread); pass 2: in (exclusive offsets)
+    int32_t* ent_val; u64* path_off; u32* depth; u32* minpos_fwd; u32* minpos_rev; u32* err;
+    AC_D void emit(u64& idx, u64 p, u32 s, u32 r, bool strand) const {
+        if (WRITE) {
+            ent_val[idx] = strand ? (int32_t)(r + 1) : -(int32_t)(r + 1);
+            atomic_add32(&depth[r], 1u);
+            u32 f = (u32)(p - t.seq_off[s]);
+            u32 other = t.seq_len[s] - uc.ulen[r] - f;   // position of the same occurrence on the opposite strand
+            if (strand) { atomic_min32(&minpos_fwd[r], f); atomic_min32(&minpos_rev[r], other); }
+            else { atomic_min32(&minpos_rev[r], f); atomic_min32(&minpos_fwd[r], other); }
+        }
+        idx++;
+    }
+    AC_D void operator()(u64 tid) const {
+        const int k = t.k;
+        u64 p0 = tid * (u64)pc;
+        if (p0 >= t.n_text) { if (!WRITE) cnt[tid] = 0; return; }
+        u64 p1 = p0 + (u64)pc;
+        if (p1 > t.n_text) p1 = t.n_text;
+        u64 idx = WRITE ? cnt[tid] : 0;
+        const u64 idx0 = idx;
+        // first sequence whose k-mer starts are not all below p0
+        u32 lo = 0, hi = t.n_seqs;
+        while (lo < hi) { u32 mid = lo + ((hi - lo) >> 1); if (t.seq_off[mid] + (u64)t.seq_len[mid] <= p0) lo = mid + 1; else hi = mid; }
+        u32 s = lo;
+        u64 p = p0;
+        while (s < t.n_seqs) {
+            u64 s_begin = t.seq_off[s], s_end = s_begin + (u64)t.seq_len[s];
+            if (p < s_begin) p = s_begin;
+            if (p >= p1) break;
+            if (WRITE && p == s_begin) path_off[s] = idx;
+            // locate the walker: which unitig strand covers the k-mer at p, and where does that unitig end here?
+            XKmer<W> x;
+            u64 pos; bool rel_same;
+            if (!xkmer_at<W>(t, p, &x) || !find_xk<W>(t, tb, x, &pos, &rel_same)) { atomic_or32(err, 8u); break; }
+            u32 j = novel_rank(nv, pos);
+            u32 u = uc.scan[j] - 1;
+            u32 a = uc.ustart[u];
+            u32 b = (u + 1 < uc.n_unitigs) ? uc.ustart[u + 1] : (u32)uc.n_novel;
+            u32 r = uc.rank[u];
+            bool strand = rel_same ? (uc.uorient[r] != 0) : (uc.uorient[r] == 0);
+            if (rel_same) { if (j == a) emit(idx, p, s, r, strand); p += (u64)(b - j); }
+            else { if (j == b - 1) emit(idx, p, s, r, strand); p += (u64)(j - a + 1); }
+            // walk the links
+            bool bad = false;
+            while (p < s_end && p < p1) {
+                u64 e = p + (u64)k - 1;
+                u32 c = text_mask(t.mask, e) ? 4u : text_code(t.bits, e);
+                int32_t val = links[((u64)r * 2 + (strand ? 0 : 1)) * 5 + c];
+                if (val == 0) { atomic_or32(err, 16u); bad = true; break; }
+                strand = val > 0;
+                r = (u32)(strand ? val : -val) - 1;
+                emit(idx, p, s, r, strand);
+                p += (u64)uc.ulen[r];
+            }
+            if (bad) break;
+            if (p >= s_end) s++; else break;   // p >= p1
+        }
+        if (!WRITE) cnt[tid] = idx - idx0;
     }
 };
 
@@ -502,6 +588,10 @@ struct GraphBuilder::Impl {
 };
 
 GraphBuilder::GraphBuilder(uint32_t k) : impl_(new Impl) {
+    // A builder owns the arenas for its lifetime (the C ABI serialises builds): whatever the previous build
+    // left there — device buffers and the pinned RawGraph its host tail has already consumed — is dead.
+    Arena::device().reset();
+    Arena::pinned_host().reset();
     impl_->k = k;
     if (k < 1 || (k % 2) == 0) throw DeviceError("k must be odd");
     if ((int)k > max_supported_k())
@@ -532,35 +622,46 @@ void GraphBuilder::set_text_device(const uint8_t* d_text, uint64_t n_text, const
 
 static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 
+template <class T> static Span<T> pinned(const T* d, size_t n) {
+    Span<T> sp;
+    sp.p = to_pinned_async(d, n);
+    sp.n = n;
+    return sp;
+}
+
 template <int W>
 void GraphBuilder::Impl::build_impl(u32 assembly_count_hint, RawGraph* out, BuildTimings* tm) {
     double t_begin = now_s(), t0 = t_begin;
     auto lap = [&](double* acc) { stream_sync(); double t = now_s(); *acc += t - t0; t0 = t; };
     if (n_text >= POS_MASK) throw DeviceError("input too large for 40-bit text positions");
     if (n_seqs == 0) throw DeviceError("no sequences");
+    if (n_text < (u64)k + 2) throw DeviceError("no sequences");
 
     // K1 pack
     u64 n_bits_words = n_text / 32 + W + 4, n_mask_words = n_text / 64 + 4;
-    DBuf<u64> bits(n_bits_words, true), mask(n_mask_words);
+    DBuf<u64> bits(n_bits_words), mask(n_mask_words);
+    bits.fill_bytes(0);
     mask.fill_bytes(0xFF);
-    launch((n_text + 63) / 64, PackFunctor{d_text, n_text, bits.ptr(), mask.ptr()});
+    launch((n_text + 31) / 32, PackFunctor{d_text, n_text, bits.ptr(), (u32*)mask.ptr()});
     lap(&tm->pack);
 
     TextCtx t{bits.ptr(), mask.ptr(), n_text, (int)k, seq_off.ptr(), seq_len.ptr(), seq_d1.ptr(), seq_d2.ptr(), n_seqs};
-    u64 n_chunks = (n_text + CH - 1) / CH;
+    const u64 p_end_all = n_text - (u64)k + 1;     // one past the last window that fits in the text
 
     // K2 insert.  Capacity from the reference's own capacity hint (assembly_count, kmer_graph.rs:40):
     // similar assemblies share most k-mers.  Overflow -> retry with a larger table.
     u64 est = n_bases / (assembly_count_hint ? assembly_count_hint : 1);
     u64 cap = next_pow2(std::max<u64>(1024, est * 3 + 4096));
     if (cap > next_pow2(n_bases * 2 + 1024)) cap = next_pow2(n_bases * 2 + 1024);
+    DBuf<u32> counters(8);         // [1] insert err, [3] link err, [4] path err
+    DBuf<InsertStats> istats(256);
     DBuf<u64> slots;
-    DBuf<u32> counters(8, true);   // [0] claimed, [1] err, [2] path entries, [3] link err
-    u32 n_distinct = 0;
+    u64 n_distinct = 0;
     for (;;) {
         slots.alloc(cap);
         slots.fill_bytes(0xFF);
         counters.fill_bytes(0);
+        istats.fill_bytes(0);
         Table tb{slots.ptr(), cap - 1};
         stream_sync();
 #ifndef AC_EMU
@@ -568,7 +669,21 @@ void GraphBuilder::Impl::build_impl(u32 assembly_count_hint, RawGraph* out, Buil
         AC_HIP_CHECK(hipEventCreate(&e0)); AC_HIP_CHECK(hipEventCreate(&e1));
         AC_HIP_CHECK(hipEventRecord(e0, 0));
 #endif
-        launch(n_chunks, InsertFunctor<W>{t, tb, counters.ptr(), counters.ptr() + 1});
+        // Phases over geometrically growing prefixes: [0, n/A), [n/A, 2n/A), [2n/A, 4n/A), ...  (A = assembly
+        // count): what a phase streams has, for similar assemblies, mostly been inserted by the earlier ones.
+        u32 launches = 0;
+        u64 first = std::max<u64>(p_end_all / (assembly_count_hint ? assembly_count_hint : 1), 1u << 16);
+        u64 pb = 0;
+        while (pb < p_end_all) {
+            u64 pe = (pb == 0) ? first : pb * 2;
+            if (pe > p_end_all || p_end_all - pe < (1u << 16)) pe = p_end_all;
+            u64 len = pe - pb;
+            u32 chunk = 64;
+            while (chunk < 1024 && len / chunk > (1u << 19)) chunk *= 2;   // >= ~0.5 M threads when the phase is long
+            launch((len + chunk - 1) / chunk, InsertFunctor<W>{t, tb, pb, pe, chunk, istats.ptr(), counters.ptr() + 1});
+            launches++;
+            pb = pe;
+        }
 #ifndef AC_EMU
         AC_HIP_CHECK(hipEventRecord(e1, 0));
         AC_HIP_CHECK(hipEventSynchronize(e1));
@@ -576,33 +691,40 @@ void GraphBuilder::Impl::build_impl(u32 assembly_count_hint, RawGraph* out, Buil
         tm->insert_kernel_ms = ms;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 #endif
+        tm->insert_launches = launches;
         std::vector<u32> c = to_host(counters, 2);
-        n_distinct = c[0];
-        bool overflow = (c[1] != 0) || ((u64)n_distinct * 10 > cap * 7);
+        std::vector<InsertStats> st = to_host(istats, 256);
+        n_distinct = 0; tm->insert_real = 0;
+        for (auto& x : st) { n_distinct += x.claimed; tm->insert_real += x.real; }
+        bool overflow = (c[1] != 0) || (n_distinct * 10 > cap * 7);
         if (!overflow) break;
         if (cap >= next_pow2(n_bases * 4 + 1024)) throw DeviceError("k-mer table overflow");
         cap *= 4;
     }
+    if (n_distinct >= 0xFFFFFFF0ULL) throw DeviceError("too many distinct k-mers for 32-bit novel indices");
     tm->insert_positions = n_text;
     tm->table_capacity = cap;
     tm->n_distinct = n_distinct;
     Table tb{slots.ptr(), cap - 1};
     lap(&tm->insert);
 
-    // K3 collect + sort by position -> novel list
+    // K3 novel-position bitmap -> sorted novel list + rank support
     u64 N = n_distinct;
-    DBuf<u64> npos(N); DBuf<u32> nslot(N);
-    counters.fill_bytes(0);
-    launch(cap, CollectFunctor{slots.ptr(), npos.ptr(), nslot.ptr(), counters.ptr()});
-    sort_pairs_u64_u32(npos, nslot, N, 40);
-    DBuf<u32> slot2n(cap);
-    launch(N, Slot2NFunctor{nslot.ptr(), slot2n.ptr()});
+    u64 n_bm_words = n_text / 64 + 1;
+    DBuf<u64> bm(n_bm_words); DBuf<u32> wcnt(n_bm_words), wprefix(n_bm_words);
+    bm.fill_bytes(0);
+    launch(cap, MarkFunctor{slots.ptr(), (u32*)bm.ptr()});
+    launch(n_bm_words, PopcFunctor{bm.ptr(), wcnt.ptr()});
+    exclusive_scan_u32(wcnt.ptr(), wprefix.ptr(), n_bm_words);
+    DBuf<u64> npos(N);
+    launch(n_bm_words, FillNovelFunctor{bm.ptr(), wprefix.ptr(), npos.ptr()});
+    Novel nv{bm.ptr(), wprefix.ptr()};
     lap(&tm->collect_sort);
 
     // K5/K6 degrees + first flags
     DBuf<u32> kinfo(N, true);
     launch(N, DegreeFunctor<W>{t, tb, npos.ptr(), kinfo.ptr(), any_dots});
-    launch(n_seqs, FirstFunctor<W>{t, tb, slot2n.ptr(), kinfo.ptr()});
+    launch(n_seqs, FirstFunctor<W>{t, tb, nv, kinfo.ptr()});
     lap(&tm->degree);
 
     // K7 heads -> unitig ids
@@ -627,40 +749,34 @@ void GraphBuilder::Impl::build_impl(u32 assembly_count_hint, RawGraph* out, Buil
     DBuf<u32> order(U);
     launch(U, IotaFunctor{order.ptr()});
     sort_by_key_cmp(umin, order, U, MinValLess<W>());
-    DBuf<u32> rank(U), ulen(U); DBuf<u64> ulen64(U), ustartpos(U), useq_off(U + 1); DBuf<u8> uorient(U);
-    launch(U, UnitigMetaFunctor<W>{order.ptr(), ustart.ptr(), npos.ptr(), umin.ptr(), U, N, rank.ptr(), ulen.ptr(),
-                                   ulen64.ptr(), ustartpos.ptr(), uorient.ptr()});
-    exclusive_scan_u64(ulen64.ptr(), useq_off.ptr(), U);
+    DBuf<u32> rank(U), ulen(U); DBuf<u64> ulen64(U + 1), ustartpos(U), useq_off(U + 1); DBuf<u8> uorient(U);
+    launch((u64)U + 1, UnitigMetaFunctor<W>{order.ptr(), ustart.ptr(), npos.ptr(), umin.ptr(), U, N, rank.ptr(), ulen.ptr(),
+                                            ulen64.ptr(), ustartpos.ptr(), uorient.ptr()});
+    exclusive_scan_u64(ulen64.ptr(), useq_off.ptr(), (u64)U + 1);
+    UnitigCtx uc{head.ptr(), scan.ptr(), rank.ptr(), uorient.ptr(), ustart.ptr(), ulen.ptr(), U, N};
     lap(&tm->rank);
 
-    // K10 paths
+    // K11 links by successor symbol
+    DBuf<int32_t> links((u64)U * 10);
+    launch((u64)U * 2, LinksFunctor<W>{t, tb, nv, uc, order.ptr(), npos.ptr(), any_dots, links.ptr(), counters.ptr() + 3});
+    lap(&tm->links);
+
+    // K10 paths: count, scan, write
+    const u32 PC = 256;
+    u64 n_walkers = (n_text + PC - 1) / PC;
     DBuf<u32> depth(U, true), minpos_fwd(U), minpos_rev(U);
     minpos_fwd.fill_bytes(0xFF); minpos_rev.fill_bytes(0xFF);
-    u64 ent_cap = std::min<u64>(n_bases, std::max<u64>(1u << 20, n_bases / 4));
-    DBuf<u64> ent_pos; DBuf<int32_t> ent_val;
-    u64 n_ent = 0;
-    for (;;) {
-        ent_pos.alloc(ent_cap); ent_val.alloc(ent_cap);
-        counters.fill_bytes(0);
-        depth.fill_bytes(0); minpos_fwd.fill_bytes(0xFF); minpos_rev.fill_bytes(0xFF);
-        PathVisitor<W> pv{t, tb, slot2n.ptr(), head.ptr(), scan.ptr(), rank.ptr(), uorient.ptr(), ulen.ptr(), N,
-                          ent_pos.ptr(), ent_val.ptr(), ent_cap, counters.ptr() + 2, depth.ptr(), minpos_fwd.ptr(), minpos_rev.ptr()};
-        launch(n_chunks, PathFunctor<W>{pv});
-        n_ent = read_scalar(counters.ptr() + 2);
-        if (n_ent <= ent_cap) break;
-        ent_cap = n_ent;
-    }
-    sort_pairs_u64_i32(ent_pos, ent_val, n_ent, 40);
-    DBuf<u64> path_off(n_seqs + 1);
-    launch(n_seqs + 1, PathOffFunctor{ent_pos.ptr(), n_ent, seq_off.ptr(), n_seqs, n_text, path_off.ptr()});
+    DBuf<u64> wcount(n_walkers + 1), woff(n_walkers + 1), path_off(n_seqs + 1);
+    wcount.fill_bytes(0);
+    launch(n_walkers, PathWalkFunctor<W, false>{t, tb, nv, uc, links.ptr(), PC, wcount.ptr(), nullptr, nullptr, nullptr, nullptr,
+                                               nullptr, counters.ptr() + 4});
+    exclusive_scan_u64(wcount.ptr(), woff.ptr(), n_walkers + 1);
+    u64 n_ent = read_scalar(woff.ptr() + n_walkers);
+    DBuf<int32_t> ent_val(n_ent);
+    launch(n_walkers, PathWalkFunctor<W, true>{t, tb, nv, uc, links.ptr(), PC, woff.ptr(), ent_val.ptr(), path_off.ptr(), depth.ptr(),
+                                              minpos_fwd.ptr(), minpos_rev.ptr(), counters.ptr() + 4});
     tm->n_path_entries = n_ent;
     lap(&tm->paths);
-
-    // K11 links
-    DBuf<u8> link_cnt((u64)U * 2, true); DBuf<int32_t> links((u64)U * 10, true);
-    launch((u64)U * 2, LinksFunctor<W>{t, tb, slot2n.ptr(), head.ptr(), scan.ptr(), rank.ptr(), uorient.ptr(), order.ptr(),
-                                      ustart.ptr(), npos.ptr(), U, N, any_dots, link_cnt.ptr(), links.ptr(), counters.ptr() + 3});
-    lap(&tm->links);
 
     // K12 sequences
     u64 total = N;   // sum of unitig lengths == number of distinct canonical k-mers
@@ -669,29 +785,30 @@ void GraphBuilder::Impl::build_impl(u32 assembly_count_hint, RawGraph* out, Buil
                                          (int)(k / 2), useq.ptr()});
     lap(&tm->seqs);
 
-    // D2H
+    // D2H into the pinned host arena
     out->k = k;
     out->n_kmers = 2 * (u64)N;
     out->n_unitigs = U;
-    out->len = to_host(ulen, U);
-    out->depth = to_host(depth, U);
-    out->minpos_fwd = to_host(minpos_fwd, U);
-    out->minpos_rev = to_host(minpos_rev, U);
-    out->seq_off = to_host(useq_off, U);
-    out->seq_off.push_back(total);
-    out->seqs.resize(total);
-    copy_d2h(&out->seqs[0], useq.ptr(), total);
-    out->link_cnt = to_host(link_cnt, (u64)U * 2);
-    out->links = to_host(links, (u64)U * 10);
-    out->path_off = to_host(path_off, n_seqs + 1);
-    out->path = to_host(ent_val, n_ent);
-    u32 lerr = read_scalar(counters.ptr() + 3);
-    if (lerr) throw DeviceError("internal error: inconsistent unitig ends (code " + std::to_string(lerr) + ")");
+    out->len = pinned(ulen.ptr(), U);
+    out->depth = pinned(depth.ptr(), U);
+    out->minpos_fwd = pinned(minpos_fwd.ptr(), U);
+    out->minpos_rev = pinned(minpos_rev.ptr(), U);
+    out->seq_off = pinned(useq_off.ptr(), (u64)U + 1);
+    out->seqs = pinned((const char*)useq.ptr(), total);
+    out->links = pinned(links.ptr(), (u64)U * 10);
+    out->path_off = pinned(path_off.ptr(), (u64)n_seqs + 1);
+    out->path = pinned(ent_val.ptr(), n_ent);
+    std::vector<u32> errs = to_host(counters, 8);   // synchronises the stream: everything above has landed
+    ((u64*)out->path_off.p)[n_seqs] = n_ent;
+    if (errs[3] || errs[4])
+        throw DeviceError("internal error: inconsistent unitig ends (codes " + std::to_string(errs[3]) + "/" + std::to_string(errs[4]) + ")");
     lap(&tm->d2h);
     tm->total_device = now_s() - t_begin;
 }
 
 void GraphBuilder::build(uint32_t assembly_count_hint, RawGraph* out) {
+    // Everything the previous build left in the arenas is dead (its RawGraph has been consumed by the host
+    // tail); the sequence table of this builder lives outside the arena.
     BuildTimings keep = tm_;
     tm_ = BuildTimings();
     tm_.h2d = keep.h2d;

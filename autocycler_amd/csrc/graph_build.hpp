@@ -17,20 +17,32 @@ struct SeqView {          // one padded, end-repaired forward sequence as at com
     uint32_t length;      // unpadded length (number of forward k-mers)
 };
 
+// Read-only view of an array in the pinned host arena (valid until the next build on this process).
+template <class T> struct Span {
+    const T* p = nullptr;
+    size_t n = 0;
+    const T& operator[](size_t i) const { return p[i]; }
+    size_t size() const { return n; }
+    const T* data() const { return p; }
+    const T* begin() const { return p; }
+    const T* end() const { return p + n; }
+};
+
 struct RawGraph {
     uint32_t k = 0;
     uint64_t n_kmers = 0;               // KmerGraph.kmers.len(): both strands (compress.rs:152)
     uint32_t n_unitigs = 0;
-    std::vector<uint32_t> len;          // per unitig (seed order): k-mer count == trimmed length
-    std::vector<uint32_t> depth;        // occurrences (unitig.rs:149-156: always integral)
-    std::vector<uint32_t> minpos_fwd;   // min p.pos over forward_positions / reverse_positions
-    std::vector<uint32_t> minpos_rev;   //   (all graph_simplification.rs:164-181 ever asks of them)
-    std::vector<uint64_t> seq_off;      // n_unitigs + 1
-    std::string seqs;                   // concatenated trimmed forward sequences
-    std::vector<uint8_t> link_cnt;      // [2*u + side]: side 0 = forward strand end, 1 = reverse strand end
-    std::vector<int32_t> links;         // [(2*u + side)*5 + j]: signed seed numbers (+: forward strand)
-    std::vector<uint64_t> path_off;     // n_seqs + 1
-    std::vector<int32_t> path;          // signed seed numbers per sequence, in order (unitig_graph.rs:447-465)
+    Span<uint32_t> len;                 // per unitig (seed order): k-mer count == trimmed length
+    Span<uint32_t> depth;               // occurrences (unitig.rs:149-156: always integral)
+    Span<uint32_t> minpos_fwd;          // min p.pos over forward_positions / reverse_positions
+    Span<uint32_t> minpos_rev;          //   (all graph_simplification.rs:164-181 ever asks of them)
+    Span<uint64_t> seq_off;             // n_unitigs + 1
+    Span<char> seqs;                    // concatenated trimmed forward sequences
+    Span<int32_t> links;                // [(2*u + side)*5 + c]: successor of the strand end (side 0 = forward strand,
+                                        //   1 = reverse strand) by next symbol c (ACGT = 0..3, '.' = 4) as a signed
+                                        //   seed number (+: forward strand), 0 = no such successor
+    Span<uint64_t> path_off;            // n_seqs + 1
+    Span<int32_t> path;                 // signed seed numbers per sequence, in order (unitig_graph.rs:447-465)
 };
 
 struct BuildTimings {                   // seconds; device stages are bracketed by stream syncs
@@ -41,6 +53,8 @@ struct BuildTimings {                   // seconds; device stages are bracketed 
     uint64_t table_capacity = 0;
     uint64_t n_distinct = 0;
     uint64_t n_path_entries = 0;
+    uint32_t insert_launches = 0;       // phases of the run-following insert (same kernel, launched per phase)
+    uint64_t insert_real = 0;           // positions that actually touched the table
 };
 
 class GraphBuilder {

@@ -64,17 +64,25 @@ void run_host_tail(RawGraph& raw, const std::vector<uint16_t>& seq_ids, const st
     //                  then b+ (case 3 of iteration a, asc), then a'- for a' > a (asc).
     Csr fnext, rnext;
     fnext.off.assign(U + 1, 0); rnext.off.assign(U + 1, 0);
-    for (uint32_t a = 0; a < U; a++) {
-        fnext.off[a + 1] = fnext.off[a] + raw.link_cnt[2 * a];
-        rnext.off[a + 1] = rnext.off[a] + raw.link_cnt[2 * a + 1];
+    auto gather = [&](uint32_t a, int side, int32_t* tmp) {   // successors by symbol -> compact list
+        int n = 0;
+        const int32_t* src = raw.links.data() + ((size_t)2 * a + side) * 5;
+        for (int c = 0; c < 5; c++) if (src[c] != 0) tmp[n++] = src[c];
+        return n;
+    };
+    {
+        int32_t tmp[5];
+        for (uint32_t a = 0; a < U; a++) {
+            fnext.off[a + 1] = fnext.off[a] + gather(a, 0, tmp);
+            rnext.off[a + 1] = rnext.off[a] + gather(a, 1, tmp);
+        }
     }
     fnext.v.resize(fnext.off[U]); rnext.v.resize(rnext.off[U]);
     uint64_t n_self_rc = 0;
     for (uint32_t a = 0; a < U; a++) {
         int32_t num = (int32_t)a + 1;
         {
-            int32_t tmp[5]; int n = raw.link_cnt[2 * a];
-            for (int i = 0; i < n; i++) tmp[i] = raw.links[(size_t)(2 * a) * 5 + i];
+            int32_t tmp[5]; int n = gather(a, 0, tmp);
             std::sort(tmp, tmp + n, [](int32_t x, int32_t y) {
                 bool xp = x > 0, yp = y > 0;
                 if (xp != yp) return xp;                 // positives first
@@ -83,8 +91,7 @@ void run_host_tail(RawGraph& raw, const std::vector<uint16_t>& seq_ids, const st
             for (int i = 0; i < n; i++) { fnext.v[fnext.off[a] + i] = tmp[i]; if (tmp[i] == -num) n_self_rc++; }
         }
         {
-            int32_t tmp[5]; int n = raw.link_cnt[2 * a + 1];
-            for (int i = 0; i < n; i++) tmp[i] = raw.links[(size_t)(2 * a + 1) * 5 + i];
+            int32_t tmp[5]; int n = gather(a, 1, tmp);
             auto cls = [num](int32_t x) { if (x > 0) return 1; return (-x <= num) ? 0 : 2; };
             std::sort(tmp, tmp + n, [&](int32_t x, int32_t y) {
                 int cx = cls(x), cy = cls(y);
@@ -102,7 +109,7 @@ void run_host_tail(RawGraph& raw, const std::vector<uint16_t>& seq_ids, const st
     // ---- 2. sequences, first renumber_unitigs (unitig_graph.rs:295-315): STABLE sort on seed order ---------
     std::vector<USeq> us(U);
     for (uint32_t r = 0; r < U; r++) { us[r].p = raw.seqs.data() + raw.seq_off[r]; us[r].len = raw.len[r]; }
-    std::vector<uint32_t> minf = raw.minpos_fwd, minr = raw.minpos_rev;
+    std::vector<uint32_t> minf(raw.minpos_fwd.begin(), raw.minpos_fwd.end()), minr(raw.minpos_rev.begin(), raw.minpos_rev.end());
     auto unitig_less = [&](uint32_t a, uint32_t b) {
         if (us[a].len != us[b].len) return us[a].len > us[b].len;
         int c = memcmp(us[a].p, us[b].p, us[a].len);
@@ -304,7 +311,7 @@ void run_host_tail(RawGraph& raw, const std::vector<uint16_t>& seq_ids, const st
         for (uint32_t j = 0; j < rnext.count(r); j++)
             out->links.push_back(Link{i + 1, 0, final_number[idx_of(p[j])], (uint8_t)(p[j] > 0)});
     }
-    out->path_off = raw.path_off;
+    out->path_off.assign(raw.path_off.begin(), raw.path_off.end());
     out->path.resize(raw.path.size());
     for (size_t i = 0; i < raw.path.size(); i++) {
         int32_t v = raw.path[i];

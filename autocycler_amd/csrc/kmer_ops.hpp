@@ -173,6 +173,88 @@ AC_HD int text_mask_count(const u64* mask, u64 p, int n) {
     return cnt;
 }
 
+// ---- word-at-a-time run matching over the packed text ---------------------------------------------
+// Used by the run-following insert (graph_build.hip): once a k-mer occurrence at p is known to equal an
+// EARLIER occurrence at q, every following position whose next base also agrees is an occurrence of a
+// k-mer that already has an earlier occurrence, so it needs no table access at all.
+AC_HD int clz64(u64 x) {
+#ifdef AC_EMU
+    return x ? __builtin_clzll(x) : 64;
+#else
+    return x ? __clzll((long long)x) : 64;
+#endif
+}
+AC_HD int ctz32(u32 x) {
+#ifdef AC_EMU
+    return x ? __builtin_ctz(x) : 32;
+#else
+    return x ? (__ffs((int)x) - 1) : 32;
+#endif
+}
+AC_HD u32 brev32(u32 x) {
+#ifdef AC_EMU
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    return __builtin_bswap32(x);
+#else
+    return __brev(x);
+#endif
+}
+// 32 bases starting at p (first base most significant).
+AC_HD u64 text_word(const u64* bits, u64 p) {
+    u64 j = p >> 5;
+    int o = 2 * (int)(p & 31);
+    u64 a = bits[j];
+    return o ? ((a << o) | (bits[j + 1] >> (64 - o))) : a;
+}
+// Mask bits of positions p .. p+31 (bit i = position p+i).
+AC_HD u32 mask_word(const u64* mask, u64 p) {
+    u64 j = p >> 6;
+    int o = (int)(p & 63);
+    u64 a = mask[j] >> o;
+    if (o > 32) a |= mask[j + 1] << (64 - o);
+    return (u32)a;
+}
+// Reverse-complemented view: complement of bases p, p-1, ..., p-31 (comp(base p) most significant), and
+// the mask bits in the same order (bit i = position p-i).  Positions below 0 read as masked.
+AC_HD u64 text_word_rc(const u64* bits, u64 p) {
+    u64 w = (p >= 31) ? text_word(bits, p - 31) : (text_word(bits, 0) >> (2 * (31 - (int)p)));
+    return ~rev2_64(w);
+}
+AC_HD u32 mask_word_rev(const u64* mask, u64 p) {
+    u32 m = (p >= 31) ? mask_word(mask, p - 31)
+                      : ((mask_word(mask, 0) << (31 - (int)p)) | ((1u << (31 - (int)p)) - 1u));
+    return brev32(m);
+}
+// Number of i in [0, maxlen) with base[a+j] == base[b+j] and neither masked, for all j <= i.
+AC_HD u64 match_run_fwd(const u64* bits, const u64* mask, u64 a, u64 b, u64 maxlen) {
+    u64 n = 0;
+    while (n < maxlen) {
+        u64 x = text_word(bits, a + n) ^ text_word(bits, b + n);
+        u32 m = mask_word(mask, a + n) | mask_word(mask, b + n);
+        int d = clz64(x) >> 1, e = ctz32(m);
+        int t = d < e ? d : e;
+        n += (u64)t;
+        if (t < 32) break;
+    }
+    return n < maxlen ? n : maxlen;
+}
+// Number of i in [0, maxlen) with comp(base[a+j]) == base[b-j] and neither masked, for all j <= i.
+AC_HD u64 match_run_rev(const u64* bits, const u64* mask, u64 a, u64 b, u64 maxlen) {
+    u64 n = 0;
+    while (n < maxlen) {
+        if (b < n) break;   // ran off the start of the text (position 0 is a separator, so unreachable)
+        u64 x = text_word(bits, a + n) ^ text_word_rc(bits, b - n);
+        u32 m = mask_word(mask, a + n) | mask_word_rev(mask, b - n);
+        int d = clz64(x) >> 1, e = ctz32(m);
+        int t = d < e ? d : e;
+        n += (u64)t;
+        if (t < 32) break;
+    }
+    return n < maxlen ? n : maxlen;
+}
+
 // ---- extended k-mers (with dots) ----------------------------------------------------------------
 template <int W>
 struct XKmer {

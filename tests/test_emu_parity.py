@@ -36,6 +36,32 @@ def test_key_word_boundaries(emu, k):   # k around the 1/2/3/4-word key boundari
         parity_util.check_case(k, seqs, fn, hd, lib_path=emu)
 
 
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("k", [5, 11, 31, 51])
+def test_scheduling_independence(emu, monkeypatch, order, k):
+    # The emulation visits the logical threads of every launch in descending / pseudo-random order: the
+    # run-following insert, the atomics and the two-pass path walk must not depend on scheduling.
+    monkeypatch.setenv("AC_EMU_ORDER", str(order))
+    for seed in range(24):
+        seqs, fn, hd = seqgen.make_case(seed, k)
+        parity_util.check_case(k, seqs, fn, hd, lib_path=emu, repair=(seed % 2 == 0))
+
+
+@pytest.mark.parametrize("order", [0, 2])
+def test_synthetic_assemblies_emu(emu, monkeypatch, order):
+    # long shared runs with sparse variants: the regime the run-following insert and the link-walking path
+    # kernel are built for (scaled-down BASELINE config B)
+    from autocycler_amd import synth
+    monkeypatch.setenv("AC_EMU_ORDER", str(order))
+    seqs, fn, hd = [], [], []
+    for i, contigs in enumerate(synth.make_assemblies(6, genome=60_000, plasmid=3_000, sub=1e-3, indel=1e-4, seed=99)):
+        for header, s in contigs:
+            seqs.append(s.tobytes().decode()); fn.append(f"assembly_{i:04d}.fasta"); hd.append(header)
+    g, _, _ = parity_util.check_case(51, seqs, fn, hd, lib_path=emu)
+    tm = g.timings()
+    assert tm["insert_real"] < tm["insert_positions"] // 2     # most positions were run-followed, not inserted
+
+
 def test_accessors(emu):
     seqs, fn, hd = seqgen.make_case(2, 9)
     g, gfa, loaded = parity_util.check_case(9, seqs, fn, hd, lib_path=emu)

@@ -11,7 +11,13 @@ import sys
 def short(name):
     name = re.sub(r"^void ", "", name)
     name = name.replace("ac::", "")
-    return name
+    m = re.match(r"rocprim::ROCPRIM_\w+::detail::(\w+)<rocprim::ROCPRIM_\w+::detail::wrapped_(\w+?)_config<", name)
+    if m:   # rocPRIM kernels carry their whole instantiation in the name: keep the primitive only
+        return f"rocprim::{m.group(2)} ({m.group(1)})"
+    m = re.match(r"rocprim::ROCPRIM_\w+::detail::(\w+)", name)
+    if m:
+        return f"rocprim::{m.group(1)}"
+    return re.sub(r"\(.*$", "", name)
 
 
 def main(path):

@@ -40,7 +40,8 @@ class Timings(C.Structure):
                                           "rank", "paths", "links", "seqs", "d2h", "total_device", "host_tail",
                                           "insert_kernel_ms")] + \
                [(n, C.c_uint64) for n in ("insert_positions", "table_capacity", "n_distinct", "n_path_entries")] + \
-               [("simplify_passes", C.c_uint32), ("insert_launches", C.c_uint32), ("insert_real", C.c_uint64)]
+               [("simplify_passes", C.c_uint32), ("insert_launches", C.c_uint32), ("insert_real", C.c_uint64),
+                ("analysis", C.c_double), ("finalize", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

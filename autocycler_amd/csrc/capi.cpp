@@ -73,6 +73,17 @@ static void validate(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs) {
     }
 }
 
+// compress.rs:42-44 behind the ABI: device build (k-mer table .. paths, link order, candidates, first renumber),
+// the sequential expand_repeats on the host, device finalisation (second renumber, final numbering everywhere).
+static void build_graph(GraphBuilder& b, uint32_t assembly_count, ac_graph* h) {
+    RawGraph raw;
+    b.build(assembly_count, &raw);
+    TailResult tail;
+    run_expand_repeats(raw, b.staging(), &tail);
+    b.finalize(tail, h->seq_lens, h->seq_ids, &h->g);
+    h->tm = b.timings();
+}
+
 extern "C" {
 
 const char* ac_last_error(void) { return g_err.c_str(); }
@@ -126,10 +137,7 @@ int ac_compress_build(uint32_t k, uint32_t assembly_count, const ac_seq_view* se
         }
         GraphBuilder b(k);
         b.set_sequences_host(v);
-        RawGraph raw;
-        b.build(assembly_count, &raw);
-        h->tm = b.timings();
-        run_host_tail(raw, h->seq_ids, h->seq_lens, &h->g);
+        build_graph(b, assembly_count, h.get());
         *out = h.release();
     });
 }
@@ -151,10 +159,7 @@ int ac_compress_build_device(uint32_t k, uint32_t assembly_count, const void* d_
         h->seq_lens = len;
         GraphBuilder b(k);
         b.set_text_device((const uint8_t*)d_text, n_text, off, len, d1, d2);
-        RawGraph raw;
-        b.build(assembly_count, &raw);
-        h->tm = b.timings();
-        run_host_tail(raw, h->seq_ids, h->seq_lens, &h->g);
+        build_graph(b, assembly_count, h.get());
         *out = h.release();
     });
 }
@@ -162,17 +167,17 @@ int ac_compress_build_device(uint32_t k, uint32_t assembly_count, const void* d_
 uint64_t ac_kmer_count(const ac_graph* g) { return g->g.n_kmers; }
 ac_stats ac_stats_pre(const ac_graph* g) { return ac_stats{g->g.pre.unitigs, g->g.pre.links_one_way, g->g.pre.total_length}; }
 ac_stats ac_stats_post(const ac_graph* g) { return ac_stats{g->g.post.unitigs, g->g.post.links_one_way, g->g.post.total_length}; }
-uint32_t ac_unitig_count(const ac_graph* g) { return (uint32_t)g->g.seqs.size(); }
+uint32_t ac_unitig_count(const ac_graph* g) { return g->g.n_unitigs; }
 
 int ac_unitig(const ac_graph* g, uint32_t idx, const uint8_t** seq, uint32_t* len, double* depth) {
-    if (idx >= g->g.seqs.size()) { g_err = "unitig index out of range"; return 1; }
-    if (seq) *seq = (const uint8_t*)g->g.seqs[idx].data();
-    if (len) *len = (uint32_t)g->g.seqs[idx].size();
+    if (idx >= g->g.n_unitigs) { g_err = "unitig index out of range"; return 1; }
+    if (seq) *seq = (const uint8_t*)g->g.seq(idx);
+    if (len) *len = g->g.seq_len[idx];
     if (depth) *depth = g->g.depth[idx];
     return 0;
 }
 int ac_unitig_positions(ac_graph* g, uint32_t idx, int forward, const ac_position** positions, uint32_t* n) {
-    if (idx >= g->g.seqs.size()) { g_err = "unitig index out of range"; return 1; }
+    if (idx >= g->g.n_unitigs) { g_err = "unitig index out of range"; return 1; }
     return guarded([&] {
         if (!g->positions_built) { build_positions(&g->g, g->seq_ids, g->seq_lens); g->positions_built = true; }
         auto& v = forward ? g->g.fwd_positions[idx] : g->g.rev_positions[idx];
@@ -183,14 +188,14 @@ int ac_unitig_positions(ac_graph* g, uint32_t idx, int forward, const ac_positio
 }
 int ac_links(const ac_graph* g, const ac_link** links, uint64_t* n) {
     static_assert(sizeof(ac_link) == sizeof(Link), "layout");
-    *links = (const ac_link*)g->g.links.data();
-    *n = g->g.links.size();
+    *links = (const ac_link*)g->g.links;
+    *n = g->g.n_links;
     return 0;
 }
 int ac_path(const ac_graph* g, uint32_t seq_index, const int32_t** signed_unitigs, uint32_t* n) {
     if ((size_t)seq_index + 1 >= g->g.path_off.size()) { g_err = "sequence index out of range"; return 1; }
     uint64_t b = g->g.path_off[seq_index], e = g->g.path_off[seq_index + 1];
-    *signed_unitigs = g->g.path.data() + b;
+    *signed_unitigs = g->g.path + b;
     *n = (uint32_t)(e - b);
     return 0;
 }
@@ -203,6 +208,7 @@ int ac_timings_get(const ac_graph* g, ac_timings* o) {
     o->table_capacity = t.table_capacity; o->n_distinct = t.n_distinct; o->n_path_entries = t.n_path_entries;
     o->simplify_passes = (uint32_t)g->g.simplify_passes;
     o->insert_launches = t.insert_launches; o->insert_real = t.insert_real;
+    o->analysis = t.analysis; o->finalize = t.finalize;
     return 0;
 }
 void ac_free(ac_graph* g) { delete g; }

@@ -11,7 +11,10 @@
 #include <vector>
 #include <algorithm>
 
+#include <mutex>
+
 #include "kmer_ops.hpp"
+#include "graph_types.hpp"
 
 #ifndef AC_EMU
 #include <hip/hip_runtime.h>
@@ -128,6 +131,66 @@ class Arena {
     size_t peak_ = 0;
 };
 
+// Recycling pool of pinned host blocks for results that outlive a build (they are owned by the caller's graph
+// handle).  hipHostMalloc costs milliseconds for tens of MB; in steady state (free the previous graph, build the
+// next) every block is reused.
+class PinnedPool {
+  public:
+    static PinnedPool& get() { static PinnedPool p; return p; }
+    HostBlock alloc(size_t bytes) {
+        if (bytes == 0) bytes = 1;
+        HostBlock b;
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            size_t best = free_.size();
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i].cap >= bytes && free_[i].cap <= 2 * bytes + 4096 && (best == free_.size() || free_[i].cap < free_[best].cap)) best = i;
+            if (best != free_.size()) {
+                b.p = free_[best].p; b.bytes = free_[best].cap;
+                held_ -= free_[best].cap;
+                free_.erase(free_.begin() + (long)best);
+            }
+        }
+        if (!b.p) {
+            size_t cap = bytes + bytes / 8 + 4096;
+#ifdef AC_EMU
+            b.p = malloc(cap);
+            if (!b.p) throw DeviceError("out of host memory");
+#else
+            AC_HIP_CHECK(hipHostMalloc(&b.p, cap, hipHostMallocDefault));
+#endif
+            b.bytes = cap;
+        }
+        b.release = &PinnedPool::give_back;
+        return b;
+    }
+    void trim() {
+        std::lock_guard<std::mutex> lock(mu_);
+        for (auto& e : free_) raw_free(e.p);
+        free_.clear(); held_ = 0;
+    }
+
+  private:
+    struct Entry { void* p; size_t cap; };
+    static void raw_free(void* p) {
+#ifdef AC_EMU
+        free(p);
+#else
+        (void)hipHostFree(p);
+#endif
+    }
+    static void give_back(void* p, size_t cap) {
+        PinnedPool& self = get();
+        std::lock_guard<std::mutex> lock(self.mu_);
+        if (self.free_.size() >= 32 || self.held_ + cap > ((size_t)8 << 30)) { raw_free(p); return; }
+        self.free_.push_back(Entry{p, cap});
+        self.held_ += cap;
+    }
+    std::mutex mu_;
+    std::vector<Entry> free_;
+    size_t held_ = 0;
+};
+
 template <class T>
 class DBuf {   // a typed slice of the device arena (no ownership: the arena reset frees everything)
   public:
@@ -207,6 +270,11 @@ inline void stream_sync(stream_t s = 0) {
 template <class T> std::vector<T> to_host(const DBuf<T>& b, size_t n, stream_t s = 0) {
     std::vector<T> v(n);
     copy_d2h(v.data(), b.ptr(), n * sizeof(T), s);
+    return v;
+}
+template <class T> std::vector<T> to_host_ptr(const T* d, size_t n, stream_t s = 0) {
+    std::vector<T> v(n);
+    copy_d2h(v.data(), d, n * sizeof(T), s);
     return v;
 }
 template <class T> T read_scalar(const T* dptr, stream_t s = 0) {
@@ -379,6 +447,22 @@ inline void sort_by_key_cmp(DBuf<K>& keys, DBuf<u32>& vals, size_t n, Cmp cmp, s
     AC_HIP_CHECK(rocprim::merge_sort(tmp.ptr(), tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, cmp, s));
     keys = std::move(k2);
     vals = std::move(v2);
+#endif
+}
+
+// Stable sort of u32 keys with a comparator (the comparator usually dereferences per-key device arrays).
+template <class Cmp>
+inline void sort_keys_cmp(DBuf<u32>& keys, size_t n, Cmp cmp, stream_t s = 0) {
+    if (n <= 1) return;
+#ifdef AC_EMU
+    std::stable_sort(keys.ptr(), keys.ptr() + n, cmp);
+#else
+    DBuf<u32> k2(n);
+    size_t tmp_bytes = 0;
+    AC_HIP_CHECK(rocprim::merge_sort(nullptr, tmp_bytes, keys.ptr(), k2.ptr(), n, cmp, s));
+    DBuf<u8> tmp(tmp_bytes);
+    AC_HIP_CHECK(rocprim::merge_sort(tmp.ptr(), tmp_bytes, keys.ptr(), k2.ptr(), n, cmp, s));
+    keys = std::move(k2);
 #endif
 }
 

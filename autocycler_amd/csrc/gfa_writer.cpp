@@ -14,16 +14,17 @@ static inline void put_u64(std::string& s, uint64_t v) {
 std::string gfa_string(const FinalGraph& g, const std::vector<SeqMeta>& seqs) {
     std::string out;
     size_t est = 64;
-    for (auto& s : g.seqs) est += s.size() + 32;
-    est += g.links.size() * 32 + g.path.size() * 10 + seqs.size() * 256;
+    est += g.post.total_length + (size_t)g.n_unitigs * 32;
+    est += g.n_links * 32 + g.n_path * 10 + seqs.size() * 256;
     out.reserve(est);
     out += "H\tVN:Z:1.0\tKM:i:"; put_u64(out, g.k); out.push_back('\n');
-    for (size_t i = 0; i < g.seqs.size(); i++) {
-        out += "S\t"; put_u64(out, i + 1); out.push_back('\t'); out += g.seqs[i]; out += "\tDP:f:";
+    for (uint32_t i = 0; i < g.n_unitigs; i++) {
+        out += "S\t"; put_u64(out, (uint64_t)i + 1); out.push_back('\t'); out.append(g.seq(i), g.seq_len[i]); out += "\tDP:f:";
         char buf[64]; snprintf(buf, sizeof buf, "%.2f", g.depth[i]);   // Rust {:.2}
         out += buf; out.push_back('\n');
     }
-    for (auto& l : g.links) {
+    for (uint64_t li = 0; li < g.n_links; li++) {
+        const Link& l = g.links[li];
         out += "L\t"; put_u64(out, l.a); out += l.a_fwd ? "\t+\t" : "\t-\t"; put_u64(out, l.b);
         out += l.b_fwd ? "\t+\t0M\n" : "\t-\t0M\n";
     }

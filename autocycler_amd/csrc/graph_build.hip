@@ -513,6 +513,160 @@ template <int W, bool WRITE> struct PathWalkFunctor {
     }
 };
 
+// ---- K13: create_links' push order (unitig_graph.rs:248-286), a function of seed numbers only:
+//   forward_next(a): all b+ (seed order ascending) then all b- (ascending);
+//   reverse_next(a): a'- for a' <= a (ascending; a' == a is the a+ -> a+ self loop pushed in case 1 of iteration a),
+//                    then b+ (case 3 of iteration a, ascending), then a'- for a' > a (ascending).
+AC_HD u32 idx_of(int32_t v) { return (u32)(v < 0 ? -v : v) - 1; }
+struct LinkOrderFunctor {
+    const int32_t* sym; int32_t* ord; u8* cnt; u32* n_self_mirror;
+    AC_D void operator()(u64 idx) const {
+        int side = (int)(idx & 1);
+        int32_t num = (int32_t)(idx >> 1) + 1;
+        int32_t tmp[5]; u64 key[5]; int n = 0;
+        for (int c = 0; c < 5; c++) {
+            int32_t v = sym[idx * 5 + (u64)c];
+            if (v == 0) continue;
+            u32 cls = (side == 0) ? (v > 0 ? 0u : 1u) : (v > 0 ? 1u : ((-v <= num) ? 0u : 2u));
+            u64 kv = ((u64)cls << 32) | (u64)(v < 0 ? -v : v);
+            int j = n++;
+            while (j > 0 && key[j - 1] > kv) { key[j] = key[j - 1]; tmp[j] = tmp[j - 1]; j--; }
+            key[j] = kv; tmp[j] = v;
+        }
+        u32 self = 0;
+        for (int i = 0; i < 5; i++) {
+            ord[idx * 5 + (u64)i] = i < n ? tmp[i] : 0;
+            if (i < n && tmp[i] == (side == 0 ? -num : num)) self++;
+        }
+        cnt[idx] = (u8)n;
+        if (self) atomic_add32(n_self_mirror, self);
+    }
+};
+struct OrderedLinks {
+    const int32_t* ord; const u8* cnt;
+    AC_HD const int32_t* next_of(int32_t x, u32* n) const {   // next links of a unitig strand
+        u64 i = (u64)idx_of(x) * 2 + (x > 0 ? 0 : 1);
+        *n = cnt[i];
+        return ord + i * 5;
+    }
+};
+
+// ---- K14: static analysis for expand_repeats -------------------------------------------------------------------
+// Fixed starts/ends (graph_simplification.rs:190-230): first/last unitig of every sequence path plus their one-step
+// neighbours; invariant across passes because paths and links never change.
+struct PathEndsFunctor {
+    const int32_t* path; const u64* path_off; u8* fs0; u8* fe0;
+    AC_HD void operator()(u64 s) const {
+        u64 b = path_off[s], e = path_off[s + 1];
+        if (b == e) return;
+        int32_t first = path[b], last = path[e - 1];
+        if (first > 0) fs0[idx_of(first)] = 1; else fe0[idx_of(first)] = 1;
+        if (last > 0) fe0[idx_of(last)] = 1; else fs0[idx_of(last)] = 1;
+    }
+};
+struct FixedSpreadFunctor {
+    const u8* fs0; const u8* fe0; OrderedLinks L; u8* fixed_start; u8* fixed_end;
+    AC_HD void operator()(u64 u) const {
+        int32_t num = (int32_t)u + 1;
+        if (fs0[u]) {   // upstream of a fixed start: forward_prev(u) = { -e : e in reverse_next(u) }
+            fixed_start[u] = 1;
+            u32 n; const int32_t* p = L.next_of(-num, &n);
+            for (u32 i = 0; i < n; i++) { int32_t up = -p[i]; if (up > 0) fixed_end[idx_of(up)] = 1; else fixed_start[idx_of(up)] = 1; }
+        }
+        if (fe0[u]) {   // downstream of a fixed end
+            fixed_end[u] = 1;
+            u32 n; const int32_t* p = L.next_of(num, &n);
+            for (u32 i = 0; i < n; i++) { int32_t down = p[i]; if (down > 0) fixed_start[idx_of(down)] = 1; else fixed_end[idx_of(down)] = 1; }
+        }
+    }
+};
+// get_exclusive_inputs / get_exclusive_outputs (:233-280) and the fixed-end guards of expand_repeats (:66-83).
+struct CandFunctor {
+    OrderedLinks L; const u8* fixed_start; const u8* fixed_end; u8* cand;
+    AC_HD void operator()(u64 idx) const {
+        u32 x = (u32)(idx >> 1);
+        bool inputs = (idx & 1) == 0;
+        int32_t xnum = (int32_t)x + 1;
+        u32 n; const int32_t* p = L.next_of(inputs ? -xnum : xnum, &n);
+        bool ok = n >= 2 && !(inputs ? fixed_start[x] : fixed_end[x]);
+        for (u32 i = 0; ok && i < n; i++) {
+            int32_t other = inputs ? -p[i] : p[i];
+            // inputs: other's next list must be exactly [x+].  outputs: other's prev list must be exactly [x+],
+            // i.e. the next list of other's opposite strand must be exactly [x-].
+            u32 m; const int32_t* q = L.next_of(inputs ? other : -other, &m);
+            if (!(m == 1 && q[0] == (inputs ? xnum : -xnum))) ok = false;
+            u32 u = idx_of(other);
+            if (u == x) ok = false;
+            if (inputs) { if ((other > 0 && fixed_end[u]) || (other < 0 && fixed_start[u])) ok = false; }
+            else { if ((other > 0 && fixed_start[u]) || (other < 0 && fixed_end[u])) ok = false; }
+        }
+        cand[idx] = ok ? 1 : 0;
+    }
+};
+
+// ---- K15: renumber_unitigs (unitig_graph.rs:295-315): length descending, forward sequence ascending, depth
+// descending; the sort is stable on the incoming order -------------------------------------------------------------
+struct UnitigLess {
+    const u32* len; const u64* off; const u8* seq; const u32* depth;
+    AC_HD bool operator()(const u32& a, const u32& b) const {
+        u32 la = len[a], lb = len[b];
+        if (la != lb) return la > lb;
+        const u8* pa = seq + off[a]; const u8* pb = seq + off[b];
+        for (u32 i = 0; i < la; i++) { u8 ca = pa[i], cb = pb[i]; if (ca != cb) return ca < cb; }
+        return depth[a] > depth[b];
+    }
+};
+
+// ---- K16: finalisation in the final numbering -----------------------------------------------------------------
+struct FinalMetaFunctor {   // per final index i
+    const u32* order2; const u64* foff; const u32* flen; const u32* depth; const u8* lcnt;
+    u64* number_len; u64* seq_begin; double* depth_out; u32* seq_len; u64* lcount;
+    AC_HD void operator()(u64 i) const {
+        u32 r = order2[i];
+        number_len[r] = ((u64)flen[r] << 32) | (u64)(i + 1);
+        seq_begin[i] = foff[r];
+        depth_out[i] = (double)depth[r];
+        seq_len[i] = flen[r];
+        lcount[i] = (u64)lcnt[2 * (u64)r] + (u64)lcnt[2 * (u64)r + 1];
+    }
+};
+struct LinkOutFunctor {     // get_links_for_gfa (unitig_graph.rs:333-350): per final unitig, forward_next then reverse_next
+    const u32* order2; OrderedLinks L; const u64* number_len; const u64* loff; Link* out;
+    AC_HD void operator()(u64 i) const {
+        u32 r = order2[i];
+        u64 w = loff[i];
+        for (int side = 0; side < 2; side++) {
+            u32 n; const int32_t* p = L.next_of(side == 0 ? (int32_t)r + 1 : -((int32_t)r + 1), &n);
+            for (u32 j = 0; j < n; j++) {
+                Link l; l.a = (u32)i + 1; l.a_fwd = side == 0 ? 1 : 0;
+                l.b = (u32)(number_len[idx_of(p[j])] & 0xFFFFFFFFu); l.b_fwd = p[j] > 0 ? 1 : 0;
+                out[w++] = l;
+            }
+        }
+    }
+};
+struct RemapFunctor {       // 64 path entries per thread: seed numbers -> final numbers, per-sequence length sums
+    int32_t* path; const u64* number_len; const u64* path_off; u32 n_seqs; u64 n_ent; u64* sums;
+    AC_D void operator()(u64 tid) const {
+        u64 i0 = tid * 64, i1 = i0 + 64;
+        if (i1 > n_ent) i1 = n_ent;
+        if (i0 >= i1) return;
+        u32 lo = 0, hi = n_seqs;   // largest s with path_off[s] <= i0
+        while (hi - lo > 1) { u32 mid = lo + ((hi - lo) >> 1); if (path_off[mid] <= i0) lo = mid; else hi = mid; }
+        u32 s = lo;
+        u64 acc = 0;
+        for (u64 i = i0; i < i1; i++) {
+            while (s + 1 < n_seqs && i >= path_off[s + 1]) { if (acc) atomic_add64(&sums[s], acc); acc = 0; s++; }
+            int32_t v = path[i];
+            u64 nl = number_len[idx_of(v)];
+            int32_t f = (int32_t)(nl & 0xFFFFFFFFu);
+            path[i] = v > 0 ? f : -f;
+            acc += nl >> 32;
+        }
+        if (acc) atomic_add64(&sums[s], acc);
+    }
+};
+
 // ---- K12: trimmed unitig sequences (unitig.rs:113-166) -----------------------------------------------------
 struct SeqFunctor {
     const u64* bits; const u64* useq_off; const u64* ustartpos; const u32* ulen; const u8* uorient;
@@ -584,6 +738,13 @@ struct GraphBuilder::Impl {
         for (u32 i = 0; i < n_seqs; i++) { n_bases += len[i]; if (d1[i] || d2[i]) any_dots = 1; }
         stream_sync();
     }
+    // device state kept between build() and finalize() (arena memory: valid until the next builder)
+    struct Fin {
+        u32 U = 0; u64 n_ent = 0; u64 total = 0; u64 n_kmers = 0; u64 n_self = 0;
+        int32_t* ent_val = nullptr; u64* path_off = nullptr; u32* depth = nullptr; int32_t* lord = nullptr; u8* lcnt = nullptr;
+        u32* order1 = nullptr;
+    } fin;
+    HostBlock staging;
     template <int W> void build_impl(u32 assembly_count_hint, RawGraph* out, BuildTimings* tm);
 };
 
@@ -785,25 +946,114 @@ void GraphBuilder::Impl::build_impl(u32 assembly_count_hint, RawGraph* out, Buil
                                          (int)(k / 2), useq.ptr()});
     lap(&tm->seqs);
 
-    // D2H into the pinned host arena
+    // K13 link push order, K14 static analysis for expand_repeats, K15 first renumber_unitigs
+    DBuf<int32_t> lord((u64)U * 10); DBuf<u8> lcnt((u64)U * 2);
+    launch((u64)U * 2, LinkOrderFunctor{links.ptr(), lord.ptr(), lcnt.ptr(), counters.ptr() + 5});
+    OrderedLinks L{lord.ptr(), lcnt.ptr()};
+    copy_h2d(path_off.ptr() + n_seqs, &n_ent, 8);
+    DBuf<u8> fs0(U, true), fe0(U, true), fixed_start(U, true), fixed_end(U, true), cand((u64)U * 2);
+    launch(n_seqs, PathEndsFunctor{ent_val.ptr(), path_off.ptr(), fs0.ptr(), fe0.ptr()});
+    launch(U, FixedSpreadFunctor{fs0.ptr(), fe0.ptr(), L, fixed_start.ptr(), fixed_end.ptr()});
+    launch((u64)U * 2, CandFunctor{L, fixed_start.ptr(), fixed_end.ptr(), cand.ptr()});
+    DBuf<u32> order1(U);
+    launch(U, IotaFunctor{order1.ptr()});
+    sort_keys_cmp(order1, U, UnitigLess{ulen.ptr(), useq_off.ptr(), useq.ptr(), depth.ptr()});
+    lap(&tm->analysis);
+
+    // D2H into the pinned host arena (the paths stay on the device until finalize())
     out->k = k;
     out->n_kmers = 2 * (u64)N;
     out->n_unitigs = U;
+    out->n_path_entries = n_ent;
     out->len = pinned(ulen.ptr(), U);
     out->depth = pinned(depth.ptr(), U);
     out->minpos_fwd = pinned(minpos_fwd.ptr(), U);
     out->minpos_rev = pinned(minpos_rev.ptr(), U);
     out->seq_off = pinned(useq_off.ptr(), (u64)U + 1);
     out->seqs = pinned((const char*)useq.ptr(), total);
-    out->links = pinned(links.ptr(), (u64)U * 10);
+    out->links = pinned(lord.ptr(), (u64)U * 10);
+    out->link_cnt = pinned(lcnt.ptr(), (u64)U * 2);
+    out->cand = pinned(cand.ptr(), (u64)U * 2);
+    out->order1 = pinned(order1.ptr(), U);
     out->path_off = pinned(path_off.ptr(), (u64)n_seqs + 1);
-    out->path = pinned(ent_val.ptr(), n_ent);
     std::vector<u32> errs = to_host(counters, 8);   // synchronises the stream: everything above has landed
-    ((u64*)out->path_off.p)[n_seqs] = n_ent;
     if (errs[3] || errs[4])
         throw DeviceError("internal error: inconsistent unitig ends (codes " + std::to_string(errs[3]) + "/" + std::to_string(errs[4]) + ")");
+    out->n_self_mirror_links = errs[5];
+    fin.U = U; fin.n_ent = n_ent; fin.total = total; fin.n_kmers = 2 * (u64)N; fin.n_self = errs[5];
+    fin.ent_val = ent_val.ptr(); fin.path_off = path_off.ptr(); fin.depth = depth.ptr(); fin.lord = lord.ptr(); fin.lcnt = lcnt.ptr();
+    fin.order1 = order1.ptr();
+    staging = PinnedPool::get().alloc(total);
     lap(&tm->d2h);
     tm->total_device = now_s() - t_begin;
+}
+
+char* GraphBuilder::staging() { return (char*)impl_->staging.p; }
+
+void GraphBuilder::finalize(const TailResult& tail, const std::vector<uint32_t>& seq_lens, const std::vector<uint16_t>& seq_ids,
+                            FinalGraph* out) {
+    double t_begin = now_s();
+    Impl::Fin& f = impl_->fin;
+    const u32 U = f.U;
+    const u32 n_seqs = impl_->n_seqs;
+    // final sequences (seed order) -> device; second renumber_unitigs (graph_simplification.rs:39): a stable sort
+    // of the CURRENT order (order1) on the new sequences
+    DBuf<u8> fseq(tail.total_len); DBuf<u64> foff(U); DBuf<u32> flen(U);
+    copy_h2d(fseq.ptr(), impl_->staging.p, tail.total_len);
+    copy_h2d(foff.ptr(), tail.final_off.data(), (size_t)U * 8);
+    copy_h2d(flen.ptr(), tail.final_len.data(), (size_t)U * 4);
+    DBuf<u32> order2(U);
+    copy_d2d(order2.ptr(), f.order1, (size_t)U * 4);
+    sort_keys_cmp(order2, U, UnitigLess{flen.ptr(), foff.ptr(), fseq.ptr(), f.depth});
+    // per-unitig outputs in final order, links in get_links_for_gfa order, paths in final numbers
+    DBuf<u64> number_len(U), lcount((u64)U + 1), loff((u64)U + 1);
+    DBuf<u8> meta((size_t)U * 20);
+    u64* d_seq_begin = (u64*)meta.ptr();
+    double* d_depth = (double*)(meta.ptr() + (size_t)U * 8);
+    u32* d_seq_len = (u32*)(meta.ptr() + (size_t)U * 16);
+    lcount.fill_bytes(0);
+    launch(U, FinalMetaFunctor{order2.ptr(), foff.ptr(), flen.ptr(), f.depth, f.lcnt, number_len.ptr(), d_seq_begin, d_depth,
+                               d_seq_len, lcount.ptr()});
+    exclusive_scan_u64(lcount.ptr(), loff.ptr(), (u64)U + 1);
+    u64 n_links = read_scalar(loff.ptr() + U);
+    DBuf<Link> links_out(n_links);
+    OrderedLinks L{f.lord, f.lcnt};
+    launch(U, LinkOutFunctor{order2.ptr(), L, number_len.ptr(), loff.ptr(), links_out.ptr()});
+    DBuf<u64> sums(n_seqs);
+    sums.fill_bytes(0);
+    launch((f.n_ent + 63) / 64, RemapFunctor{f.ent_val, number_len.ptr(), f.path_off, n_seqs, f.n_ent, sums.ptr()});
+
+    out->k = impl_->k;
+    out->n_kmers = f.n_kmers;
+    out->n_unitigs = U;
+    out->meta_block = PinnedPool::get().alloc((size_t)U * 20);
+    out->links_block = PinnedPool::get().alloc(n_links * sizeof(Link));
+    out->path_block = PinnedPool::get().alloc(f.n_ent * 4);
+    copy_d2h_async(out->meta_block.p, meta.ptr(), (size_t)U * 20);
+    copy_d2h_async(out->links_block.p, links_out.ptr(), n_links * sizeof(Link));
+    copy_d2h_async(out->path_block.p, f.ent_val, f.n_ent * 4);
+    std::vector<u64> h_sums = to_host(sums, n_seqs);   // synchronises
+    std::vector<u64> h_off = to_host_ptr(f.path_off, (size_t)n_seqs + 1);
+    out->seq_block = std::move(impl_->staging);
+    out->seq_begin = (const u64*)out->meta_block.p;
+    out->depth = (const double*)((const u8*)out->meta_block.p + (size_t)U * 8);
+    out->seq_len = (const u32*)((const u8*)out->meta_block.p + (size_t)U * 16);
+    out->links = (const Link*)out->links_block.p;
+    out->n_links = n_links;
+    out->path = (const int32_t*)out->path_block.p;
+    out->n_path = f.n_ent;
+    out->path_off = h_off;
+    u64 links_one_way = (n_links + f.n_self) / 2;   // link_count().1 (unitig_graph.rs:478-507): a link and its mirror
+                                                     // count once; a link that is its own mirror counts once
+    out->pre = GraphStats{U, links_one_way, f.total};
+    out->post = GraphStats{U, links_one_way, tail.total_len};
+    out->simplify_passes = tail.passes;
+    out->tail_seconds = tail.seconds;
+    // The path of every sequence must spell its full length (unitig_graph.rs:160-174, decompress.rs).
+    for (u32 s = 0; s < n_seqs; s++)
+        if (h_sums[s] != seq_lens[s])
+            throw DeviceError("internal error: path length mismatch for sequence " + std::to_string(seq_ids[s]));
+    tm_.finalize = now_s() - t_begin;
 }
 
 void GraphBuilder::build(uint32_t assembly_count_hint, RawGraph* out) {

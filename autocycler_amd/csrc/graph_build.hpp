@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 
+#include "graph_types.hpp"
+
 namespace ac {
 
 struct SeqView {          // one padded, end-repaired forward sequence as at compress.rs:41
@@ -17,37 +19,11 @@ struct SeqView {          // one padded, end-repaired forward sequence as at com
     uint32_t length;      // unpadded length (number of forward k-mers)
 };
 
-// Read-only view of an array in the pinned host arena (valid until the next build on this process).
-template <class T> struct Span {
-    const T* p = nullptr;
-    size_t n = 0;
-    const T& operator[](size_t i) const { return p[i]; }
-    size_t size() const { return n; }
-    const T* data() const { return p; }
-    const T* begin() const { return p; }
-    const T* end() const { return p + n; }
-};
-
-struct RawGraph {
-    uint32_t k = 0;
-    uint64_t n_kmers = 0;               // KmerGraph.kmers.len(): both strands (compress.rs:152)
-    uint32_t n_unitigs = 0;
-    Span<uint32_t> len;                 // per unitig (seed order): k-mer count == trimmed length
-    Span<uint32_t> depth;               // occurrences (unitig.rs:149-156: always integral)
-    Span<uint32_t> minpos_fwd;          // min p.pos over forward_positions / reverse_positions
-    Span<uint32_t> minpos_rev;          //   (all graph_simplification.rs:164-181 ever asks of them)
-    Span<uint64_t> seq_off;             // n_unitigs + 1
-    Span<char> seqs;                    // concatenated trimmed forward sequences
-    Span<int32_t> links;                // [(2*u + side)*5 + c]: successor of the strand end (side 0 = forward strand,
-                                        //   1 = reverse strand) by next symbol c (ACGT = 0..3, '.' = 4) as a signed
-                                        //   seed number (+: forward strand), 0 = no such successor
-    Span<uint64_t> path_off;            // n_seqs + 1
-    Span<int32_t> path;                 // signed seed numbers per sequence, in order (unitig_graph.rs:447-465)
-};
-
 struct BuildTimings {                   // seconds; device stages are bracketed by stream syncs
     double h2d = 0, pack = 0, insert = 0, collect_sort = 0, degree = 0, segment = 0, minkey = 0, rank = 0,
            paths = 0, links = 0, seqs = 0, d2h = 0, total_device = 0;
+    double analysis = 0;                // link push order + expand_repeats candidates + first renumber (device)
+    double finalize = 0;                // device renumbering of the paths + their D2H (after the host tail)
     double insert_kernel_ms = 0;        // event-timed duration of the dominant kernel (k-mer insert)
     uint64_t insert_positions = 0;      // text positions streamed by that launch
     uint64_t table_capacity = 0;
@@ -69,8 +45,15 @@ class GraphBuilder {
     void set_text_device(const uint8_t* d_text, uint64_t n_text, const std::vector<uint64_t>& off,
                          const std::vector<uint32_t>& len, const std::vector<uint16_t>& d1,
                          const std::vector<uint16_t>& d2);
-    // The timed region: packed text -> RawGraph (host).
+    // The timed region, part 1: packed text -> RawGraph (host); the paths stay on the device in seed numbering.
     void build(uint32_t assembly_count_hint, RawGraph* out);
+    // Pinned scratch the host tail writes the final sequences (seed order) into; capacity = RawGraph::seqs.size().
+    char* staging();
+    // Part 2, after expand_repeats: second renumber_unitigs (graph_simplification.rs:39) on the device, paths
+    // renumbered, links / depths / sequence offsets emitted in final order, everything copied into host blocks.
+    // Throws if a sequence's path does not spell its full length (unitig_graph.rs:160-174).
+    void finalize(const TailResult& tail, const std::vector<uint32_t>& seq_lens, const std::vector<uint16_t>& seq_ids,
+                  FinalGraph* out);
     const BuildTimings& timings() const { return tm_; }
     uint64_t n_text() const;
     uint64_t n_bases() const;   // sum of unpadded lengths

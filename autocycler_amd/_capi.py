@@ -37,11 +37,11 @@ class Stats(C.Structure):
 
 class Timings(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("h2d", "pack", "insert", "collect_sort", "degree", "segment", "minkey",
-                                          "rank", "paths", "links", "seqs", "d2h", "total_device", "host_tail",
+                                          "rank", "paths", "links", "seqs", "d2h", "total_device", "expand",
                                           "insert_kernel_ms")] + \
                [(n, C.c_uint64) for n in ("insert_positions", "table_capacity", "n_distinct", "n_path_entries")] + \
                [("simplify_passes", C.c_uint32), ("insert_launches", C.c_uint32), ("insert_real", C.c_uint64),
-                ("analysis", C.c_double), ("finalize", C.c_double)]
+                ("analysis", C.c_double), ("finalize", C.c_double), ("n_candidates", C.c_uint32), ("n_levels", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

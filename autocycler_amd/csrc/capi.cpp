@@ -73,14 +73,9 @@ static void validate(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs) {
     }
 }
 
-// compress.rs:42-44 behind the ABI: device build (k-mer table .. paths, link order, candidates, first renumber),
-// the sequential expand_repeats on the host, device finalisation (second renumber, final numbering everywhere).
+// compress.rs:42-44 behind the ABI: one device pipeline from the packed text to the final UnitigGraph.
 static void build_graph(GraphBuilder& b, uint32_t assembly_count, ac_graph* h) {
-    RawGraph raw;
-    b.build(assembly_count, &raw);
-    TailResult tail;
-    run_expand_repeats(raw, b.staging(), &tail);
-    b.finalize(tail, h->seq_lens, h->seq_ids, &h->g);
+    b.build(assembly_count, &h->g);
     h->tm = b.timings();
 }
 
@@ -203,10 +198,10 @@ int ac_timings_get(const ac_graph* g, ac_timings* o) {
     const BuildTimings& t = g->tm;
     o->h2d = t.h2d; o->pack = t.pack; o->insert = t.insert; o->collect_sort = t.collect_sort; o->degree = t.degree;
     o->segment = t.segment; o->minkey = t.minkey; o->rank = t.rank; o->paths = t.paths; o->links = t.links; o->seqs = t.seqs;
-    o->d2h = t.d2h; o->total_device = t.total_device; o->host_tail = g->g.tail_seconds;
+    o->d2h = t.d2h; o->total_device = t.total_device; o->expand = t.expand;
     o->insert_kernel_ms = t.insert_kernel_ms; o->insert_positions = t.insert_positions;
     o->table_capacity = t.table_capacity; o->n_distinct = t.n_distinct; o->n_path_entries = t.n_path_entries;
-    o->simplify_passes = (uint32_t)g->g.simplify_passes;
+    o->simplify_passes = t.simplify_passes; o->n_candidates = t.n_candidates; o->n_levels = t.n_levels;
     o->insert_launches = t.insert_launches; o->insert_real = t.insert_real;
     o->analysis = t.analysis; o->finalize = t.finalize;
     return 0;

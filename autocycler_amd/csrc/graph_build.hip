@@ -617,6 +617,212 @@ struct UnitigLess {
     }
 };
 
+// ---- K17: expand_repeats on the device (graph_simplification.rs:26-142, shift primitives unitig.rs:217-249) ---------
+// The reference visits junctions sequentially (unitigs in first-renumber order, inputs side then outputs side) and
+// the result depends on that order only where two junctions touch a common unitig.  A junction (x, side) reads and
+// writes x (as the destination that gains sequence) and its exclusive sources (which lose it); everything that
+// decides WHICH junctions qualify is static (K14).  So: number the candidate junctions in visiting order, give
+// every candidate the level 1 + max(level of earlier candidates sharing a unitig with it), and run each pass level
+// by level — candidates of one level never share a unitig, every conflicting pair keeps the reference's order.
+// The two sides of the same destination touch disjoint fields of it (prefix + min forward position vs. suffix + min
+// reverse position) and are not a conflict.
+// A unitig's sequence during a pass is [bytes gained at its start this pass][core view][bytes gained at its end this
+// pass]; after every pass that moved something the sequences are rewritten contiguously.
+struct ExpState {
+    const u8* cur; u64* coff; u32* clen;                       // core: view into the current sequence buffer
+    u32* pre_off; u32* pre_len; u32* post_off; u32* post_len;  // gained this pass: offsets into `pool`
+    u8* pool; u32* pool_used;
+    u32* minf; u32* minr;                                      // min forward / reverse position (graph_simplification.rs:164-181)
+    u8* dirty; const u8* cand;
+    OrderedLinks L;
+    u64* shifted;
+};
+AC_HD u8 comp_base(u8 c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
+AC_HD u32 exp_len(const ExpState& e, u32 u) { return e.pre_len[u] + e.clen[u] + e.post_len[u]; }
+AC_HD u8 exp_at(const ExpState& e, u32 u, u32 i) {
+    u32 pl = e.pre_len[u];
+    if (i < pl) return e.pool[e.pre_off[u] + i];
+    i -= pl;
+    u32 cl = e.clen[u];
+    if (i < cl) return e.cur[e.coff[u] + i];
+    return e.pool[e.post_off[u] + (i - cl)];
+}
+AC_HD u8 exp_from_start(const ExpState& e, int32_t s, u32 i) { u32 u = idx_of(s); return s > 0 ? exp_at(e, u, i) : comp_base(exp_at(e, u, exp_len(e, u) - 1 - i)); }
+AC_HD u8 exp_from_end(const ExpState& e, int32_t s, u32 i) { u32 u = idx_of(s); return s > 0 ? exp_at(e, u, exp_len(e, u) - 1 - i) : comp_base(exp_at(e, u, i)); }
+AC_HD void exp_remove_start(const ExpState& e, u32 u, u32 n) {
+    u32 d = n < e.pre_len[u] ? n : e.pre_len[u]; e.pre_off[u] += d; e.pre_len[u] -= d; n -= d;
+    d = n < e.clen[u] ? n : e.clen[u]; e.coff[u] += d; e.clen[u] -= d; n -= d;
+    e.post_off[u] += n; e.post_len[u] -= n;
+}
+AC_HD void exp_remove_end(const ExpState& e, u32 u, u32 n) {
+    u32 d = n < e.post_len[u] ? n : e.post_len[u]; e.post_len[u] -= d; n -= d;
+    d = n < e.clen[u] ? n : e.clen[u]; e.clen[u] -= d; n -= d;
+    e.pre_len[u] -= n;
+}
+// The (at most four) candidate junctions that read or write unitig u: u as destination (2u, 2u+1) and u as an
+// exclusive source of the junction its only forward / reverse link leads to.  0xFFFFFFFF = none.
+AC_HD void touchers(const OrderedLinks& L, const u8* cand, u32 u, u32 out[4]) {
+    out[0] = cand[2 * (u64)u] ? 2 * u : 0xFFFFFFFFu;
+    out[1] = cand[2 * (u64)u + 1] ? 2 * u + 1 : 0xFFFFFFFFu;
+    for (int side = 0; side < 2; side++) {
+        u32 c = 0xFFFFFFFFu;
+        if (L.cnt[2 * (u64)u + side] == 1) {
+            int32_t p0 = L.ord[(2 * (u64)u + side) * 5];
+            u32 cc = 2 * idx_of(p0) + (p0 > 0 ? 0u : 1u);
+            if (cand[cc]) c = cc;
+        }
+        out[2 + side] = c;
+    }
+}
+struct CandFlagFunctor {    // j = 2*oi + side over the visiting order: is (order1[oi], side) a candidate?
+    const u32* order1; const u8* cand; u32* flag;
+    AC_HD void operator()(u64 j) const { flag[j] = cand[2 * (u64)order1[j >> 1] + (j & 1)] ? 1u : 0u; }
+};
+struct CandListFunctor {
+    const u32* order1; const u32* flag; const u32* pos; u32* clist; u32* prio;
+    AC_HD void operator()(u64 j) const {
+        if (!flag[j]) return;
+        u32 c = 2 * order1[j >> 1] + (u32)(j & 1);
+        clist[pos[j]] = c;
+        prio[c] = pos[j];
+    }
+};
+struct LevelRelaxFunctor {
+    OrderedLinks L; const u8* cand; const u32* clist; const u32* prio; u32* level; u32* changed;
+    AC_D void operator()(u64 ci) const {
+        u32 c = clist[ci];
+        u32 x = c >> 1;
+        bool inputs = (c & 1) == 0;
+        u32 n; const int32_t* p = L.next_of(inputs ? -((int32_t)x + 1) : (int32_t)x + 1, &n);
+        u32 lv = 1;
+        for (u32 i = 0; i <= n; i++) {
+            u32 u = (i == n) ? x : idx_of(p[i]);
+            u32 t[4];
+            touchers(L, cand, u, t);
+            for (int j = 0; j < 4; j++) {
+                u32 c2 = t[j];
+                if (c2 == 0xFFFFFFFFu || c2 == c) continue;
+                if (u == x && (c2 >> 1) == x) continue;     // the other side of the same destination: disjoint fields
+                u32 pr = prio[c2];
+                if (pr < (u32)ci) { u32 l2 = level[pr] + 1; if (l2 > lv) lv = l2; }
+            }
+        }
+        if (lv > level[ci]) { level[ci] = lv; atomic_or32(changed, 1u); }
+    }
+};
+struct LevelKeyFunctor {
+    const u32* level; u64* key;
+    AC_HD void operator()(u64 ci) const { key[ci] = ((u64)level[ci] << 32) | ci; }
+};
+struct LevelBoundsFunctor {   // keys sorted by (level, visiting position): first index of every level
+    const u64* key; u64 n; u32* bstart;
+    AC_HD void operator()(u64 i) const {
+        u32 lv = (u32)(key[i] >> 32);
+        if (i == 0 || (u32)(key[i - 1] >> 32) != lv) bstart[lv] = (u32)i;
+    }
+};
+struct ExpandFunctor {
+    ExpState e; const u32* clist; u64 begin;
+    AC_D void operator()(u64 i) const {
+        u32 c = clist[begin + i];
+        if (!e.dirty[c]) return;    // unchanged since it last shifted nothing: shifts nothing again
+        e.dirty[c] = 0;
+        const u32 x = c >> 1;
+        const bool inputs = (c & 1) == 0;
+        u32 n;
+        const int32_t* p = e.L.next_of(inputs ? -((int32_t)x + 1) : (int32_t)x + 1, &n);
+        // inputs:  forward_prev(x) = { -l : l in reverse_next(x) }   (graph_simplification.rs:233-255)
+        // outputs: forward_next(x)                                    (:258-280)
+        int32_t srcs[5];
+        u32 min_len = 0xFFFFFFFFu;
+        bool dup = false;
+        for (u32 j = 0; j < n; j++) {
+            srcs[j] = inputs ? -p[j] : p[j];
+            u32 l = exp_len(e, idx_of(srcs[j]));
+            if (l < min_len) min_len = l;
+            for (u32 q = 0; q < j; q++) if (idx_of(srcs[q]) == idx_of(srcs[j])) dup = true;
+        }
+        // get_common_end_seq (:298-312) / get_common_start_seq (:283-295) of the source strand sequences
+        u32 amount = 0;
+        while (amount < min_len) {
+            u8 ch = inputs ? exp_from_end(e, srcs[0], amount) : exp_from_start(e, srcs[0], amount);
+            bool same = true;
+            for (u32 j = 1; j < n; j++) {
+                u8 cj = inputs ? exp_from_end(e, srcs[j], amount) : exp_from_start(e, srcs[j], amount);
+                if (cj != ch) { same = false; break; }
+            }
+            if (!same) break;
+            amount++;
+        }
+        if (amount > 0) {   // avoid_zero_len_unitigs (:145-161): trim while min_source_len <= len * dup
+            u32 lim = (min_len - 1) / (dup ? 2u : 1u);
+            if (amount > lim) amount = lim;
+        }
+        if (amount > 0) {   // avoid_start_of_path (:164-181): trim while any forward / reverse position <= len
+            u32 m = inputs ? e.minf[x] : e.minr[x];
+            u32 lim = m > 0 ? m - 1 : 0;
+            if (amount > lim) amount = lim;
+        }
+        if (amount == 0) return;
+        u32 off = atomic_add32(e.pool_used, amount);
+        if (inputs) {   // shift_sequence_1 (:89-119): the LAST `amount` characters of the common suffix move onto x's start
+            for (u32 j = 0; j < amount; j++) e.pool[off + (amount - 1 - j)] = exp_from_end(e, srcs[0], j);
+            for (u32 j = 0; j < n; j++) {
+                u32 u = idx_of(srcs[j]);
+                if (srcs[j] > 0) { exp_remove_end(e, u, amount); e.minr[u] += amount; }       // unitig.rs:226-233
+                else { exp_remove_start(e, u, amount); e.minf[u] += amount; }                  // unitig.rs:217-224
+            }
+            e.pre_off[x] = off; e.pre_len[x] = amount; e.minf[x] -= amount;                    // unitig.rs:235-241
+        } else {        // shift_sequence_2 (:122-142): the FIRST `amount` characters of the common prefix move onto x's end
+            for (u32 j = 0; j < amount; j++) e.pool[off + j] = exp_from_start(e, srcs[0], j);
+            for (u32 j = 0; j < n; j++) {
+                u32 u = idx_of(srcs[j]);
+                if (srcs[j] > 0) { exp_remove_start(e, u, amount); e.minf[u] += amount; }
+                else { exp_remove_end(e, u, amount); e.minr[u] += amount; }
+            }
+            e.post_off[x] = off; e.post_len[x] = amount; e.minr[x] -= amount;                  // unitig.rs:243-249
+        }
+        atomic_add64(e.shifted, (u64)amount);
+        for (u32 j = 0; j <= n; j++) {   // every junction that touches a changed unitig must be looked at again
+            u32 u = (j == n) ? x : idx_of(srcs[j]);
+            u32 t[4];
+            touchers(e.L, e.cand, u, t);
+            for (int q = 0; q < 4; q++) {
+                if (t[q] == 0xFFFFFFFFu) continue;
+                if (u == x && (t[q] >> 1) == x && t[q] != c) continue;   // the destination's other side reads nothing that changed
+                e.dirty[t[q]] = 1;
+            }
+        }
+    }
+};
+struct FillU32Functor { u32* a; u32 v; AC_HD void operator()(u64 i) const { a[i] = v; } };
+struct ExpLenFunctor {
+    ExpState e; u64* len64; u32 n_unitigs;
+    AC_HD void operator()(u64 u) const { len64[u] = u < n_unitigs ? (u64)exp_len(e, (u32)u) : 0; }
+};
+struct MaterializeFunctor {   // 64 output bytes per thread
+    ExpState e; const u64* noff; u32 n_unitigs; u64 total; u8* out;
+    AC_HD void operator()(u64 tid) const {
+        u64 g0 = tid * 64, g1 = g0 + 64;
+        if (g1 > total) g1 = total;
+        if (g0 >= total) return;
+        u32 lo = 0, hi = n_unitigs;   // largest r with noff[r] <= g0
+        while (hi - lo > 1) { u32 mid = lo + ((hi - lo) >> 1); if (noff[mid] <= g0) lo = mid; else hi = mid; }
+        u32 r = lo;
+        for (u64 g = g0; g < g1; g++) {
+            while (g >= noff[r + 1]) r++;
+            out[g] = exp_at(e, r, (u32)(g - noff[r]));
+        }
+    }
+};
+struct ExpResetFunctor {
+    ExpState e; const u64* noff;
+    AC_HD void operator()(u64 u) const {
+        e.clen[u] = (u32)(noff[u + 1] - noff[u]); e.coff[u] = noff[u];
+        e.pre_len[u] = 0; e.post_len[u] = 0; e.pre_off[u] = 0; e.post_off[u] = 0;
+    }
+};
+
 // ---- K16: finalisation in the final numbering -----------------------------------------------------------------
 struct FinalMetaFunctor {   // per final index i
     const u32* order2; const u64* foff; const u32* flen; const u32* depth; const u8* lcnt;
@@ -738,14 +944,7 @@ struct GraphBuilder::Impl {
         for (u32 i = 0; i < n_seqs; i++) { n_bases += len[i]; if (d1[i] || d2[i]) any_dots = 1; }
         stream_sync();
     }
-    // device state kept between build() and finalize() (arena memory: valid until the next builder)
-    struct Fin {
-        u32 U = 0; u64 n_ent = 0; u64 total = 0; u64 n_kmers = 0; u64 n_self = 0;
-        int32_t* ent_val = nullptr; u64* path_off = nullptr; u32* depth = nullptr; int32_t* lord = nullptr; u8* lcnt = nullptr;
-        u32* order1 = nullptr;
-    } fin;
-    HostBlock staging;
-    template <int W> void build_impl(u32 assembly_count_hint, RawGraph* out, BuildTimings* tm);
+    template <int W> void build_impl(u32 assembly_count_hint, FinalGraph* out, BuildTimings* tm);
 };
 
 GraphBuilder::GraphBuilder(uint32_t k) : impl_(new Impl) {
@@ -783,15 +982,8 @@ void GraphBuilder::set_text_device(const uint8_t* d_text, uint64_t n_text, const
 
 static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 
-template <class T> static Span<T> pinned(const T* d, size_t n) {
-    Span<T> sp;
-    sp.p = to_pinned_async(d, n);
-    sp.n = n;
-    return sp;
-}
-
 template <int W>
-void GraphBuilder::Impl::build_impl(u32 assembly_count_hint, RawGraph* out, BuildTimings* tm) {
+void GraphBuilder::Impl::build_impl(u32 assembly_count_hint, FinalGraph* out, BuildTimings* tm) {
     double t_begin = now_s(), t0 = t_begin;
     auto lap = [&](double* acc) { stream_sync(); double t = now_s(); *acc += t - t0; t0 = t; };
     if (n_text >= POS_MASK) throw DeviceError("input too large for 40-bit text positions");
@@ -960,103 +1152,129 @@ void GraphBuilder::Impl::build_impl(u32 assembly_count_hint, RawGraph* out, Buil
     sort_keys_cmp(order1, U, UnitigLess{ulen.ptr(), useq_off.ptr(), useq.ptr(), depth.ptr()});
     lap(&tm->analysis);
 
-    // D2H into the pinned host arena (the paths stay on the device until finalize())
-    out->k = k;
-    out->n_kmers = 2 * (u64)N;
-    out->n_unitigs = U;
-    out->n_path_entries = n_ent;
-    out->len = pinned(ulen.ptr(), U);
-    out->depth = pinned(depth.ptr(), U);
-    out->minpos_fwd = pinned(minpos_fwd.ptr(), U);
-    out->minpos_rev = pinned(minpos_rev.ptr(), U);
-    out->seq_off = pinned(useq_off.ptr(), (u64)U + 1);
-    out->seqs = pinned((const char*)useq.ptr(), total);
-    out->links = pinned(lord.ptr(), (u64)U * 10);
-    out->link_cnt = pinned(lcnt.ptr(), (u64)U * 2);
-    out->cand = pinned(cand.ptr(), (u64)U * 2);
-    out->order1 = pinned(order1.ptr(), U);
-    out->path_off = pinned(path_off.ptr(), (u64)n_seqs + 1);
-    std::vector<u32> errs = to_host(counters, 8);   // synchronises the stream: everything above has landed
-    if (errs[3] || errs[4])
-        throw DeviceError("internal error: inconsistent unitig ends (codes " + std::to_string(errs[3]) + "/" + std::to_string(errs[4]) + ")");
-    out->n_self_mirror_links = errs[5];
-    fin.U = U; fin.n_ent = n_ent; fin.total = total; fin.n_kmers = 2 * (u64)N; fin.n_self = errs[5];
-    fin.ent_val = ent_val.ptr(); fin.path_off = path_off.ptr(); fin.depth = depth.ptr(); fin.lord = lord.ptr(); fin.lcnt = lcnt.ptr();
-    fin.order1 = order1.ptr();
-    staging = PinnedPool::get().alloc(total);
-    lap(&tm->d2h);
-    tm->total_device = now_s() - t_begin;
-}
+    // K17 expand_repeats, level-scheduled (see the kernels)
+    DBuf<u64> coff(U), len64((u64)U + 1), noff((u64)U + 1);
+    DBuf<u32> clen(U), pre_off(U, true), pre_len(U, true), post_off(U, true), post_len(U, true);
+    copy_d2d(coff.ptr(), useq_off.ptr(), (size_t)U * 8);
+    copy_d2d(clen.ptr(), ulen.ptr(), (size_t)U * 4);
+    DBuf<u8> seq_alt(total), pool(total), dirty((u64)U * 2);
+    DBuf<u64> shifted(1); DBuf<u32> pool_used(1);
+    copy_d2d(dirty.ptr(), cand.ptr(), (size_t)U * 2);
+    u8* cur = useq.ptr(); u8* alt = seq_alt.ptr();
+    u64 final_total = total;
+    int passes = 0;
+    u32 n_cand = 0, n_levels = 0;
+    {
+        u64 J = (u64)U * 2;
+        DBuf<u32> cflag(J), cpos(J), prio(J);
+        launch(J, CandFlagFunctor{order1.ptr(), cand.ptr(), cflag.ptr()});
+        exclusive_scan_u32(cflag.ptr(), cpos.ptr(), J);
+        n_cand = read_scalar(cpos.ptr() + (J - 1)) + read_scalar(cflag.ptr() + (J - 1));
+        if (n_cand == 0) {
+            passes = 1;   // the reference's single pass that moves nothing
+        } else {
+            u64 C = n_cand;
+            DBuf<u32> clist(C), level(C);
+            prio.fill_bytes(0xFF);
+            launch(J, CandListFunctor{order1.ptr(), cflag.ptr(), cpos.ptr(), clist.ptr(), prio.ptr()});
+            launch(C, FillU32Functor{level.ptr(), 1u});
+            DBuf<u32> changed(1);
+            for (;;) {   // longest-path levels of the conflict DAG by relaxation (monotone, so stale reads only delay)
+                changed.fill_bytes(0);
+                for (int it = 0; it < 4; it++)
+                    launch(C, LevelRelaxFunctor{L, cand.ptr(), clist.ptr(), prio.ptr(), level.ptr(), changed.ptr()});
+                if (read_scalar(changed.ptr()) == 0) break;
+            }
+            DBuf<u64> lkey(C);
+            launch(C, LevelKeyFunctor{level.ptr(), lkey.ptr()});
+            sort_pairs_u64_u32(lkey, clist, C, 64);
+            n_levels = (u32)(read_scalar(lkey.ptr() + (C - 1)) >> 32);
+            DBuf<u32> bstart((u64)n_levels + 2);
+            launch(C, LevelBoundsFunctor{lkey.ptr(), C, bstart.ptr()});
+            std::vector<u32> hb = to_host(bstart, (u64)n_levels + 2);
+            hb[n_levels + 1] = (u32)C;
+            ExpState e{cur, coff.ptr(), clen.ptr(), pre_off.ptr(), pre_len.ptr(), post_off.ptr(), post_len.ptr(), pool.ptr(),
+                       pool_used.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), dirty.ptr(), cand.ptr(), L, shifted.ptr()};
+            for (;;) {
+                shifted.fill_bytes(0); pool_used.fill_bytes(0);
+                for (u32 lv = 1; lv <= n_levels; lv++)
+                    launch((u64)(hb[lv + 1] - hb[lv]), ExpandFunctor{e, clist.ptr(), (u64)hb[lv]});
+                passes++;
+                if (read_scalar(shifted.ptr()) == 0) break;
+                launch((u64)U + 1, ExpLenFunctor{e, len64.ptr(), U});
+                exclusive_scan_u64(len64.ptr(), noff.ptr(), (u64)U + 1);
+                final_total = read_scalar(noff.ptr() + U);
+                launch((final_total + 63) / 64, MaterializeFunctor{e, noff.ptr(), U, final_total, alt});
+                launch(U, ExpResetFunctor{e, noff.ptr()});
+                std::swap(cur, alt);
+                e.cur = cur;
+            }
+        }
+    }
+    tm->simplify_passes = (u32)passes; tm->n_candidates = n_cand; tm->n_levels = n_levels;
+    lap(&tm->expand);
 
-char* GraphBuilder::staging() { return (char*)impl_->staging.p; }
-
-void GraphBuilder::finalize(const TailResult& tail, const std::vector<uint32_t>& seq_lens, const std::vector<uint16_t>& seq_ids,
-                            FinalGraph* out) {
-    double t_begin = now_s();
-    Impl::Fin& f = impl_->fin;
-    const u32 U = f.U;
-    const u32 n_seqs = impl_->n_seqs;
-    // final sequences (seed order) -> device; second renumber_unitigs (graph_simplification.rs:39): a stable sort
-    // of the CURRENT order (order1) on the new sequences
-    DBuf<u8> fseq(tail.total_len); DBuf<u64> foff(U); DBuf<u32> flen(U);
-    copy_h2d(fseq.ptr(), impl_->staging.p, tail.total_len);
-    copy_h2d(foff.ptr(), tail.final_off.data(), (size_t)U * 8);
-    copy_h2d(flen.ptr(), tail.final_len.data(), (size_t)U * 4);
+    // K15b second renumber_unitigs (graph_simplification.rs:39): a stable sort of the CURRENT order on the new
+    // sequences; K16 per-unitig outputs in final order, links in get_links_for_gfa order, paths in final numbers
     DBuf<u32> order2(U);
-    copy_d2d(order2.ptr(), f.order1, (size_t)U * 4);
-    sort_keys_cmp(order2, U, UnitigLess{flen.ptr(), foff.ptr(), fseq.ptr(), f.depth});
-    // per-unitig outputs in final order, links in get_links_for_gfa order, paths in final numbers
+    copy_d2d(order2.ptr(), order1.ptr(), (size_t)U * 4);
+    sort_keys_cmp(order2, U, UnitigLess{clen.ptr(), coff.ptr(), cur, depth.ptr()});
     DBuf<u64> number_len(U), lcount((u64)U + 1), loff((u64)U + 1);
     DBuf<u8> meta((size_t)U * 20);
     u64* d_seq_begin = (u64*)meta.ptr();
     double* d_depth = (double*)(meta.ptr() + (size_t)U * 8);
     u32* d_seq_len = (u32*)(meta.ptr() + (size_t)U * 16);
     lcount.fill_bytes(0);
-    launch(U, FinalMetaFunctor{order2.ptr(), foff.ptr(), flen.ptr(), f.depth, f.lcnt, number_len.ptr(), d_seq_begin, d_depth,
+    launch(U, FinalMetaFunctor{order2.ptr(), coff.ptr(), clen.ptr(), depth.ptr(), lcnt.ptr(), number_len.ptr(), d_seq_begin, d_depth,
                                d_seq_len, lcount.ptr()});
     exclusive_scan_u64(lcount.ptr(), loff.ptr(), (u64)U + 1);
     u64 n_links = read_scalar(loff.ptr() + U);
     DBuf<Link> links_out(n_links);
-    OrderedLinks L{f.lord, f.lcnt};
     launch(U, LinkOutFunctor{order2.ptr(), L, number_len.ptr(), loff.ptr(), links_out.ptr()});
     DBuf<u64> sums(n_seqs);
     sums.fill_bytes(0);
-    launch((f.n_ent + 63) / 64, RemapFunctor{f.ent_val, number_len.ptr(), f.path_off, n_seqs, f.n_ent, sums.ptr()});
+    launch((n_ent + 63) / 64, RemapFunctor{ent_val.ptr(), number_len.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr()});
+    lap(&tm->finalize);
 
-    out->k = impl_->k;
-    out->n_kmers = f.n_kmers;
+    // D2H straight into pinned blocks owned by the result
+    out->k = k;
+    out->n_kmers = 2 * (u64)N;
     out->n_unitigs = U;
+    out->seq_block = PinnedPool::get().alloc(final_total);
     out->meta_block = PinnedPool::get().alloc((size_t)U * 20);
     out->links_block = PinnedPool::get().alloc(n_links * sizeof(Link));
-    out->path_block = PinnedPool::get().alloc(f.n_ent * 4);
+    out->path_block = PinnedPool::get().alloc(n_ent * 4);
+    copy_d2h_async(out->seq_block.p, cur, final_total);
     copy_d2h_async(out->meta_block.p, meta.ptr(), (size_t)U * 20);
     copy_d2h_async(out->links_block.p, links_out.ptr(), n_links * sizeof(Link));
-    copy_d2h_async(out->path_block.p, f.ent_val, f.n_ent * 4);
-    std::vector<u64> h_sums = to_host(sums, n_seqs);   // synchronises
-    std::vector<u64> h_off = to_host_ptr(f.path_off, (size_t)n_seqs + 1);
-    out->seq_block = std::move(impl_->staging);
+    copy_d2h_async(out->path_block.p, ent_val.ptr(), n_ent * 4);
+    std::vector<u64> h_sums = to_host(sums, n_seqs);
+    out->path_off = to_host(path_off, (size_t)n_seqs + 1);
+    std::vector<u32> errs = to_host(counters, 8);   // synchronises the stream: everything above has landed
+    if (errs[3] || errs[4])
+        throw DeviceError("internal error: inconsistent unitig ends (codes " + std::to_string(errs[3]) + "/" + std::to_string(errs[4]) + ")");
     out->seq_begin = (const u64*)out->meta_block.p;
     out->depth = (const double*)((const u8*)out->meta_block.p + (size_t)U * 8);
     out->seq_len = (const u32*)((const u8*)out->meta_block.p + (size_t)U * 16);
     out->links = (const Link*)out->links_block.p;
     out->n_links = n_links;
     out->path = (const int32_t*)out->path_block.p;
-    out->n_path = f.n_ent;
-    out->path_off = h_off;
-    u64 links_one_way = (n_links + f.n_self) / 2;   // link_count().1 (unitig_graph.rs:478-507): a link and its mirror
-                                                     // count once; a link that is its own mirror counts once
-    out->pre = GraphStats{U, links_one_way, f.total};
-    out->post = GraphStats{U, links_one_way, tail.total_len};
-    out->simplify_passes = tail.passes;
-    out->tail_seconds = tail.seconds;
+    out->n_path = n_ent;
+    u64 n_self = errs[5];
+    u64 links_one_way = (n_links + n_self) / 2;   // link_count().1 (unitig_graph.rs:478-507): a link and its mirror count
+                                                   // once; a link that is its own mirror (a+ -> a-, a- -> a+) counts once
+    out->pre = GraphStats{U, links_one_way, total};
+    out->post = GraphStats{U, links_one_way, final_total};
+    out->simplify_passes = passes;
     // The path of every sequence must spell its full length (unitig_graph.rs:160-174, decompress.rs).
     for (u32 s = 0; s < n_seqs; s++)
-        if (h_sums[s] != seq_lens[s])
-            throw DeviceError("internal error: path length mismatch for sequence " + std::to_string(seq_ids[s]));
-    tm_.finalize = now_s() - t_begin;
+        if (h_sums[s] != (u64)h_len[s])
+            throw DeviceError("internal error: path length mismatch for sequence " + std::to_string(s + 1));
+    lap(&tm->d2h);
+    tm->total_device = now_s() - t_begin;
 }
 
-void GraphBuilder::build(uint32_t assembly_count_hint, RawGraph* out) {
+void GraphBuilder::build(uint32_t assembly_count_hint, FinalGraph* out) {
     // Everything the previous build left in the arenas is dead (its RawGraph has been consumed by the host
     // tail); the sequence table of this builder lives outside the arena.
     BuildTimings keep = tm_;

@@ -22,8 +22,9 @@ struct SeqView {          // one padded, end-repaired forward sequence as at com
 struct BuildTimings {                   // seconds; device stages are bracketed by stream syncs
     double h2d = 0, pack = 0, insert = 0, collect_sort = 0, degree = 0, segment = 0, minkey = 0, rank = 0,
            paths = 0, links = 0, seqs = 0, d2h = 0, total_device = 0;
+    double expand = 0;                  // expand_repeats passes on the device (level-scheduled)
     double analysis = 0;                // link push order + expand_repeats candidates + first renumber (device)
-    double finalize = 0;                // device renumbering of the paths + their D2H (after the host tail)
+    double finalize = 0;                // second renumber + final numbering of links and paths (device)
     double insert_kernel_ms = 0;        // event-timed duration of the dominant kernel (k-mer insert)
     uint64_t insert_positions = 0;      // text positions streamed by that launch
     uint64_t table_capacity = 0;
@@ -31,6 +32,7 @@ struct BuildTimings {                   // seconds; device stages are bracketed 
     uint64_t n_path_entries = 0;
     uint32_t insert_launches = 0;       // phases of the run-following insert (same kernel, launched per phase)
     uint64_t insert_real = 0;           // positions that actually touched the table
+    uint32_t simplify_passes = 0, n_candidates = 0, n_levels = 0;   // expand_repeats: passes, candidate junctions, conflict levels
 };
 
 class GraphBuilder {
@@ -45,15 +47,9 @@ class GraphBuilder {
     void set_text_device(const uint8_t* d_text, uint64_t n_text, const std::vector<uint64_t>& off,
                          const std::vector<uint32_t>& len, const std::vector<uint16_t>& d1,
                          const std::vector<uint16_t>& d2);
-    // The timed region, part 1: packed text -> RawGraph (host); the paths stay on the device in seed numbering.
-    void build(uint32_t assembly_count_hint, RawGraph* out);
-    // Pinned scratch the host tail writes the final sequences (seed order) into; capacity = RawGraph::seqs.size().
-    char* staging();
-    // Part 2, after expand_repeats: second renumber_unitigs (graph_simplification.rs:39) on the device, paths
-    // renumbered, links / depths / sequence offsets emitted in final order, everything copied into host blocks.
-    // Throws if a sequence's path does not spell its full length (unitig_graph.rs:160-174).
-    void finalize(const TailResult& tail, const std::vector<uint32_t>& seq_lens, const std::vector<uint16_t>& seq_ids,
-                  FinalGraph* out);
+    // The timed region (compress.rs:42-44): packed text -> final UnitigGraph in host memory.  Everything runs on
+    // the device, including expand_repeats and both renumberings; the host only receives the results.
+    void build(uint32_t assembly_count_hint, FinalGraph* out);
     const BuildTimings& timings() const { return tm_; }
     uint64_t n_text() const;
     uint64_t n_bases() const;   // sum of unpadded lengths

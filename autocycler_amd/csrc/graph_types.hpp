@@ -17,31 +17,6 @@ template <class T> struct Span {
     const T* end() const { return p + n; }
 };
 
-struct RawGraph {
-    uint32_t k = 0;
-    uint64_t n_kmers = 0;               // KmerGraph.kmers.len(): both strands (compress.rs:152)
-    uint32_t n_unitigs = 0;
-    uint64_t n_path_entries = 0;
-    // per unitig, in SEED order (the reference's initial numbering, unitig_graph.rs:176-226)
-    Span<uint32_t> len;                 // k-mer count == trimmed length
-    Span<uint32_t> depth;               // occurrences (unitig.rs:149-156: always integral)
-    Span<uint32_t> minpos_fwd;          // min p.pos over forward_positions / reverse_positions
-    Span<uint32_t> minpos_rev;          //   (all graph_simplification.rs:164-181 ever asks of them)
-    Span<uint64_t> seq_off;             // n_unitigs + 1
-    Span<char> seqs;                    // concatenated trimmed forward sequences
-    // forward_next (side 0) / reverse_next (side 1) of unitig u in create_links' PUSH ORDER
-    // (unitig_graph.rs:248-286): entries [(2u+side)*5 .. +link_cnt[2u+side]) are signed seed numbers
-    Span<int32_t> links;
-    Span<uint8_t> link_cnt;
-    uint64_t n_self_mirror_links = 0;   // links that are their own mirror (a+ -> a-, a- -> a+): link_count() counts them once
-    // static analysis for expand_repeats (graph_simplification.rs:43-86, 190-280): cand[2u] = the inputs side of u
-    // passes every test that does not depend on sequence content (>= 2 exclusive inputs, no fixed start/end
-    // involved); cand[2u+1] = the same for the outputs side
-    Span<uint8_t> cand;
-    Span<uint32_t> order1;              // first renumber_unitigs (unitig_graph.rs:295-315): stable sort of seed order
-    Span<uint64_t> path_off;            // n_seqs + 1 (the path itself stays on the device until finalize_paths)
-};
-
 // A block of host memory handed to the caller together with its deleter (pinned memory from a recycling pool
 // in the HIP build, so device -> host copies into it run at full PCIe rate and cost no allocation in steady state).
 struct HostBlock {
@@ -88,20 +63,9 @@ struct FinalGraph {
     // lazily built by build_positions(): forward/reverse positions per unitig as from_gfa_lines would
     // rebuild them (unitig_graph.rs:151-174)
     std::vector<std::vector<Position>> fwd_positions, rev_positions;
-    double tail_seconds = 0;                 // the sequential expand_repeats part only
     int simplify_passes = 0;
 
     const char* seq(uint32_t i) const { return (const char*)seq_block.p + seq_begin[i]; }
 };
 
-// expand_repeats until nothing moves, in the reference's visiting order (`raw.order1`, then inputs side before
-// outputs side).  Writes the final forward sequence of every unitig, in SEED order, into `seq_out` (capacity
-// >= raw.seqs.size(): shifts never grow the total) and its offset / length into final_off / final_len.
-struct TailResult {
-    std::vector<uint64_t> final_off;
-    std::vector<uint32_t> final_len;
-    uint64_t total_len = 0;
-    int passes = 0;
-    double seconds = 0;
-};
 }  // namespace ac

@@ -180,8 +180,8 @@ def main():
         alg_bytes = A_K(k) * bases
         achieved = alg_bytes / (ins_ms * 1e-3)
         stage = {key: sum(t[key] for t in tms) / len(tms) for key in
-                 ("pack", "insert", "collect_sort", "degree", "segment", "minkey", "rank", "links", "paths", "seqs", "analysis", "d2h",
-                  "total_device", "host_tail", "finalize")}
+                 ("pack", "insert", "collect_sort", "degree", "segment", "minkey", "rank", "links", "paths", "seqs", "analysis", "expand", "finalize", "d2h",
+                  "total_device")}
         line = {
             "metric": "Mbp/sec through compress->unitig GFA (k=%d)" % k,
             "value": value, "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -44,16 +44,18 @@ typedef struct { uint32_t unitigs; uint64_t links_one_way; uint64_t total_length
 /* Seconds spent in each stage of the last build (device stages are bracketed by stream syncs). */
 typedef struct {
     double h2d, pack, insert, collect_sort, degree, segment, minkey, rank, paths, links, seqs, d2h;
-    double total_device; /* pack .. d2h */
-    double host_tail;    /* the sequential expand_repeats passes on the host */
+    double total_device; /* pack .. d2h: the whole replaced region */
+    double expand;       /* expand_repeats passes (device, level-scheduled) */
     double insert_kernel_ms;    /* HIP-event duration of the k-mer insert kernel, summed over its phase launches */
-    uint64_t insert_positions;  /* text positions that launch streamed */
+    uint64_t insert_positions;  /* text positions those launches streamed */
     uint64_t table_capacity, n_distinct, n_path_entries;
     uint32_t simplify_passes;
     uint32_t insert_launches;   /* phases of the run-following insert (launches of that kernel per build) */
     uint64_t insert_real;       /* positions that really accessed the k-mer table (the rest were run-followed) */
-    double analysis;            /* device: link push order, expand_repeats candidates, first renumber (in total_device) */
-    double finalize;            /* device: second renumber, final numbering of links and paths, D2H (after host_tail) */
+    double analysis;            /* link push order, expand_repeats candidates, first renumber */
+    double finalize;            /* second renumber, final numbering of links and paths */
+    uint32_t n_candidates;      /* junctions that pass the static tests of expand_repeats */
+    uint32_t n_levels;          /* conflict levels they are scheduled in */
 } ac_timings;
 
 /* Replaces compress.rs:42-44.  k: --kmer (odd).  assembly_count: the reference's capacity hint

@@ -179,6 +179,16 @@ def main():
         ins_ms = sum(t["insert_kernel_ms"] for t in tms) / len(tms)
         alg_bytes = A_K(k) * bases
         achieved = alg_bytes / (ins_ms * 1e-3)
+        # HBM bytes of that kernel per build from the PMC passes (collected separately with tools/pmc_round.sh and
+        # committed under profiles/; rocprofv3 counters cannot be read from inside this process).  Only quoted
+        # when this run is the workload the counters were collected on.
+        traffic, traffic_src = None, None
+        pmc = ROOT / "profiles" / "pmc_traffic.json"
+        default_workload = (args.assemblies, args.genome, args.plasmid, args.sub, args.indel, k) == (96, 5_000_000, 100_000, 1e-4, 1e-5, 51)
+        if pmc.exists() and default_workload:
+            pj = json.loads(pmc.read_text())
+            traffic = pj["traffic_bytes_per_build"]
+            traffic_src = "profiles/pmc_traffic.json (rocprofv3 PMC passes; FETCH_SIZE x2 per the gfx950 calibration, + WRITE_SIZE)"
         stage = {key: sum(t[key] for t in tms) / len(tms) for key in
                  ("pack", "insert", "collect_sort", "degree", "segment", "minkey", "rank", "links", "paths", "seqs", "analysis", "expand", "finalize", "d2h",
                   "total_device")}
@@ -193,7 +203,8 @@ def main():
                        "timed_region": "padded+repaired sequences in HBM -> final unitig graph in host RAM (device build + host tail)"},
             "roofline": {"bound": "hbm", "kernel": "functor_kernel<InsertFunctor<W>> (k-mer table insert)",
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": ins_ms,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": ins_ms,
                          "whole_path_frac": alg_bytes / (elapsed / args.steps) / HBM_PEAK},
             "stages_s": stage,
             "graph": {**g.stats_post, "kmers": g.kmer_count, "distinct_canonical": tms[-1]["n_distinct"],

@@ -41,7 +41,9 @@ class Timings(C.Structure):
                                           "insert_kernel_ms")] + \
                [(n, C.c_uint64) for n in ("insert_positions", "table_capacity", "n_distinct", "n_path_entries")] + \
                [("simplify_passes", C.c_uint32), ("insert_launches", C.c_uint32), ("insert_real", C.c_uint64),
-                ("analysis", C.c_double), ("finalize", C.c_double), ("n_candidates", C.c_uint32), ("n_levels", C.c_uint32)]
+                ("analysis", C.c_double), ("finalize", C.c_double), ("n_candidates", C.c_uint32), ("n_levels", C.c_uint32),
+                ("fragments", C.c_double), ("union_pack", C.c_double), ("union_insert", C.c_double),
+                ("n_local_distinct", C.c_uint64), ("n_fragments", C.c_uint64), ("fragment_bytes", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -50,7 +52,12 @@ class Timings(C.Structure):
 EXPORTS = ["ac_compress_build", "ac_compress_build_device", "ac_text_size", "ac_layout_text", "ac_kmer_count",
            "ac_stats_pre", "ac_stats_post", "ac_unitig_count", "ac_unitig", "ac_unitig_positions", "ac_links",
            "ac_path", "ac_timings_get", "ac_free", "ac_gfa_string", "ac_string_free", "ac_last_error",
-           "ac_device_count", "ac_max_kmer", "ac_version"]
+           "ac_device_count", "ac_max_kmer", "ac_version",
+           "ac_shard_begin", "ac_shard_fragment_sizes", "ac_shard_fragments_export", "ac_shard_build_union",
+           "ac_shard_unitig_count", "ac_shard_reduce_export", "ac_shard_reduce_import", "ac_shard_finish",
+           "ac_shard_path_entries", "ac_shard_paths_export", "ac_shard_free", "ac_graph_set_paths", "ac_graph_seq_count", "ac_path_counts",
+           "ac_seqs_load", "ac_seqs_from_raw", "ac_seqs_count", "ac_seqs_assembly_count", "ac_seqs_views", "ac_seqs_get",
+           "ac_seqs_repair_seconds", "ac_seqs_metrics_yaml", "ac_seqs_free", "ac_compress_seqs", "ac_compress_dir"]
 
 _libs = {}
 
@@ -83,6 +90,13 @@ def load_library(path=None):
     lib.ac_links.argtypes = [C.c_void_p, C.POINTER(C.POINTER(Link)), C.POINTER(C.c_uint64)]
     lib.ac_path.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_uint32)]
     lib.ac_timings_get.argtypes = [C.c_void_p, C.POINTER(Timings)]
+    lib.ac_shard_unitig_count.restype = C.c_uint32
+    lib.ac_shard_unitig_count.argtypes = [C.c_void_p]
+    lib.ac_shard_path_entries.restype = C.c_uint64
+    lib.ac_shard_path_entries.argtypes = [C.c_void_p]
+    lib.ac_shard_free.argtypes = [C.c_void_p]
+    lib.ac_graph_seq_count.restype = C.c_uint32
+    lib.ac_graph_seq_count.argtypes = [C.c_void_p]
     _libs[key] = lib
     return lib
 
@@ -148,6 +162,12 @@ class Graph:
         p, n = C.POINTER(C.c_int32)(), C.c_uint32()
         _check(self._lib, self._lib.ac_path(self._h, seq_index, C.byref(p), C.byref(n)))
         return p[:n.value]
+
+    def path_counts(self):
+        n = self._lib.ac_graph_seq_count(self._h)
+        out = (C.c_uint64 * n)()
+        _check(self._lib, self._lib.ac_path_counts(self._h, out))
+        return list(out)
 
     def timings(self):
         t = Timings()

@@ -21,6 +21,7 @@ using namespace ac;
 
 static thread_local std::string g_err;
 static std::mutex g_build_mutex;   // one build at a time per process: the device / pinned arenas are shared
+static int g_live_shards = 0;      // a live sharded build owns the arenas between its phases: no other build may start
 
 struct ac_graph {
     FinalGraph g;
@@ -28,6 +29,7 @@ struct ac_graph {
     std::vector<uint16_t> seq_ids;
     std::vector<uint32_t> seq_lens;
     bool positions_built = false;
+    bool host_arrays = true;   // false: a non-writing rank of a sharded build kept only the statistics
 };
 
 struct ac_seqs {
@@ -122,6 +124,7 @@ int ac_compress_build(uint32_t k, uint32_t assembly_count, const ac_seq_view* se
     return guarded([&] {
         validate(k, seqs, n_seqs);
         std::lock_guard<std::mutex> lock(g_build_mutex);
+        if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
         select_device(device);
         auto h = std::make_unique<ac_graph>();
         std::vector<SeqView> v(n_seqs);
@@ -145,6 +148,7 @@ int ac_compress_build_device(uint32_t k, uint32_t assembly_count, const void* d_
         if (!d_text || n_seqs == 0) throw DeviceError("no sequences found in input assemblies");
         if (n_seqs > 32767) throw DeviceError("no more than 32767 input sequences are allowed");
         std::lock_guard<std::mutex> lock(g_build_mutex);
+        if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
         select_device(device);
         auto h = std::make_unique<ac_graph>();
         std::vector<uint64_t> off(seq_off, seq_off + n_seqs);
@@ -159,6 +163,148 @@ int ac_compress_build_device(uint32_t k, uint32_t assembly_count, const void* d_
     });
 }
 
+// ---- one job sharded by sequence over several devices (the collectives between the phases are the caller's) ------
+struct ac_shard {
+    std::unique_ptr<GraphBuilder> b;
+    std::vector<uint16_t> seq_ids;
+    std::vector<uint32_t> seq_lens;
+    int device = 0;
+    int phase = 0;   // 1 = fragments ready, 2 = union graph + walk done, 3 = reduced quantities imported, 4 = finished
+};
+
+int ac_shard_begin(uint32_t k, uint32_t local_assembly_count, const void* d_text, uint64_t n_text, const uint64_t* seq_off,
+                   const uint32_t* seq_len, const uint16_t* seq_ids, const uint16_t* seq_d1, const uint16_t* seq_d2,
+                   uint32_t n_seqs, int device, ac_shard** out) {
+    return guarded([&] {
+        if (!d_text || n_seqs == 0) throw DeviceError("no sequences found in input assemblies");
+        if (n_seqs > 32767) throw DeviceError("no more than 32767 input sequences are allowed");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        if (g_live_shards) throw DeviceError("another sharded build is in flight in this process");
+        select_device(device);
+        auto h = std::make_unique<ac_shard>();
+        h->device = device;
+        std::vector<uint64_t> off(seq_off, seq_off + n_seqs);
+        std::vector<uint32_t> len(seq_len, seq_len + n_seqs);
+        std::vector<uint16_t> d1(seq_d1, seq_d1 + n_seqs), d2(seq_d2, seq_d2 + n_seqs);
+        h->seq_ids.assign(seq_ids, seq_ids + n_seqs);
+        h->seq_lens = len;
+        h->b = std::make_unique<GraphBuilder>(k);
+        h->b->set_text_device((const uint8_t*)d_text, n_text, off, len, d1, d2);
+        h->b->shard_begin(local_assembly_count);
+        h->phase = 1;
+        g_live_shards++;
+        *out = h.release();
+    });
+}
+int ac_shard_fragment_sizes(const ac_shard* s, uint64_t* text_bytes, uint64_t* n_fragments) {
+    *text_bytes = s->b->fragment_text_bytes();
+    *n_fragments = s->b->fragment_count();
+    return 0;
+}
+int ac_shard_fragments_export(ac_shard* s, void* d_text_out, void* d_meta_out) {
+    return guarded([&] {
+        if (s->phase < 1) throw DeviceError("ac_shard_fragments_export: no fragments yet");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->fragments_export(d_text_out, d_meta_out);
+    });
+}
+int ac_shard_build_union(ac_shard* s, uint32_t n_shards, const void* d_union_text, uint64_t n_union_text, const void* d_meta,
+                         uint64_t n_fragments_total) {
+    return guarded([&] {
+        if (s->phase != 1) throw DeviceError("ac_shard_build_union: wrong phase");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->shard_build_union(n_shards, (const uint8_t*)d_union_text, n_union_text, d_meta, n_fragments_total);
+        s->phase = 2;
+    });
+}
+uint32_t ac_shard_unitig_count(const ac_shard* s) { return s->b->unitig_count(); }
+int ac_shard_reduce_export(ac_shard* s, void* d_sum_i32, void* d_min_i32) {
+    return guarded([&] {
+        if (s->phase != 2) throw DeviceError("ac_shard_reduce_export: wrong phase");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->reduce_export((int32_t*)d_sum_i32, (int32_t*)d_min_i32);
+    });
+}
+int ac_shard_reduce_import(ac_shard* s, const void* d_sum_i32, const void* d_min_i32) {
+    return guarded([&] {
+        if (s->phase != 2) throw DeviceError("ac_shard_reduce_import: wrong phase");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->reduce_import((const int32_t*)d_sum_i32, (const int32_t*)d_min_i32);
+        s->phase = 3;
+    });
+}
+int ac_shard_finish(ac_shard* s, int want_graph, ac_graph** out) {
+    return guarded([&] {
+        if (s->phase != 3) throw DeviceError("ac_shard_finish: wrong phase");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        auto h = std::make_unique<ac_graph>();
+        h->seq_ids = s->seq_ids;
+        h->seq_lens = s->seq_lens;
+        s->b->shard_finish(&h->g, want_graph != 0);
+        h->tm = s->b->timings();
+        h->host_arrays = want_graph != 0;
+        s->phase = 4;
+        *out = h.release();
+    });
+}
+uint64_t ac_shard_path_entries(const ac_shard* s) { return s->b->path_entry_count(); }
+int ac_shard_paths_export(ac_shard* s, void* d_out_i32) {
+    return guarded([&] {
+        if (s->phase != 4) throw DeviceError("ac_shard_paths_export: wrong phase");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->paths_export(d_out_i32);
+    });
+}
+void ac_shard_free(ac_shard* s) {
+    if (!s) return;
+    std::lock_guard<std::mutex> lock(g_build_mutex);
+    if (s->phase >= 1) g_live_shards--;
+    delete s;
+}
+// The rank that writes the GFA replaces its own paths by those of ALL sequences of the job (rank order).
+int ac_graph_set_paths(ac_graph* g, uint32_t n_seqs_total, const uint16_t* seq_ids, const uint32_t* seq_lens,
+                       const uint64_t* path_counts, const void* d_path_i32, int device) {
+    return guarded([&] {
+        if (!g->host_arrays) throw DeviceError("ac_graph_set_paths: this graph was finished without host arrays");
+        if (n_seqs_total == 0 || n_seqs_total > 32767) throw DeviceError("no more than 32767 input sequences are allowed");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(device);
+        std::vector<uint64_t> off((size_t)n_seqs_total + 1, 0);
+        for (uint32_t i = 0; i < n_seqs_total; i++) off[i + 1] = off[i] + path_counts[i];
+        uint64_t n = off[n_seqs_total];
+        HostBlock blk = PinnedPool::get().alloc(n * 4);
+        copy_d2h(blk.p, d_path_i32, n * 4);
+        const int32_t* p = (const int32_t*)blk.p;
+        for (uint32_t s = 0; s < n_seqs_total; s++) {   // every path must spell its sequence (unitig_graph.rs:160-174)
+            uint64_t sum = 0;
+            for (uint64_t i = off[s]; i < off[s + 1]; i++) {
+                uint32_t u = (uint32_t)(p[i] < 0 ? -p[i] : p[i]);
+                if (u == 0 || u > g->g.n_unitigs) throw DeviceError("internal error: gathered path names an unknown unitig");
+                sum += g->g.seq_len[u - 1];
+            }
+            if (sum != seq_lens[s]) throw DeviceError("internal error: gathered path length mismatch for sequence " + std::to_string(s + 1));
+        }
+        g->g.path_block = std::move(blk);
+        g->g.path = p;
+        g->g.n_path = n;
+        g->g.path_off = off;
+        g->seq_ids.assign(seq_ids, seq_ids + n_seqs_total);
+        g->seq_lens.assign(seq_lens, seq_lens + n_seqs_total);
+        g->positions_built = false;
+    });
+}
+uint32_t ac_graph_seq_count(const ac_graph* g) { return (uint32_t)g->seq_ids.size(); }
+int ac_path_counts(const ac_graph* g, uint64_t* counts) {   // entries per sequence; also valid without host arrays
+    for (size_t s = 0; s + 1 < g->g.path_off.size(); s++) counts[s] = g->g.path_off[s + 1] - g->g.path_off[s];
+    return 0;
+}
+
 uint64_t ac_kmer_count(const ac_graph* g) { return g->g.n_kmers; }
 ac_stats ac_stats_pre(const ac_graph* g) { return ac_stats{g->g.pre.unitigs, g->g.pre.links_one_way, g->g.pre.total_length}; }
 ac_stats ac_stats_post(const ac_graph* g) { return ac_stats{g->g.post.unitigs, g->g.post.links_one_way, g->g.post.total_length}; }
@@ -166,6 +312,7 @@ uint32_t ac_unitig_count(const ac_graph* g) { return g->g.n_unitigs; }
 
 int ac_unitig(const ac_graph* g, uint32_t idx, const uint8_t** seq, uint32_t* len, double* depth) {
     if (idx >= g->g.n_unitigs) { g_err = "unitig index out of range"; return 1; }
+    if (!g->host_arrays) { g_err = "this rank kept no host arrays (sharded build, not the writing rank)"; return 1; }
     if (seq) *seq = (const uint8_t*)g->g.seq(idx);
     if (len) *len = g->g.seq_len[idx];
     if (depth) *depth = g->g.depth[idx];
@@ -174,6 +321,7 @@ int ac_unitig(const ac_graph* g, uint32_t idx, const uint8_t** seq, uint32_t* le
 int ac_unitig_positions(ac_graph* g, uint32_t idx, int forward, const ac_position** positions, uint32_t* n) {
     if (idx >= g->g.n_unitigs) { g_err = "unitig index out of range"; return 1; }
     return guarded([&] {
+        if (!g->host_arrays) throw DeviceError("this rank kept no host arrays (sharded build, not the writing rank)");
         if (!g->positions_built) { build_positions(&g->g, g->seq_ids, g->seq_lens); g->positions_built = true; }
         auto& v = forward ? g->g.fwd_positions[idx] : g->g.rev_positions[idx];
         static_assert(sizeof(ac_position) == sizeof(Position), "layout");
@@ -183,12 +331,14 @@ int ac_unitig_positions(ac_graph* g, uint32_t idx, int forward, const ac_positio
 }
 int ac_links(const ac_graph* g, const ac_link** links, uint64_t* n) {
     static_assert(sizeof(ac_link) == sizeof(Link), "layout");
+    if (!g->host_arrays) { g_err = "this rank kept no host arrays (sharded build, not the writing rank)"; return 1; }
     *links = (const ac_link*)g->g.links;
     *n = g->g.n_links;
     return 0;
 }
 int ac_path(const ac_graph* g, uint32_t seq_index, const int32_t** signed_unitigs, uint32_t* n) {
     if ((size_t)seq_index + 1 >= g->g.path_off.size()) { g_err = "sequence index out of range"; return 1; }
+    if (!g->host_arrays) { g_err = "this rank kept no host arrays (sharded build, not the writing rank)"; return 1; }
     uint64_t b = g->g.path_off[seq_index], e = g->g.path_off[seq_index + 1];
     *signed_unitigs = g->g.path + b;
     *n = (uint32_t)(e - b);
@@ -204,12 +354,15 @@ int ac_timings_get(const ac_graph* g, ac_timings* o) {
     o->simplify_passes = t.simplify_passes; o->n_candidates = t.n_candidates; o->n_levels = t.n_levels;
     o->insert_launches = t.insert_launches; o->insert_real = t.insert_real;
     o->analysis = t.analysis; o->finalize = t.finalize;
+    o->fragments = t.fragments; o->union_pack = t.union_pack; o->union_insert = t.union_insert;
+    o->n_local_distinct = t.n_local_distinct; o->n_fragments = t.n_fragments; o->fragment_bytes = t.fragment_bytes;
     return 0;
 }
 void ac_free(ac_graph* g) { delete g; }
 
 int ac_gfa_string(const ac_graph* g, const char* const* filenames, const char* const* headers, char** out, uint64_t* out_len) {
     return guarded([&] {
+        if (!g->host_arrays) throw DeviceError("this rank kept no host arrays (sharded build, not the writing rank)");
         std::vector<SeqMeta> meta(g->seq_ids.size());
         for (size_t i = 0; i < meta.size(); i++) meta[i] = SeqMeta{g->seq_ids[i], g->seq_lens[i], filenames[i], headers[i]};
         std::string s = gfa_string(g->g, meta);

@@ -321,10 +321,13 @@ template <int W> struct DegreeFunctor {
 
 // ---- K6: first_position flags (kmer_graph.rs:57-60): first forward k-mer of each sequence and the RC of
 // its last forward k-mer sit at pos 0 of a strand.
+// `flags` (sharded builds, where the "sequences" of the graph text are fragments): bit 0 = the fragment starts at a
+// sequence start, bit 1 = it ends at a sequence end; nullptr = every entry is a whole sequence.
 template <int W> struct FirstFunctor {
-    TextCtx t; Table tb; Novel nv; u32* kinfo;
+    TextCtx t; Table tb; Novel nv; u32* kinfo; const u8* flags;
     AC_D void operator()(u64 s) const {
         for (int which = 0; which < 2; which++) {
+            if (flags && !(flags[s] & (which ? 2u : 1u))) continue;
             u64 p = t.seq_off[s] + (which ? (u64)t.seq_len[s] - 1 : 0);
             XKmer<W> x;
             if (!xkmer_at<W>(t, p, &x)) continue;
@@ -449,8 +452,10 @@ template <int W> struct LinksFunctor {
 // next unitig is links[(current strand end)][next text symbol] — an L2-resident gather, no hashing.  Thread tid
 // owns the unitig heads that fall into text positions [tid*PC, (tid+1)*PC); pass 1 counts them, an exclusive
 // scan turns counts into offsets, pass 2 writes them, so entries come out in text order without a sort.
+// `t` is the text being walked (this rank's sequences), `g` the text the graph was built from (the same text for a
+// single-device build, the union of all ranks' novel fragments for a sharded one): table slots point into `g`.
 template <int W, bool WRITE> struct PathWalkFunctor {
-    TextCtx t; Table tb; Novel nv; UnitigCtx uc; const int32_t* links; u32 pc;
+    TextCtx t; TextCtx g; Table tb; Novel nv; UnitigCtx uc; const int32_t* links; u32 pc;
     u64* cnt;                 // pass 1: out (entries per thread); pass 2: in (exclusive offsets)
     int32_t* ent_val; u64* path_off; u32* depth; u32* minpos_fwd; u32* minpos_rev; u32* err;
     AC_D void emit(u64& idx, u64 p, u32 s, u32 r, bool strand) const {
@@ -485,7 +490,7 @@ template <int W, bool WRITE> struct PathWalkFunctor {
             // locate the walker: which unitig strand covers the k-mer at p, and where does that unitig end here?
             XKmer<W> x;
             u64 pos; bool rel_same;
-            if (!xkmer_at<W>(t, p, &x) || !find_xk<W>(t, tb, x, &pos, &rel_same)) { atomic_or32(err, 8u); break; }
+            if (!xkmer_at<W>(t, p, &x) || !find_xk<W>(g, tb, x, &pos, &rel_same)) { atomic_or32(err, 8u); break; }
             u32 j = novel_rank(nv, pos);
             u32 u = uc.scan[j] - 1;
             u32 a = uc.ustart[u];
@@ -896,6 +901,96 @@ struct SeqFunctor {
     }
 };
 
+// ---- sharded build, phase 1: this rank's novel runs ("fragments") --------------------------------------------
+// One compress job sharded by sequence over several devices: a rank inserts only its own sequences; the maximal runs
+// of consecutive rank-novel positions are exactly the text this rank can contribute to the global k-mer set (every
+// k-mer's globally smallest occurrence is rank-novel on the rank that holds it, and a whole unitig is novel
+// together).  The union of all ranks' fragments is a text with the same k-mer set as the whole input — for similar
+// assemblies a small multiple of ONE assembly — from which every rank builds the identical global graph.
+struct RunEdgeCountFunctor {
+    const u64* bm; u64 n_words; u32* n_start; u32* n_end;
+    AC_HD void operator()(u64 w) const {
+        u64 x = bm[w];
+        u64 prev = w ? (bm[w - 1] >> 63) : 0;
+        u64 next = (w + 1 < n_words) ? (bm[w + 1] & 1) : 0;
+        n_start[w] = (u32)popc64(x & ~((x << 1) | prev));
+        n_end[w] = (u32)popc64(x & ~((x >> 1) | (next << 63)));
+    }
+};
+struct RunEdgeFillFunctor {
+    const u64* bm; u64 n_words; const u32* soff; const u32* eoff; u64* run_start; u64* run_end;
+    AC_HD void operator()(u64 w) const {
+        u64 x = bm[w];
+        u64 prev = w ? (bm[w - 1] >> 63) : 0;
+        u64 next = (w + 1 < n_words) ? (bm[w + 1] & 1) : 0;
+        u64 st = x & ~((x << 1) | prev), en = x & ~((x >> 1) | (next << 63));
+        u32 i = soff[w];
+        while (st) { u64 low = st & (~st + 1); run_start[i++] = w * 64 + (u64)popc64(low - 1); st ^= low; }
+        i = eoff[w];
+        while (en) { u64 low = en & (~en + 1); run_end[i++] = w * 64 + (u64)popc64(low - 1); en ^= low; }
+    }
+};
+// Fragment i < n_runs: the i-th novel run.  Fragments n_runs + 2s, n_runs + 2s + 1: the first and the last k-mer of
+// sequence s on their own (1 k-mer each), flagged START / END: they carry first_position (kmer_graph.rs:57-60) to
+// the global build.  They sit AFTER the rank's novel runs, so they never hold the smallest occurrence of a k-mer in
+// the union text and cannot split a unitig.
+// meta record: [len:32][leading dots:8][trailing dots:8][flags:8][0:8]
+static const u32 FRAG_START = 1, FRAG_END = 2;
+struct FragMetaFunctor {
+    TextCtx t; const u64* run_start; const u64* run_end; u64 n_runs, n_frags; u64* fpos; u64* meta; u64* blen; u32* err;
+    AC_D void operator()(u64 i) const {
+        if (i == n_frags) { blen[i] = 0; return; }    // sentinel: the exclusive scan then ends with the total
+        u64 a; u32 len; u32 flags = 0;
+        if (i < n_runs) { a = run_start[i]; len = (u32)(run_end[i] - a + 1); }
+        else { u64 j = i - n_runs; u32 s = (u32)(j >> 1); bool last = (j & 1) != 0;
+               a = t.seq_off[s] + (last ? (u64)t.seq_len[s] - 1 : 0); len = 1; flags = last ? FRAG_END : FRAG_START; }
+        u32 s, f;
+        if (!locate(t, a, &s, &f) || (u64)f + len > (u64)t.seq_len[s]) { atomic_or32(err, 32u); fpos[i] = a; meta[i] = 0; blen[i] = 0; return; }
+        int k = t.k;
+        int plen = (int)t.seq_len[s] + k - 1;
+        int ld = (int)t.seq_d1[s] - (int)f;
+        int td = (int)(f + len - 1) + k - (plen - (int)t.seq_d2[s]);
+        if (ld < 0) ld = 0;
+        if (td < 0) td = 0;
+        fpos[i] = a;
+        meta[i] = (u64)len | ((u64)ld << 32) | ((u64)td << 40) | ((u64)flags << 48);
+        blen[i] = (u64)len + (u64)k;                  // k-1 tail bytes + one separator
+    }
+};
+struct FragCopyFunctor {     // 64 output bytes per thread
+    const u8* text; const u64* fpos; const u64* boff; u64 n_frags, total; u8* out;
+    AC_HD void operator()(u64 tid) const {
+        u64 g0 = tid * 64, g1 = g0 + 64;
+        if (g1 > total) g1 = total;
+        if (g0 >= total) return;
+        u64 lo = 0, hi = n_frags;   // largest r with boff[r] <= g0
+        while (hi - lo > 1) { u64 mid = lo + ((hi - lo) >> 1); if (boff[mid] <= g0) lo = mid; else hi = mid; }
+        u64 r = lo;
+        for (u64 g = g0; g < g1; g++) {
+            while (g >= boff[r + 1]) r++;
+            u64 j = g - boff[r];
+            out[g] = (g + 1 == boff[r + 1]) ? (u8)'$' : text[fpos[r] + j];
+        }
+    }
+};
+// ---- sharded build: per-unitig quantities that combine over ranks -------------------------------------------------
+// sum[0..U) = occurrences (depth), sum[U..2U) / sum[2U..3U) = "a path starts / ends here" counts; min[0..U) / [U..2U) = smallest
+// forward / reverse position, biased by 2^31 so that a signed 32-bit MIN orders them as unsigned.
+struct ReduceExportFunctor {
+    const u32* depth; const u8* fs0; const u8* fe0; const u32* mf; const u32* mr; u64 U; int32_t* sum; int32_t* mn;
+    AC_HD void operator()(u64 i) const {
+        sum[i] = (int32_t)depth[i]; sum[U + i] = fs0[i]; sum[2 * U + i] = fe0[i];
+        mn[i] = (int32_t)(mf[i] ^ 0x80000000u); mn[U + i] = (int32_t)(mr[i] ^ 0x80000000u);
+    }
+};
+struct ReduceImportFunctor {
+    u32* depth; u8* fs0; u8* fe0; u32* mf; u32* mr; u64 U; const int32_t* sum; const int32_t* mn;
+    AC_HD void operator()(u64 i) const {
+        depth[i] = (u32)sum[i]; fs0[i] = sum[U + i] > 0 ? 1 : 0; fe0[i] = sum[2 * U + i] > 0 ? 1 : 0;
+        mf[i] = (u32)mn[i] ^ 0x80000000u; mr[i] = (u32)mn[U + i] ^ 0x80000000u;
+    }
+};
+
 // =============================================================================================================
 std::vector<uint8_t> layout_text(const std::vector<SeqView>& seqs, uint32_t k, std::vector<uint64_t>* off,
                                  std::vector<uint32_t>* len, std::vector<uint16_t>* d1, std::vector<uint16_t>* d2) {
@@ -922,100 +1017,105 @@ std::vector<uint8_t> layout_text(const std::vector<SeqView>& seqs, uint32_t k, s
 
 int max_supported_k() { return (64 * 4 - 8) / 2; }   // W <= 4 key words in this build
 
-struct GraphBuilder::Impl {
-    u32 k = 0;
+static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
+
+// A text resident in HBM with its sequence table and its 2-bit packing.
+struct PackedText {
+    const u8* d_text = nullptr;
     u64 n_text = 0, n_bases = 0;
     u32 n_seqs = 0;
     int any_dots = 0;
-    DBuf<u8> text_owned;
-    const u8* d_text = nullptr;
-    DBuf<u64> seq_off; DBuf<u32> seq_len; DBuf<u16> seq_d1, seq_d2;
+    DBuf<u64> seq_off; DBuf<u32> seq_len; DBuf<u16> seq_d1, seq_d2; DBuf<u8> seq_flags;
+    bool has_flags = false;
+    DBuf<u64> bits, mask;
     std::vector<u64> h_off; std::vector<u32> h_len;
     void set_table(const std::vector<uint64_t>& off, const std::vector<uint32_t>& len, const std::vector<uint16_t>& d1,
-                   const std::vector<uint16_t>& d2) {
+                   const std::vector<uint16_t>& d2, const std::vector<uint8_t>* flags = nullptr) {
         n_seqs = (u32)off.size();
         h_off = off; h_len = len;
         seq_off.alloc(n_seqs); seq_len.alloc(n_seqs); seq_d1.alloc(n_seqs); seq_d2.alloc(n_seqs);
-        copy_h2d(seq_off.ptr(), off.data(), n_seqs * 8);
-        copy_h2d(seq_len.ptr(), len.data(), n_seqs * 4);
-        copy_h2d(seq_d1.ptr(), d1.data(), n_seqs * 2);
-        copy_h2d(seq_d2.ptr(), d2.data(), n_seqs * 2);
+        copy_h2d(seq_off.ptr(), off.data(), (size_t)n_seqs * 8);
+        copy_h2d(seq_len.ptr(), len.data(), (size_t)n_seqs * 4);
+        copy_h2d(seq_d1.ptr(), d1.data(), (size_t)n_seqs * 2);
+        copy_h2d(seq_d2.ptr(), d2.data(), (size_t)n_seqs * 2);
+        has_flags = flags != nullptr;
+        if (flags) { seq_flags.alloc(n_seqs); copy_h2d(seq_flags.ptr(), flags->data(), n_seqs); }
         n_bases = 0; any_dots = 0;
         for (u32 i = 0; i < n_seqs; i++) { n_bases += len[i]; if (d1[i] || d2[i]) any_dots = 1; }
         stream_sync();
     }
-    template <int W> void build_impl(u32 assembly_count_hint, FinalGraph* out, BuildTimings* tm);
+    TextCtx ctx(int k) const { return TextCtx{bits.ptr(), mask.ptr(), n_text, k, seq_off.ptr(), seq_len.ptr(), seq_d1.ptr(), seq_d2.ptr(), n_seqs}; }
+    void pack() {   // K1
+        u64 n_bits_words = n_text / 32 + 8, n_mask_words = n_text / 64 + 4;   // slack for W <= 4 key words
+        bits.alloc(n_bits_words); mask.alloc(n_mask_words);
+        bits.fill_bytes(0);
+        mask.fill_bytes(0xFF);
+        launch((n_text + 31) / 32, PackFunctor{d_text, n_text, bits.ptr(), (u32*)mask.ptr()});
+    }
 };
 
-GraphBuilder::GraphBuilder(uint32_t k) : impl_(new Impl) {
-    // A builder owns the arenas for its lifetime (the C ABI serialises builds): whatever the previous build
-    // left there — device buffers and the pinned RawGraph its host tail has already consumed — is dead.
-    Arena::device().reset();
-    Arena::pinned_host().reset();
-    impl_->k = k;
-    if (k < 1 || (k % 2) == 0) throw DeviceError("k must be odd");
-    if ((int)k > max_supported_k())
-        throw DeviceError("k-mer sizes above " + std::to_string(max_supported_k()) + " are not supported by this build of the HIP backend");
-}
-GraphBuilder::~GraphBuilder() { delete impl_; }
-uint64_t GraphBuilder::n_text() const { return impl_->n_text; }
-uint64_t GraphBuilder::n_bases() const { return impl_->n_bases; }
+// All device state of one build.  Buffers are slices of the device arena, which the owning GraphBuilder resets
+// when it is created, so the state of a sharded build survives between its phases.
+struct GraphBuilder::Impl {
+    u32 k = 0;
+    DBuf<u8> text_owned;
+    PackedText loc;            // this rank's sequences
+    PackedText uni;            // sharded builds: union of all ranks' fragments
+    PackedText* G = &loc;      // the text the graph is built from
+    BuildTimings* tm = nullptr;
+    double t0 = 0, t_begin = 0;
+    void lap(double* acc) { stream_sync(); double t = now_s(); *acc += t - t0; t0 = t; }
 
-void GraphBuilder::set_sequences_host(const std::vector<SeqView>& seqs) {
-    double t0 = now_s();
-    std::vector<uint64_t> off; std::vector<uint32_t> len; std::vector<uint16_t> d1, d2;
-    std::vector<uint8_t> text = layout_text(seqs, impl_->k, &off, &len, &d1, &d2);
-    impl_->n_text = text.size();
-    impl_->text_owned.alloc(text.size());
-    copy_h2d(impl_->text_owned.ptr(), text.data(), text.size());
-    impl_->d_text = impl_->text_owned.ptr();
-    impl_->set_table(off, len, d1, d2);
-    tm_.h2d = now_s() - t0;
-}
-void GraphBuilder::set_text_device(const uint8_t* d_text, uint64_t n_text, const std::vector<uint64_t>& off,
-                                   const std::vector<uint32_t>& len, const std::vector<uint16_t>& d1,
-                                   const std::vector<uint16_t>& d2) {
-    impl_->d_text = d_text;
-    impl_->n_text = n_text;
-    impl_->set_table(off, len, d1, d2);
-}
+    DBuf<u32> counters;        // [1] insert err, [3] link err, [4] path err, [5] self-mirror links, [6] fragment err
+    // k-mer table and novel list of G
+    DBuf<u64> slots; u64 cap = 0; u64 N = 0;
+    DBuf<u64> bm; DBuf<u32> wprefix; DBuf<u64> npos;
+    // unitigs in seed order
+    u32 U = 0;
+    DBuf<u32> kinfo, head, scan, ustart, order, rank, ulen;
+    DBuf<u64> ustartpos, useq_off; DBuf<u8> uorient;
+    DBuf<int32_t> links;
+    // per-occurrence quantities from the walk over loc
+    DBuf<u32> depth, minpos_fwd, minpos_rev; DBuf<u64> path_off; DBuf<int32_t> ent_val; u64 n_ent = 0;
+    DBuf<u8> fs0, fe0;
+    // fragments of a sharded build
+    DBuf<u8> frag_text; DBuf<u64> frag_meta; u64 frag_bytes = 0, n_frags = 0;
 
-static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
+    void begin(BuildTimings* t) {
+        tm = t; t_begin = t0 = now_s();
+        counters.alloc(8); counters.fill_bytes(0);
+    }
+    void check_sizes(const PackedText& t) const {
+        if (t.n_text >= POS_MASK) throw DeviceError("input too large for 40-bit text positions");
+        if (t.n_seqs == 0 || t.n_text < (u64)k + 2) throw DeviceError("no sequences");
+    }
+    template <int W> void insert(const PackedText& t, u32 hint, DBuf<u64>* slots_out, u64* cap_out, u64* n_distinct_out);
+    void novel_bitmap(const PackedText& t, const DBuf<u64>& sl, u64 c, DBuf<u64>* bm_out);
+    template <int W> void fragments();
+    template <int W> void graph();
+    template <int W> void walk();
+    template <int W> void tail(FinalGraph* out, bool want_host);
+};
 
+// K2 insert.  Capacity from the reference's own capacity hint (assembly_count, kmer_graph.rs:40): similar assemblies
+// share most k-mers.  Overflow -> retry with a larger table.
 template <int W>
-void GraphBuilder::Impl::build_impl(u32 assembly_count_hint, FinalGraph* out, BuildTimings* tm) {
-    double t_begin = now_s(), t0 = t_begin;
-    auto lap = [&](double* acc) { stream_sync(); double t = now_s(); *acc += t - t0; t0 = t; };
-    if (n_text >= POS_MASK) throw DeviceError("input too large for 40-bit text positions");
-    if (n_seqs == 0) throw DeviceError("no sequences");
-    if (n_text < (u64)k + 2) throw DeviceError("no sequences");
-
-    // K1 pack
-    u64 n_bits_words = n_text / 32 + W + 4, n_mask_words = n_text / 64 + 4;
-    DBuf<u64> bits(n_bits_words), mask(n_mask_words);
-    bits.fill_bytes(0);
-    mask.fill_bytes(0xFF);
-    launch((n_text + 31) / 32, PackFunctor{d_text, n_text, bits.ptr(), (u32*)mask.ptr()});
-    lap(&tm->pack);
-
-    TextCtx t{bits.ptr(), mask.ptr(), n_text, (int)k, seq_off.ptr(), seq_len.ptr(), seq_d1.ptr(), seq_d2.ptr(), n_seqs};
-    const u64 p_end_all = n_text - (u64)k + 1;     // one past the last window that fits in the text
-
-    // K2 insert.  Capacity from the reference's own capacity hint (assembly_count, kmer_graph.rs:40):
-    // similar assemblies share most k-mers.  Overflow -> retry with a larger table.
-    u64 est = n_bases / (assembly_count_hint ? assembly_count_hint : 1);
-    u64 cap = next_pow2(std::max<u64>(1024, est * 3 + 4096));
-    if (cap > next_pow2(n_bases * 2 + 1024)) cap = next_pow2(n_bases * 2 + 1024);
-    DBuf<u32> counters(8);         // [1] insert err, [3] link err, [4] path err
+void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots_out, u64* cap_out, u64* n_distinct_out) {
+    TextCtx t = pt.ctx((int)k);
+    const u64 p_end_all = pt.n_text - (u64)k + 1;     // one past the last window that fits in the text
+    if (hint == 0) hint = 1;
+    u64 est = pt.n_bases / hint;
+    u64 c = next_pow2(std::max<u64>(1024, est * 3 + 4096));
+    if (c > next_pow2(pt.n_bases * 2 + 1024)) c = next_pow2(pt.n_bases * 2 + 1024);
     DBuf<InsertStats> istats(256);
-    DBuf<u64> slots;
+    DBuf<u64> sl;
     u64 n_distinct = 0;
     for (;;) {
-        slots.alloc(cap);
-        slots.fill_bytes(0xFF);
+        sl.alloc(c);
+        sl.fill_bytes(0xFF);
         counters.fill_bytes(0);
         istats.fill_bytes(0);
-        Table tb{slots.ptr(), cap - 1};
+        Table tb{sl.ptr(), c - 1};
         stream_sync();
 #ifndef AC_EMU
         hipEvent_t e0, e1;
@@ -1025,7 +1125,7 @@ void GraphBuilder::Impl::build_impl(u32 assembly_count_hint, FinalGraph* out, Bu
         // Phases over geometrically growing prefixes: [0, n/A), [n/A, 2n/A), [2n/A, 4n/A), ...  (A = assembly
         // count): what a phase streams has, for similar assemblies, mostly been inserted by the earlier ones.
         u32 launches = 0;
-        u64 first = std::max<u64>(p_end_all / (assembly_count_hint ? assembly_count_hint : 1), 1u << 16);
+        u64 first = std::max<u64>(p_end_all / hint, 1u << 16);
         u64 pb = 0;
         while (pb < p_end_all) {
             u64 pe = (pb == 0) ? first : pb * 2;
@@ -1041,51 +1141,101 @@ void GraphBuilder::Impl::build_impl(u32 assembly_count_hint, FinalGraph* out, Bu
         AC_HIP_CHECK(hipEventRecord(e1, 0));
         AC_HIP_CHECK(hipEventSynchronize(e1));
         float ms = 0; AC_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-        tm->insert_kernel_ms = ms;
+        tm->insert_kernel_ms += ms;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 #endif
-        tm->insert_launches = launches;
-        std::vector<u32> c = to_host(counters, 2);
+        tm->insert_launches += launches;
+        std::vector<u32> cc = to_host(counters, 2);
         std::vector<InsertStats> st = to_host(istats, 256);
-        n_distinct = 0; tm->insert_real = 0;
-        for (auto& x : st) { n_distinct += x.claimed; tm->insert_real += x.real; }
-        bool overflow = (c[1] != 0) || (n_distinct * 10 > cap * 7);
-        if (!overflow) break;
-        if (cap >= next_pow2(n_bases * 4 + 1024)) throw DeviceError("k-mer table overflow");
-        cap *= 4;
+        n_distinct = 0;
+        u64 real = 0;
+        for (auto& x : st) { n_distinct += x.claimed; real += x.real; }
+        bool overflow = (cc[1] != 0) || (n_distinct * 10 > c * 7);
+        if (!overflow) { tm->insert_real += real; tm->insert_positions += pt.n_text; break; }
+        if (c >= next_pow2(pt.n_bases * 4 + 1024)) throw DeviceError("k-mer table overflow");
+        c *= 4;
+        tm->insert_kernel_ms = 0; tm->insert_launches = 0;
     }
     if (n_distinct >= 0xFFFFFFF0ULL) throw DeviceError("too many distinct k-mers for 32-bit novel indices");
-    tm->insert_positions = n_text;
-    tm->table_capacity = cap;
-    tm->n_distinct = n_distinct;
-    Table tb{slots.ptr(), cap - 1};
+    *slots_out = std::move(sl);
+    *cap_out = c;
+    *n_distinct_out = n_distinct;
+}
+
+// K3a: bit p set <=> text position p is the smallest occurrence of its canonical k-mer.
+void GraphBuilder::Impl::novel_bitmap(const PackedText& t, const DBuf<u64>& sl, u64 c, DBuf<u64>* bm_out) {
+    u64 n_bm_words = t.n_text / 64 + 1;
+    bm_out->alloc(n_bm_words);
+    bm_out->fill_bytes(0);
+    launch(c, MarkFunctor{sl.ptr(), (u32*)bm_out->ptr()});
+}
+
+// Sharded phase 1 (after the local insert): novel runs of this rank -> fragment text + one meta record per fragment.
+template <int W> void GraphBuilder::Impl::fragments() {
+    DBuf<u64> lslots, lbm; u64 lcap = 0, ln = 0;
+    insert<W>(loc, tm->local_hint, &lslots, &lcap, &ln);
+    tm->n_local_distinct = ln;
     lap(&tm->insert);
+    novel_bitmap(loc, lslots, lcap, &lbm);
+    u64 nw = loc.n_text / 64 + 1;
+    DBuf<u32> ns(nw + 1), ne(nw + 1), so(nw + 1), eo(nw + 1);
+    ns.fill_bytes(0); ne.fill_bytes(0);
+    launch(nw, RunEdgeCountFunctor{lbm.ptr(), nw, ns.ptr(), ne.ptr()});
+    exclusive_scan_u32(ns.ptr(), so.ptr(), nw + 1);
+    exclusive_scan_u32(ne.ptr(), eo.ptr(), nw + 1);
+    u64 n_runs = read_scalar(so.ptr() + nw);
+    if (n_runs != (u64)read_scalar(eo.ptr() + nw)) throw DeviceError("internal error: unbalanced novel runs");
+    DBuf<u64> run_start(n_runs), run_end(n_runs);
+    launch(nw, RunEdgeFillFunctor{lbm.ptr(), nw, so.ptr(), eo.ptr(), run_start.ptr(), run_end.ptr()});
+    n_frags = n_runs + 2 * (u64)loc.n_seqs;
+    DBuf<u64> fpos(n_frags), blen(n_frags + 1), boff(n_frags + 1);
+    frag_meta.alloc(n_frags);
+    launch(n_frags + 1, FragMetaFunctor{loc.ctx((int)k), run_start.ptr(), run_end.ptr(), n_runs, n_frags, fpos.ptr(), frag_meta.ptr(),
+                                        blen.ptr(), counters.ptr() + 6});
+    exclusive_scan_u64(blen.ptr(), boff.ptr(), n_frags + 1);
+    frag_bytes = read_scalar(boff.ptr() + n_frags);
+    frag_text.alloc(frag_bytes);
+    launch((frag_bytes + 63) / 64, FragCopyFunctor{loc.d_text, fpos.ptr(), boff.ptr(), n_frags, frag_bytes, frag_text.ptr()});
+    if (read_scalar(counters.ptr() + 6)) throw DeviceError("internal error: novel run outside a sequence");
+    tm->n_fragments = n_frags; tm->fragment_bytes = frag_bytes;
+    lap(&tm->fragments);
+}
+
+// K2..K11 on the graph text G: k-mer table, novel list, degrees, unitigs in seed order, links by successor symbol.
+template <int W> void GraphBuilder::Impl::graph() {
+    PackedText& g = *G;
+    check_sizes(g);
+    TextCtx t = g.ctx((int)k);
+    insert<W>(g, tm->graph_hint, &slots, &cap, &N);
+    tm->table_capacity = cap;
+    tm->n_distinct = N;
+    Table tb{slots.ptr(), cap - 1};
+    lap(G == &loc ? &tm->insert : &tm->union_insert);
 
     // K3 novel-position bitmap -> sorted novel list + rank support
-    u64 N = n_distinct;
-    u64 n_bm_words = n_text / 64 + 1;
-    DBuf<u64> bm(n_bm_words); DBuf<u32> wcnt(n_bm_words), wprefix(n_bm_words);
-    bm.fill_bytes(0);
-    launch(cap, MarkFunctor{slots.ptr(), (u32*)bm.ptr()});
+    u64 n_bm_words = g.n_text / 64 + 1;
+    novel_bitmap(g, slots, cap, &bm);
+    DBuf<u32> wcnt(n_bm_words);
+    wprefix.alloc(n_bm_words);
     launch(n_bm_words, PopcFunctor{bm.ptr(), wcnt.ptr()});
     exclusive_scan_u32(wcnt.ptr(), wprefix.ptr(), n_bm_words);
-    DBuf<u64> npos(N);
+    npos.alloc(N);
     launch(n_bm_words, FillNovelFunctor{bm.ptr(), wprefix.ptr(), npos.ptr()});
     Novel nv{bm.ptr(), wprefix.ptr()};
     lap(&tm->collect_sort);
 
     // K5/K6 degrees + first flags
-    DBuf<u32> kinfo(N, true);
-    launch(N, DegreeFunctor<W>{t, tb, npos.ptr(), kinfo.ptr(), any_dots});
-    launch(n_seqs, FirstFunctor<W>{t, tb, nv, kinfo.ptr()});
+    kinfo.alloc(N, true);
+    launch(N, DegreeFunctor<W>{t, tb, npos.ptr(), kinfo.ptr(), g.any_dots});
+    launch(g.n_seqs, FirstFunctor<W>{t, tb, nv, kinfo.ptr(), g.has_flags ? g.seq_flags.ptr() : nullptr});
     lap(&tm->degree);
 
     // K7 heads -> unitig ids
-    DBuf<u32> head(N + 1, true), scan(N + 1, true);
+    head.alloc(N + 1, true); scan.alloc(N + 1, true);
     launch(N, HeadFunctor{npos.ptr(), kinfo.ptr(), head.ptr(), N});
     inclusive_scan_u32(head.ptr(), scan.ptr(), N);
-    u32 U = read_scalar(scan.ptr() + (N - 1));
-    DBuf<u32> ustart(U + 1);
+    U = read_scalar(scan.ptr() + (N - 1));
+    ustart.alloc((u64)U + 1);
     launch(N, UnitigStartFunctor{head.ptr(), scan.ptr(), ustart.ptr(), N});
     lap(&tm->segment);
 
@@ -1099,10 +1249,11 @@ void GraphBuilder::Impl::build_impl(u32 assembly_count_hint, FinalGraph* out, Bu
     lap(&tm->minkey);
 
     // K9 seed order = rank of the smallest k-mer
-    DBuf<u32> order(U);
+    order.alloc(U);
     launch(U, IotaFunctor{order.ptr()});
     sort_by_key_cmp(umin, order, U, MinValLess<W>());
-    DBuf<u32> rank(U), ulen(U); DBuf<u64> ulen64(U + 1), ustartpos(U), useq_off(U + 1); DBuf<u8> uorient(U);
+    rank.alloc(U); ulen.alloc(U); ustartpos.alloc(U); useq_off.alloc((u64)U + 1); uorient.alloc(U);
+    DBuf<u64> ulen64((u64)U + 1);
     launch((u64)U + 1, UnitigMetaFunctor<W>{order.ptr(), ustart.ptr(), npos.ptr(), umin.ptr(), U, N, rank.ptr(), ulen.ptr(),
                                             ulen64.ptr(), ustartpos.ptr(), uorient.ptr()});
     exclusive_scan_u64(ulen64.ptr(), useq_off.ptr(), (u64)U + 1);
@@ -1110,31 +1261,47 @@ void GraphBuilder::Impl::build_impl(u32 assembly_count_hint, FinalGraph* out, Bu
     lap(&tm->rank);
 
     // K11 links by successor symbol
-    DBuf<int32_t> links((u64)U * 10);
-    launch((u64)U * 2, LinksFunctor<W>{t, tb, nv, uc, order.ptr(), npos.ptr(), any_dots, links.ptr(), counters.ptr() + 3});
+    links.alloc((u64)U * 10);
+    launch((u64)U * 2, LinksFunctor<W>{t, tb, nv, uc, order.ptr(), npos.ptr(), g.any_dots, links.ptr(), counters.ptr() + 3});
     lap(&tm->links);
+}
 
-    // K10 paths: count, scan, write
+// K10 paths of this rank's sequences against the graph: count, scan, write; first / last unitig of every path.
+template <int W> void GraphBuilder::Impl::walk() {
+    TextCtx t = loc.ctx((int)k), g = G->ctx((int)k);
+    Table tb{slots.ptr(), cap - 1};
+    Novel nv{bm.ptr(), wprefix.ptr()};
+    UnitigCtx uc{head.ptr(), scan.ptr(), rank.ptr(), uorient.ptr(), ustart.ptr(), ulen.ptr(), U, N};
     const u32 PC = 256;
-    u64 n_walkers = (n_text + PC - 1) / PC;
-    DBuf<u32> depth(U, true), minpos_fwd(U), minpos_rev(U);
+    u64 n_walkers = (loc.n_text + PC - 1) / PC;
+    depth.alloc(U, true); minpos_fwd.alloc(U); minpos_rev.alloc(U);
     minpos_fwd.fill_bytes(0xFF); minpos_rev.fill_bytes(0xFF);
-    DBuf<u64> wcount(n_walkers + 1), woff(n_walkers + 1), path_off(n_seqs + 1);
+    DBuf<u64> wcount(n_walkers + 1), woff(n_walkers + 1);
+    path_off.alloc((u64)loc.n_seqs + 1);
     wcount.fill_bytes(0);
-    launch(n_walkers, PathWalkFunctor<W, false>{t, tb, nv, uc, links.ptr(), PC, wcount.ptr(), nullptr, nullptr, nullptr, nullptr,
+    launch(n_walkers, PathWalkFunctor<W, false>{t, g, tb, nv, uc, links.ptr(), PC, wcount.ptr(), nullptr, nullptr, nullptr, nullptr,
                                                nullptr, counters.ptr() + 4});
     exclusive_scan_u64(wcount.ptr(), woff.ptr(), n_walkers + 1);
-    u64 n_ent = read_scalar(woff.ptr() + n_walkers);
-    DBuf<int32_t> ent_val(n_ent);
-    launch(n_walkers, PathWalkFunctor<W, true>{t, tb, nv, uc, links.ptr(), PC, woff.ptr(), ent_val.ptr(), path_off.ptr(), depth.ptr(),
+    n_ent = read_scalar(woff.ptr() + n_walkers);
+    ent_val.alloc(n_ent);
+    launch(n_walkers, PathWalkFunctor<W, true>{t, g, tb, nv, uc, links.ptr(), PC, woff.ptr(), ent_val.ptr(), path_off.ptr(), depth.ptr(),
                                               minpos_fwd.ptr(), minpos_rev.ptr(), counters.ptr() + 4});
     tm->n_path_entries = n_ent;
+    copy_h2d(path_off.ptr() + loc.n_seqs, &n_ent, 8);
+    fs0.alloc(U, true); fe0.alloc(U, true);
+    launch(loc.n_seqs, PathEndsFunctor{ent_val.ptr(), path_off.ptr(), fs0.ptr(), fe0.ptr()});
     lap(&tm->paths);
+}
 
+// K12..K17 + D2H: sequences, link push order, expand_repeats, both renumberings, final numbering.  Needs depth,
+// min positions and path ends of ALL sequences (reduced over ranks first in a sharded build).
+template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_host) {
+    PackedText& g = *G;
+    const u32 n_seqs = loc.n_seqs;
     // K12 sequences
     u64 total = N;   // sum of unitig lengths == number of distinct canonical k-mers
     DBuf<u8> useq(total);
-    launch((total + 63) / 64, SeqFunctor{bits.ptr(), useq_off.ptr(), ustartpos.ptr(), ulen.ptr(), uorient.ptr(), U, total,
+    launch((total + 63) / 64, SeqFunctor{g.bits.ptr(), useq_off.ptr(), ustartpos.ptr(), ulen.ptr(), uorient.ptr(), U, total,
                                          (int)(k / 2), useq.ptr()});
     lap(&tm->seqs);
 
@@ -1142,9 +1309,7 @@ void GraphBuilder::Impl::build_impl(u32 assembly_count_hint, FinalGraph* out, Bu
     DBuf<int32_t> lord((u64)U * 10); DBuf<u8> lcnt((u64)U * 2);
     launch((u64)U * 2, LinkOrderFunctor{links.ptr(), lord.ptr(), lcnt.ptr(), counters.ptr() + 5});
     OrderedLinks L{lord.ptr(), lcnt.ptr()};
-    copy_h2d(path_off.ptr() + n_seqs, &n_ent, 8);
-    DBuf<u8> fs0(U, true), fe0(U, true), fixed_start(U, true), fixed_end(U, true), cand((u64)U * 2);
-    launch(n_seqs, PathEndsFunctor{ent_val.ptr(), path_off.ptr(), fs0.ptr(), fe0.ptr()});
+    DBuf<u8> fixed_start(U, true), fixed_end(U, true), cand((u64)U * 2);
     launch(U, FixedSpreadFunctor{fs0.ptr(), fe0.ptr(), L, fixed_start.ptr(), fixed_end.ptr()});
     launch((u64)U * 2, CandFunctor{L, fixed_start.ptr(), fixed_end.ptr(), cand.ptr()});
     DBuf<u32> order1(U);
@@ -1240,25 +1405,29 @@ void GraphBuilder::Impl::build_impl(u32 assembly_count_hint, FinalGraph* out, Bu
     out->k = k;
     out->n_kmers = 2 * (u64)N;
     out->n_unitigs = U;
-    out->seq_block = PinnedPool::get().alloc(final_total);
-    out->meta_block = PinnedPool::get().alloc((size_t)U * 20);
-    out->links_block = PinnedPool::get().alloc(n_links * sizeof(Link));
-    out->path_block = PinnedPool::get().alloc(n_ent * 4);
-    copy_d2h_async(out->seq_block.p, cur, final_total);
-    copy_d2h_async(out->meta_block.p, meta.ptr(), (size_t)U * 20);
-    copy_d2h_async(out->links_block.p, links_out.ptr(), n_links * sizeof(Link));
-    copy_d2h_async(out->path_block.p, ent_val.ptr(), n_ent * 4);
+    if (want_host) {
+        out->seq_block = PinnedPool::get().alloc(final_total);
+        out->meta_block = PinnedPool::get().alloc((size_t)U * 20);
+        out->links_block = PinnedPool::get().alloc(n_links * sizeof(Link));
+        out->path_block = PinnedPool::get().alloc(n_ent * 4);
+        copy_d2h_async(out->seq_block.p, cur, final_total);
+        copy_d2h_async(out->meta_block.p, meta.ptr(), (size_t)U * 20);
+        copy_d2h_async(out->links_block.p, links_out.ptr(), n_links * sizeof(Link));
+        copy_d2h_async(out->path_block.p, ent_val.ptr(), n_ent * 4);
+    }
     std::vector<u64> h_sums = to_host(sums, n_seqs);
     out->path_off = to_host(path_off, (size_t)n_seqs + 1);
     std::vector<u32> errs = to_host(counters, 8);   // synchronises the stream: everything above has landed
     if (errs[3] || errs[4])
         throw DeviceError("internal error: inconsistent unitig ends (codes " + std::to_string(errs[3]) + "/" + std::to_string(errs[4]) + ")");
-    out->seq_begin = (const u64*)out->meta_block.p;
-    out->depth = (const double*)((const u8*)out->meta_block.p + (size_t)U * 8);
-    out->seq_len = (const u32*)((const u8*)out->meta_block.p + (size_t)U * 16);
-    out->links = (const Link*)out->links_block.p;
+    if (want_host) {
+        out->seq_begin = (const u64*)out->meta_block.p;
+        out->depth = (const double*)((const u8*)out->meta_block.p + (size_t)U * 8);
+        out->seq_len = (const u32*)((const u8*)out->meta_block.p + (size_t)U * 16);
+        out->links = (const Link*)out->links_block.p;
+        out->path = (const int32_t*)out->path_block.p;
+    }
     out->n_links = n_links;
-    out->path = (const int32_t*)out->path_block.p;
     out->n_path = n_ent;
     u64 n_self = errs[5];
     u64 links_one_way = (n_links + n_self) / 2;   // link_count().1 (unitig_graph.rs:478-507): a link and its mirror count
@@ -1268,26 +1437,140 @@ void GraphBuilder::Impl::build_impl(u32 assembly_count_hint, FinalGraph* out, Bu
     out->simplify_passes = passes;
     // The path of every sequence must spell its full length (unitig_graph.rs:160-174, decompress.rs).
     for (u32 s = 0; s < n_seqs; s++)
-        if (h_sums[s] != (u64)h_len[s])
+        if (h_sums[s] != (u64)loc.h_len[s])
             throw DeviceError("internal error: path length mismatch for sequence " + std::to_string(s + 1));
     lap(&tm->d2h);
     tm->total_device = now_s() - t_begin;
 }
 
+// ---- GraphBuilder ------------------------------------------------------------------------------------------------
+GraphBuilder::GraphBuilder(uint32_t k) : impl_(new Impl) {
+    // A builder owns the arenas for its lifetime (the C ABI serialises builds): whatever the previous build
+    // left there — device buffers and the pinned RawGraph its host tail has already consumed — is dead.
+    Arena::device().reset();
+    Arena::pinned_host().reset();
+    impl_->k = k;
+    if (k < 1 || (k % 2) == 0) throw DeviceError("k must be odd");
+    if ((int)k > max_supported_k())
+        throw DeviceError("k-mer sizes above " + std::to_string(max_supported_k()) + " are not supported by this build of the HIP backend");
+}
+GraphBuilder::~GraphBuilder() { delete impl_; }
+uint64_t GraphBuilder::n_text() const { return impl_->loc.n_text; }
+uint64_t GraphBuilder::n_bases() const { return impl_->loc.n_bases; }
+
+void GraphBuilder::set_sequences_host(const std::vector<SeqView>& seqs) {
+    double t0 = now_s();
+    std::vector<uint64_t> off; std::vector<uint32_t> len; std::vector<uint16_t> d1, d2;
+    std::vector<uint8_t> text = layout_text(seqs, impl_->k, &off, &len, &d1, &d2);
+    impl_->loc.n_text = text.size();
+    impl_->text_owned.alloc(text.size());
+    copy_h2d(impl_->text_owned.ptr(), text.data(), text.size());
+    impl_->loc.d_text = impl_->text_owned.ptr();
+    impl_->loc.set_table(off, len, d1, d2);
+    tm_.h2d = now_s() - t0;
+}
+void GraphBuilder::set_text_device(const uint8_t* d_text, uint64_t n_text, const std::vector<uint64_t>& off,
+                                   const std::vector<uint32_t>& len, const std::vector<uint16_t>& d1,
+                                   const std::vector<uint16_t>& d2) {
+    impl_->loc.d_text = d_text;
+    impl_->loc.n_text = n_text;
+    impl_->loc.set_table(off, len, d1, d2);
+}
+
+#define AC_DISPATCH_W(NAME, ARGS)                                        \
+    switch (words_for_k((int)impl_->k)) {                                \
+        case 1: impl_->template NAME<1> ARGS; break;                     \
+        case 2: impl_->template NAME<2> ARGS; break;                     \
+        case 3: impl_->template NAME<3> ARGS; break;                     \
+        case 4: impl_->template NAME<4> ARGS; break;                     \
+        default: throw DeviceError("unsupported k");                     \
+    }
+
 void GraphBuilder::build(uint32_t assembly_count_hint, FinalGraph* out) {
-    // Everything the previous build left in the arenas is dead (its RawGraph has been consumed by the host
-    // tail); the sequence table of this builder lives outside the arena.
     BuildTimings keep = tm_;
     tm_ = BuildTimings();
     tm_.h2d = keep.h2d;
-    int W = words_for_k((int)impl_->k);
-    switch (W) {
-        case 1: impl_->build_impl<1>(assembly_count_hint, out, &tm_); break;
-        case 2: impl_->build_impl<2>(assembly_count_hint, out, &tm_); break;
-        case 3: impl_->build_impl<3>(assembly_count_hint, out, &tm_); break;
-        case 4: impl_->build_impl<4>(assembly_count_hint, out, &tm_); break;
-        default: throw DeviceError("unsupported k");
+    tm_.graph_hint = assembly_count_hint;
+    Impl& m = *impl_;
+    m.begin(&tm_);
+    m.G = &m.loc;
+    m.check_sizes(m.loc);
+    m.loc.pack();
+    m.lap(&tm_.pack);
+    AC_DISPATCH_W(graph, ())
+    AC_DISPATCH_W(walk, ())
+    AC_DISPATCH_W(tail, (out, true))
+}
+
+// ---- sharded build (one compress job over several devices; the collectives between the phases belong to the
+// caller, e.g. torch.distributed over RCCL) -----------------------------------------------------------------------
+void GraphBuilder::shard_begin(uint32_t local_assembly_hint) {
+    BuildTimings keep = tm_;
+    tm_ = BuildTimings();
+    tm_.h2d = keep.h2d;
+    tm_.local_hint = local_assembly_hint;
+    Impl& m = *impl_;
+    m.begin(&tm_);
+    m.check_sizes(m.loc);
+    m.loc.pack();
+    m.lap(&tm_.pack);
+    AC_DISPATCH_W(fragments, ())
+}
+uint64_t GraphBuilder::fragment_text_bytes() const { return impl_->frag_bytes; }
+uint64_t GraphBuilder::fragment_count() const { return impl_->n_frags; }
+void GraphBuilder::fragments_export(void* d_text_out, void* d_meta_out) {
+    copy_d2d(d_text_out, impl_->frag_text.ptr(), impl_->frag_bytes);
+    copy_d2d(d_meta_out, impl_->frag_meta.ptr(), impl_->n_frags * 8);
+    stream_sync();
+}
+void GraphBuilder::shard_build_union(uint32_t n_shards, const uint8_t* d_union_text, uint64_t n_union_text, const void* d_meta,
+                                     uint64_t n_frags_total) {
+    Impl& m = *impl_;
+    m.t0 = now_s();
+    if (n_frags_total == 0 || n_frags_total >= 0xFFFFFFF0ULL) throw DeviceError("invalid fragment count");
+    std::vector<u64> meta(n_frags_total);
+    copy_d2h(meta.data(), d_meta, n_frags_total * 8);
+    std::vector<uint64_t> off(n_frags_total); std::vector<uint32_t> len(n_frags_total);
+    std::vector<uint16_t> d1(n_frags_total), d2(n_frags_total); std::vector<uint8_t> flags(n_frags_total);
+    u64 p = 1;
+    for (u64 i = 0; i < n_frags_total; i++) {
+        u64 r = meta[i];
+        len[i] = (u32)r; d1[i] = (u16)((r >> 32) & 0xFF); d2[i] = (u16)((r >> 40) & 0xFF); flags[i] = (u8)((r >> 48) & 0xFF);
+        if (len[i] == 0) throw DeviceError("invalid fragment record");
+        off[i] = p;
+        p += (u64)len[i] + impl_->k;
     }
+    if (p != n_union_text) throw DeviceError("fragment records do not add up to the union text size");
+    m.uni.d_text = d_union_text;
+    m.uni.n_text = n_union_text;
+    m.uni.set_table(off, len, d1, d2, &flags);
+    m.G = &m.uni;
+    tm_.graph_hint = n_shards;
+    m.uni.pack();
+    m.lap(&tm_.union_pack);
+    AC_DISPATCH_W(graph, ())
+    AC_DISPATCH_W(walk, ())
+}
+uint32_t GraphBuilder::unitig_count() const { return impl_->U; }
+void GraphBuilder::reduce_export(int32_t* d_sum, int32_t* d_min) {
+    Impl& m = *impl_;
+    launch(m.U, ReduceExportFunctor{m.depth.ptr(), m.fs0.ptr(), m.fe0.ptr(), m.minpos_fwd.ptr(), m.minpos_rev.ptr(), m.U, d_sum, d_min});
+    stream_sync();
+}
+void GraphBuilder::reduce_import(const int32_t* d_sum, const int32_t* d_min) {
+    Impl& m = *impl_;
+    m.t0 = now_s();
+    launch(m.U, ReduceImportFunctor{m.depth.ptr(), m.fs0.ptr(), m.fe0.ptr(), m.minpos_fwd.ptr(), m.minpos_rev.ptr(), m.U, d_sum, d_min});
+    stream_sync();
+}
+void GraphBuilder::shard_finish(FinalGraph* out, bool want_host) {
+    impl_->t0 = now_s();
+    AC_DISPATCH_W(tail, (out, want_host))
+}
+uint64_t GraphBuilder::path_entry_count() const { return impl_->n_ent; }
+void GraphBuilder::paths_export(void* d_out) {
+    copy_d2d(d_out, impl_->ent_val.ptr(), impl_->n_ent * 4);
+    stream_sync();
 }
 
 }  // namespace ac

@@ -33,6 +33,11 @@ struct BuildTimings {                   // seconds; device stages are bracketed 
     uint32_t insert_launches = 0;       // phases of the run-following insert (same kernel, launched per phase)
     uint64_t insert_real = 0;           // positions that actually touched the table
     uint32_t simplify_passes = 0, n_candidates = 0, n_levels = 0;   // expand_repeats: passes, candidate junctions, conflict levels
+    // sharded builds (one job over several devices)
+    uint32_t local_hint = 0, graph_hint = 0;   // capacity hints of the local / graph table (assembly counts)
+    double fragments = 0;               // novel runs of this rank -> fragment text
+    double union_pack = 0, union_insert = 0;   // packing / inserting the union of all ranks' fragments
+    uint64_t n_local_distinct = 0, n_fragments = 0, fragment_bytes = 0;
 };
 
 class GraphBuilder {
@@ -50,6 +55,27 @@ class GraphBuilder {
     // The timed region (compress.rs:42-44): packed text -> final UnitigGraph in host memory.  Everything runs on
     // the device, including expand_repeats and both renumberings; the host only receives the results.
     void build(uint32_t assembly_count_hint, FinalGraph* out);
+
+    // One job sharded by sequence over several devices.  This rank's sequences are set with set_text_device /
+    // set_sequences_host as usual; the collectives between the phases are the caller's (torch.distributed / RCCL).
+    //   1. shard_begin: pack + insert this rank's sequences, cut its novel runs out as "fragments".
+    //      -> all-gather the fragment texts and meta records of all ranks (rank order).
+    //   2. shard_build_union: build the global graph from the union text ('$' + all fragment texts), then walk this
+    //      rank's sequences through it.  -> all-reduce (SUM / MIN) the per-unitig buffers of reduce_export.
+    //   3. reduce_import + shard_finish: the order-sensitive tail (identical on every rank); paths of this rank's
+    //      sequences in final numbers.  -> gather the paths (paths_export) to the rank that writes the GFA.
+    void shard_begin(uint32_t local_assembly_hint);
+    uint64_t fragment_text_bytes() const;
+    uint64_t fragment_count() const;
+    void fragments_export(void* d_text_out, void* d_meta_out);      // device buffers: text bytes, 8 bytes per fragment
+    void shard_build_union(uint32_t n_shards, const uint8_t* d_union_text, uint64_t n_union_text, const void* d_meta,
+                           uint64_t n_frags_total);
+    uint32_t unitig_count() const;
+    void reduce_export(int32_t* d_sum, int32_t* d_min);             // 3U and 2U int32
+    void reduce_import(const int32_t* d_sum, const int32_t* d_min);
+    void shard_finish(FinalGraph* out, bool want_host);
+    uint64_t path_entry_count() const;
+    void paths_export(void* d_out);                                 // int32 per entry, final numbers
     const BuildTimings& timings() const { return tm_; }
     uint64_t n_text() const;
     uint64_t n_bases() const;   // sum of unpadded lengths

@@ -1,0 +1,183 @@
+"""One `autocycler compress` job sharded by SEQUENCE over several MI355X.
+
+One process per GPU.  Rank r holds a contiguous slice of the job's sequences (rank order = sequence order) as a
+device-resident text.  The compute is libautocycler_hip.so (ac_shard_* in include/autocycler_hip.h); this module is
+only the plumbing between its phases — three collectives over torch.distributed (backend "nccl" = RCCL over xGMI on
+the GPU box, "gloo" in the CPU test-suite):
+
+    ac_shard_begin          local k-mer insert -> this rank's novel runs ("fragments")
+      all-gather            fragment text + 8-byte records of every rank           (∝ distinct content, not ∝ input)
+    ac_shard_build_union    identical global graph on every rank, then the paths of the local sequences
+      all-reduce SUM, MIN   per-unitig depth / path-end counts, smallest positions  (5 x U int32)
+    ac_shard_finish         order-sensitive tail (identical on every rank)
+      gather to root        paths of all sequences in final numbers -> the rank that writes the GFA
+
+Nothing here computes: without the library the calls raise HipLibraryMissing."""
+import ctypes as C
+import time
+
+import torch
+
+from . import _capi
+
+
+class Comm:
+    """The collectives a sharded build needs.  world == 1 (or no process group) degenerates to local copies."""
+
+    def __init__(self, device, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.device = torch.device(device)
+        if dist.is_available() and dist.is_initialized():
+            self.world = dist.get_world_size(group)
+            self.rank = dist.get_rank(group)
+            backend = dist.get_backend(group)
+        else:
+            self.world, self.rank, backend = 1, 0, None
+        # gloo moves host memory: device tensors are staged through the host (CPU test-suite, single-GPU dry runs)
+        self.stage = (backend == "gloo") and self.device.type != "cpu"
+        self.seconds = 0.0
+
+    def _out(self, t):
+        return t.cpu() if self.stage else t
+
+    def _back(self, t):
+        return t.to(self.device) if self.stage else t
+
+    def all_gather_sizes(self, values):
+        """values: list of ints -> list (per rank) of lists."""
+        if self.world == 1:
+            return [list(values)]
+        t0 = time.perf_counter()
+        mine = self._out(torch.tensor(values, dtype=torch.int64, device=self.device))
+        out = torch.empty(self.world * len(values), dtype=torch.int64, device=mine.device)
+        self.dist.all_gather_into_tensor(out, mine, group=self.group)
+        res = out.cpu().view(self.world, len(values)).tolist()
+        self.seconds += time.perf_counter() - t0
+        return res
+
+    def all_gather_padded(self, t, sizes):
+        """t: 1-D tensor holding sizes[rank] elements (may be longer); returns the per-rank slices."""
+        if self.world == 1:
+            return [t[:sizes[0]]]
+        t0 = time.perf_counter()
+        m = max(sizes)
+        mine = t if t.numel() == m else torch.cat([t[:sizes[self.rank]], t.new_zeros(m - sizes[self.rank])])
+        mine = self._out(mine)
+        out = torch.empty(self.world * m, dtype=t.dtype, device=mine.device)
+        self.dist.all_gather_into_tensor(out, mine, group=self.group)
+        out = self._back(out)
+        self.seconds += time.perf_counter() - t0
+        return [out[r * m:r * m + sizes[r]] for r in range(self.world)]
+
+    def gather_padded(self, t, sizes, root):
+        """Like all_gather_padded, but only `root` receives (others get None)."""
+        if self.world == 1:
+            return [t[:sizes[0]]]
+        t0 = time.perf_counter()
+        m = max(sizes)
+        mine = t if t.numel() == m else torch.cat([t[:sizes[self.rank]], t.new_zeros(m - sizes[self.rank])])
+        mine = self._out(mine)
+        if self.rank == root:
+            bufs = [torch.empty(m, dtype=t.dtype, device=mine.device) for _ in range(self.world)]
+            self.dist.gather(mine, bufs, dst=root, group=self.group)
+            res = [self._back(bufs[r])[:sizes[r]] for r in range(self.world)]
+        else:
+            self.dist.gather(mine, None, dst=root, group=self.group)
+            res = None
+        self.seconds += time.perf_counter() - t0
+        return res
+
+    def all_reduce(self, t, op):
+        if self.world == 1:
+            return t
+        t0 = time.perf_counter()
+        x = self._out(t)
+        self.dist.all_reduce(x, op=getattr(self.dist.ReduceOp, op), group=self.group)
+        if self.stage:
+            t.copy_(x)
+        self.seconds += time.perf_counter() - t0
+        return t
+
+
+class LocalShard:
+    """This rank's slice of the job, resident on the device: the arguments of ac_shard_begin."""
+
+    def __init__(self, k, local_assembly_count, d_text, n_text, off, lens, ids, d1, d2):
+        self.k, self.local_assembly_count = k, local_assembly_count
+        self.d_text, self.n_text = d_text, n_text          # torch uint8 tensor on the device (kept alive here)
+        self.n_seqs = len(lens)
+        self.off = (C.c_uint64 * self.n_seqs)(*off)
+        self.lens = (C.c_uint32 * self.n_seqs)(*lens)
+        self.ids = (C.c_uint16 * self.n_seqs)(*ids)
+        self.d1 = (C.c_uint16 * self.n_seqs)(*d1)
+        self.d2 = (C.c_uint16 * self.n_seqs)(*d2)
+        self.bases = int(sum(lens))
+
+
+def _check(lib, rc):
+    if rc != 0:
+        raise _capi.AutocyclerError(lib.ac_last_error().decode(errors="replace"))
+
+
+def sharded_build(lib, shard, comm, device_index=0, root=0):
+    """Runs one sharded compress build.  Returns (Graph, info): on `root` the Graph holds the whole result (all
+    paths, ready for Graph.gfa); on the other ranks it holds the statistics only."""
+    dev = comm.device
+    h = C.c_void_p()
+    _check(lib, lib.ac_shard_begin(C.c_uint32(shard.k), C.c_uint32(shard.local_assembly_count), C.c_void_p(shard.d_text.data_ptr()),
+                                   C.c_uint64(shard.n_text), shard.off, shard.lens, shard.ids, shard.d1, shard.d2,
+                                   C.c_uint32(shard.n_seqs), C.c_int(device_index), C.byref(h)))
+    try:
+        # fragments of all ranks -> union text
+        nb, nf = C.c_uint64(), C.c_uint64()
+        lib.ac_shard_fragment_sizes(h, C.byref(nb), C.byref(nf))
+        nb, nf = nb.value, nf.value
+        sizes = comm.all_gather_sizes([nf, nb])
+        mine = torch.empty(8 * nf + nb, dtype=torch.uint8, device=dev)       # [records | text]
+        _check(lib, lib.ac_shard_fragments_export(h, C.c_void_p(mine.data_ptr() + 8 * nf), C.c_void_p(mine.data_ptr())))
+        parts = comm.all_gather_padded(mine, [8 * f + b for f, b in sizes])
+        nf_total = sum(f for f, _ in sizes)
+        nb_total = 1 + sum(b for _, b in sizes)
+        dollar = torch.full((1,), ord("$"), dtype=torch.uint8, device=dev)
+        union = torch.cat([dollar] + [p[8 * f:] for p, (f, _) in zip(parts, sizes)])
+        # 8-byte alignment of the records: build them in their own tensor
+        meta = torch.cat([p[:8 * f] for p, (f, _) in zip(parts, sizes)]).contiguous()
+        _check(lib, lib.ac_shard_build_union(h, C.c_uint32(comm.world), C.c_void_p(union.data_ptr()), C.c_uint64(nb_total),
+                                             C.c_void_p(meta.data_ptr()), C.c_uint64(nf_total)))
+        del parts, mine
+        # per-unitig quantities over all sequences
+        U = lib.ac_shard_unitig_count(h)
+        red = torch.empty(5 * U, dtype=torch.int32, device=dev)
+        _check(lib, lib.ac_shard_reduce_export(h, C.c_void_p(red.data_ptr()), C.c_void_p(red.data_ptr() + 12 * U)))
+        comm.all_reduce(red[:3 * U], "SUM")
+        comm.all_reduce(red[3 * U:], "MIN")
+        _check(lib, lib.ac_shard_reduce_import(h, C.c_void_p(red.data_ptr()), C.c_void_p(red.data_ptr() + 12 * U)))
+        g = C.c_void_p()
+        _check(lib, lib.ac_shard_finish(h, C.c_int(1 if comm.rank == root else 0), C.byref(g)))
+        graph = _capi.Graph(lib, g, shard.n_seqs)
+        # paths of all sequences -> root
+        if comm.world > 1:
+            ne = lib.ac_shard_path_entries(h)
+            psz = comm.all_gather_sizes([ne, shard.n_seqs])
+            ent = torch.empty(max(ne, 1), dtype=torch.int32, device=dev)
+            _check(lib, lib.ac_shard_paths_export(h, C.c_void_p(ent.data_ptr())))
+            counts = graph.path_counts()
+            info = torch.tensor([[shard.ids[i], shard.lens[i], counts[i]] for i in range(shard.n_seqs)], dtype=torch.int64,
+                                device=dev).reshape(-1)
+            infos = comm.gather_padded(info, [3 * s for _, s in psz], root)
+            ents = comm.gather_padded(ent, [e for e, _ in psz], root)
+            if comm.rank == root:
+                all_info = torch.cat(infos).cpu().view(-1, 3)
+                n_total = all_info.shape[0]
+                all_ent = torch.cat(ents).contiguous()
+                ids = (C.c_uint16 * n_total)(*all_info[:, 0].tolist())
+                lens = (C.c_uint32 * n_total)(*all_info[:, 1].tolist())
+                cnts = (C.c_uint64 * n_total)(*all_info[:, 2].tolist())
+                _check(lib, lib.ac_graph_set_paths(g, C.c_uint32(n_total), ids, lens, cnts, C.c_void_p(all_ent.data_ptr()),
+                                                   C.c_int(device_index)))
+                graph.n_seqs = n_total
+        return graph, {"fragments": nf_total, "union_text_bytes": nb_total, "unitigs": U, "comm_s": comm.seconds}
+    finally:
+        lib.ac_shard_free(h)

@@ -56,6 +56,10 @@ typedef struct {
     double finalize;            /* second renumber, final numbering of links and paths */
     uint32_t n_candidates;      /* junctions that pass the static tests of expand_repeats */
     uint32_t n_levels;          /* conflict levels they are scheduled in */
+    /* sharded builds only */
+    double fragments;           /* cutting this rank's novel runs out of its text */
+    double union_pack, union_insert;   /* packing / inserting the union of all ranks' fragments */
+    uint64_t n_local_distinct, n_fragments, fragment_bytes;
 } ac_timings;
 
 /* Replaces compress.rs:42-44.  k: --kmer (odd).  assembly_count: the reference's capacity hint
@@ -70,6 +74,47 @@ int ac_compress_build_device(uint32_t k, uint32_t assembly_count, const void* d_
                              const uint64_t* seq_off, const uint32_t* seq_len, const uint16_t* seq_ids,
                              const uint16_t* seq_d1, const uint16_t* seq_d2, uint32_t n_seqs, int device,
                              ac_graph** out);
+
+/* ---- one compress job sharded by SEQUENCE over several devices --------------------------------------
+ * One process per device; every rank holds a slice of the job's sequences (rank order = sequence order) as a device text
+ * laid out as above.  The library never communicates: the three collectives between the phases belong to the caller
+ * (torch.distributed over RCCL in autocycler_amd/sharded.py; anything that moves device buffers works).
+ *
+ *   ac_shard_begin            pack + insert this rank's sequences (KmerGraph::add_sequences on the slice), cut the runs of
+ *                             rank-novel positions out as "fragments" (+ the first and last k-mer of every sequence, which
+ *                             carry first_position, kmer_graph.rs:57-60)
+ *   [all-gather]              fragment texts and 8-byte meta records of all ranks, concatenated in rank order;
+ *                             union text = '$' + the concatenated fragment texts
+ *   ac_shard_build_union      global k-mer set, unitigs in seed order and links from the union text — identical on every
+ *                             rank — then the paths of this rank's sequences through it
+ *   [all-reduce SUM, MIN]     ac_shard_reduce_export -> sum buffer (3U int32: depth, path starts, path ends) and min buffer
+ *                             (2U int32: smallest forward / reverse position, biased so signed MIN orders them)
+ *   ac_shard_reduce_import    the reduced buffers
+ *   ac_shard_finish           link order, renumber, expand_repeats, final numbering (identical on every rank); the graph
+ *                             handle holds this rank's paths only; want_graph = 0 keeps just the statistics on the host
+ *   [gather]                  ac_shard_paths_export (final numbers) -> the writing rank calls ac_graph_set_paths with the
+ *                             paths of all sequences in rank order
+ * All `d_` pointers are device pointers into caller-owned buffers of the stated sizes. */
+typedef struct ac_shard ac_shard;
+int ac_shard_begin(uint32_t k, uint32_t local_assembly_count, const void* d_text, uint64_t n_text, const uint64_t* seq_off,
+                   const uint32_t* seq_len, const uint16_t* seq_ids, const uint16_t* seq_d1, const uint16_t* seq_d2,
+                   uint32_t n_seqs, int device, ac_shard** out);
+int ac_shard_fragment_sizes(const ac_shard*, uint64_t* text_bytes, uint64_t* n_fragments);
+int ac_shard_fragments_export(ac_shard*, void* d_text_out /* text_bytes */, void* d_meta_out /* 8 * n_fragments */);
+int ac_shard_build_union(ac_shard*, uint32_t n_shards, const void* d_union_text, uint64_t n_union_text, const void* d_meta,
+                         uint64_t n_fragments_total);
+uint32_t ac_shard_unitig_count(const ac_shard*);       /* U: sizes the reduce buffers */
+int ac_shard_reduce_export(ac_shard*, void* d_sum_i32 /* 3U */, void* d_min_i32 /* 2U */);
+int ac_shard_reduce_import(ac_shard*, const void* d_sum_i32, const void* d_min_i32);
+int ac_shard_finish(ac_shard*, int want_graph, ac_graph** out);
+uint64_t ac_shard_path_entries(const ac_shard*);
+int ac_shard_paths_export(ac_shard*, void* d_out_i32 /* ac_shard_path_entries() */);
+void ac_shard_free(ac_shard*);
+/* path_counts[s] = number of path entries of sequence s; d_path_i32 = all entries, concatenated (device). */
+int ac_graph_set_paths(ac_graph*, uint32_t n_seqs_total, const uint16_t* seq_ids, const uint32_t* seq_lens,
+                       const uint64_t* path_counts, const void* d_path_i32, int device);
+uint32_t ac_graph_seq_count(const ac_graph*);
+int ac_path_counts(const ac_graph*, uint64_t* counts /* ac_graph_seq_count() */);   /* path entries per sequence */
 
 /* Host helper: lay sequences out as the text described above.  text must hold ac_text_size() bytes. */
 uint64_t ac_text_size(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs);

@@ -57,11 +57,12 @@ def _place(rng, seq):
     return np.ascontiguousarray(seq)
 
 
-def make_assemblies(n_assemblies, genome=5_000_000, plasmid=100_000, sub=1e-4, indel=1e-5, seed=51_000):
-    """Returns a list of assemblies; each is a list of (header, uint8 array of ACGT bytes)."""
+def make_assemblies(n_assemblies, genome=5_000_000, plasmid=100_000, sub=1e-4, indel=1e-5, seed=51_000, first=0):
+    """Returns a list of assemblies; each is a list of (header, uint8 array of ACGT bytes).  `first`: index of the
+    first assembly to make (assemblies first .. first + n_assemblies - 1 of the same species: one job's slice)."""
     chrom, plas = _root(np.random.default_rng(seed - 1), genome, plasmid)
     out = []
-    for i in range(n_assemblies):
+    for i in range(first, first + n_assemblies):
         rng = np.random.default_rng(seed + i)
         contigs = []
         c = _place(rng, _mutate(rng, chrom, sub, indel))

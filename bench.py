@@ -9,9 +9,11 @@ the timed region (they are upstream of the seam).
 
     python bench.py [--gpus N --steps K --warmup W] [--assemblies 96 --genome 5000000 --kmer 51]
 
-N > 1: launched by torch.distributed.run, one rank per GPU.  The path shards by input assembly: every rank
-builds the graph of its own 96-assembly set (independent compress jobs, weak scaling, no data-path collective);
-RCCL is used only for the barrier / max-over-ranks timing.
+N > 1: launched by torch.distributed.run, one rank per GPU.  Default `--mode sharded`: ONE compress job of
+N x 96 assemblies of the same species, sharded by sequence (rank r holds assemblies 96r .. 96r+95); the ranks
+exchange their novel-run fragments (all-gather), the per-unitig depths / positions (all-reduce) and the paths
+(gather to rank 0) over RCCL — autocycler_amd/sharded.py.  Weak scaling: 96 assemblies per GPU.
+`--mode independent`: every rank builds the graph of its own 96-assembly set (N unrelated jobs, no data-path collective).
 """
 import argparse
 import ctypes as C
@@ -28,15 +30,17 @@ A_K = lambda k: 1 + 2 * (8 * ((2 * k + 63) // 64) + 8)   # algorithmic bytes per
 HBM_PEAK = 8.0e12
 
 
-def make_inputs(args, rank):
+def make_inputs(args, rank, sharded_job):
+    """sharded_job: this rank's slice (assemblies rank*A .. rank*A + A-1) of ONE job; else an unrelated job per rank."""
     import numpy as np
     from autocycler_amd import synth
+    first = rank * args.assemblies if sharded_job else 0
     asm = synth.make_assemblies(args.assemblies, genome=args.genome, plasmid=args.plasmid, sub=args.sub, indel=args.indel,
-                                seed=51_000 + 1000 * rank)
+                                seed=51_000 + (0 if sharded_job else 1000 * rank), first=first)
     seqs, fn, hd = [], [], []
     for i, contigs in enumerate(asm):
         for header, s in contigs:
-            seqs.append(np.ascontiguousarray(s)); fn.append(f"assembly_{i:04d}.fasta"); hd.append(header)
+            seqs.append(np.ascontiguousarray(s)); fn.append(f"assembly_{first + i:04d}.fasta"); hd.append(header)
     return seqs, fn, hd
 
 
@@ -90,6 +94,8 @@ def main():
     ap.add_argument("--kmer", type=int, default=51)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=str, default="4x1000000")
+    ap.add_argument("--mode", choices=["auto", "single", "sharded", "independent"], default="auto",
+                    help="auto: single-device build at N=1, one sharded job at N>1")
     args = ap.parse_args()
 
     import torch
@@ -114,8 +120,13 @@ def main():
     lib.ac_seqs_repair_seconds.restype = C.c_double
     k = args.kmer
 
+    mode = args.mode
+    if mode == "auto":
+        mode = "single" if world == 1 else "sharded"
+    if mode == "single" and world > 1:
+        mode = "independent"
     t0 = time.time()
-    seqs, fn, hd = make_inputs(args, rank)
+    seqs, fn, hd = make_inputs(args, rank, mode == "sharded")
     t_gen = time.time() - t0
     h_seqs = prepare(lib, k, seqs, fn, hd, args.assemblies, threads=os.cpu_count() or 1)
     del seqs
@@ -136,7 +147,24 @@ def main():
     torch.cuda.synchronize()
     t_h2d = time.time() - t1
 
+    shard = None
+    if mode == "sharded":
+        from autocycler_amd import sharded
+        id0 = 0
+        if world > 1:     # job-wide sequence ids: rank order = sequence order
+            counts = torch.zeros(world, dtype=torch.int64, device=dev)
+            counts[rank] = n
+            dist.all_reduce(counts)
+            id0 = int(counts[:rank].sum().item())
+        shard = sharded.LocalShard(k, args.assemblies, d_text, n_text, list(off), list(lens), [id0 + i + 1 for i in range(n)],
+                                   list(d1), list(d2))
+    last_info = {}
+
     def step():
+        if shard is not None:
+            g, info = sharded.sharded_build(lib, shard, sharded.Comm(dev), device_index=local_rank, root=0)
+            last_info.update(info)
+            return g
         h = C.c_void_p()
         rc = lib.ac_compress_build_device(C.c_uint32(k), C.c_uint32(args.assemblies), C.c_void_p(d_text.data_ptr()),
                                           C.c_uint64(n_text), off, lens, ids, d1, d2, C.c_uint32(n), C.c_int(local_rank), C.byref(h))
@@ -191,7 +219,10 @@ def main():
             traffic_src = "profiles/pmc_traffic.json (rocprofv3 PMC passes; FETCH_SIZE x2 per the gfx950 calibration, + WRITE_SIZE)"
         stage = {key: sum(t[key] for t in tms) / len(tms) for key in
                  ("pack", "insert", "collect_sort", "degree", "segment", "minkey", "rank", "links", "paths", "seqs", "analysis", "expand", "finalize", "d2h",
-                  "total_device")}
+                  "total_device") + (("fragments", "union_pack", "union_insert") if mode == "sharded" else ())}
+        sharding = {"single": "one device", "independent": "by assembly set, one unrelated compress job per GPU",
+                    "sharded": "ONE job sharded by sequence: fragments all-gather + per-unitig all-reduce + paths gather "
+                               "(autocycler_amd/sharded.py)"}[mode]
         line = {
             "metric": "Mbp/sec through compress->unitig GFA (k=%d)" % k,
             "value": value, "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -199,7 +230,7 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{args.assemblies} x ~{args.genome / 1e6:g} Mbp synthetic assemblies per GPU (+plasmid {args.plasmid} bp, "
                                    f"sub {args.sub:g}, indel {args.indel:g}), k={k}, 1 species; BASELINE.json configs[2]",
-                       "bases_per_gpu": bases, "sequences_per_gpu": n, "sharding": "by assembly set, one compress job per GPU",
+                       "bases_per_gpu": bases, "sequences_per_gpu": n, "mode": mode, "sharding": sharding,
                        "timed_region": "padded+repaired sequences in HBM -> final unitig graph in host RAM (device build + host tail)"},
             "roofline": {"bound": "hbm", "kernel": "functor_kernel<InsertFunctor<W>> (k-mer table insert)",
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
@@ -212,6 +243,9 @@ def main():
                       "simplify_passes": tms[-1]["simplify_passes"]},
             "prep_s": {"generate": t_gen, "end_repair": t_repair, "h2d": t_h2d, "h2d_GBps": n_text / t_h2d / 1e9},
         }
+        if mode == "sharded":
+            line["sharded"] = {**last_info, "fragments_rank0": tms[-1]["n_fragments"], "fragment_bytes_rank0": tms[-1]["fragment_bytes"],
+                               "local_distinct_rank0": tms[-1]["n_local_distinct"]}
         if not args.no_cpu_baseline and world == 1:
             a, b2 = args.cpu_sample.split("x")
             line["cpu_baseline"] = cpu_baseline(k, int(a), int(b2))

@@ -54,7 +54,7 @@ EXPORTS = ["ac_compress_build", "ac_compress_build_device", "ac_text_size", "ac_
            "ac_path", "ac_timings_get", "ac_free", "ac_gfa_string", "ac_string_free", "ac_last_error",
            "ac_device_count", "ac_max_kmer", "ac_version",
            "ac_shard_begin", "ac_shard_fragment_sizes", "ac_shard_fragments_export", "ac_shard_build_union",
-           "ac_shard_unitig_count", "ac_shard_reduce_export", "ac_shard_reduce_import", "ac_shard_finish",
+           "ac_shard_unitig_count", "ac_shard_distinct_count", "ac_shard_degrees_export", "ac_shard_build_graph", "ac_gfa_string_parts", "ac_shard_reduce_export", "ac_shard_reduce_import", "ac_shard_finish",
            "ac_shard_path_entries", "ac_shard_paths_export", "ac_shard_free", "ac_graph_set_paths", "ac_graph_seq_count", "ac_path_counts",
            "ac_seqs_load", "ac_seqs_from_raw", "ac_seqs_count", "ac_seqs_assembly_count", "ac_seqs_views", "ac_seqs_get",
            "ac_seqs_repair_seconds", "ac_seqs_metrics_yaml", "ac_seqs_free", "ac_compress_seqs", "ac_compress_dir"]
@@ -92,6 +92,8 @@ def load_library(path=None):
     lib.ac_timings_get.argtypes = [C.c_void_p, C.POINTER(Timings)]
     lib.ac_shard_unitig_count.restype = C.c_uint32
     lib.ac_shard_unitig_count.argtypes = [C.c_void_p]
+    lib.ac_shard_distinct_count.restype = C.c_uint64
+    lib.ac_shard_distinct_count.argtypes = [C.c_void_p]
     lib.ac_shard_path_entries.restype = C.c_uint64
     lib.ac_shard_path_entries.argtypes = [C.c_void_p]
     lib.ac_shard_free.argtypes = [C.c_void_p]
@@ -174,12 +176,13 @@ class Graph:
         _check(self._lib, self._lib.ac_timings_get(self._h, C.byref(t)))
         return t.as_dict()
 
-    def gfa(self, filenames, headers):
+    def gfa(self, filenames, headers, parts=3):
+        """parts: bit 0 = H, S, L lines; bit 1 = P lines (of the sequences this handle holds paths for)."""
         n = self.n_seqs
         fn = (C.c_char_p * n)(*[f.encode() for f in filenames])
         hd = (C.c_char_p * n)(*[h.encode() for h in headers])
         out, ln = C.c_void_p(), C.c_uint64()
-        _check(self._lib, self._lib.ac_gfa_string(self._h, fn, hd, C.byref(out), C.byref(ln)))
+        _check(self._lib, self._lib.ac_gfa_string_parts(self._h, C.c_int(parts), fn, hd, C.byref(out), C.byref(ln)))
         s = C.string_at(out.value, ln.value).decode()
         self._lib.ac_string_free(out)
         return s

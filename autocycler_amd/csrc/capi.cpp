@@ -29,7 +29,8 @@ struct ac_graph {
     std::vector<uint16_t> seq_ids;
     std::vector<uint32_t> seq_lens;
     bool positions_built = false;
-    bool host_arrays = true;   // false: a non-writing rank of a sharded build kept only the statistics
+    bool host_arrays = true;   // false: a rank of a sharded build that did not ask for the unitigs / links
+    bool host_paths = true;    // false: ... that did not ask for its paths either
 };
 
 struct ac_seqs {
@@ -209,20 +210,38 @@ int ac_shard_fragments_export(ac_shard* s, void* d_text_out, void* d_meta_out) {
         s->b->fragments_export(d_text_out, d_meta_out);
     });
 }
-int ac_shard_build_union(ac_shard* s, uint32_t n_shards, const void* d_union_text, uint64_t n_union_text, const void* d_meta,
-                         uint64_t n_fragments_total) {
+int ac_shard_build_union(ac_shard* s, uint32_t rank, uint32_t n_shards, const void* d_union_text, uint64_t n_union_text,
+                         const void* d_meta, uint64_t n_fragments_total) {
     return guarded([&] {
         if (s->phase != 1) throw DeviceError("ac_shard_build_union: wrong phase");
         std::lock_guard<std::mutex> lock(g_build_mutex);
         select_device(s->device);
-        s->b->shard_build_union(n_shards, (const uint8_t*)d_union_text, n_union_text, d_meta, n_fragments_total);
+        s->b->shard_build_union(rank, n_shards, (const uint8_t*)d_union_text, n_union_text, d_meta, n_fragments_total);
         s->phase = 2;
+    });
+}
+uint64_t ac_shard_distinct_count(const ac_shard* s) { return s->b->distinct_count(); }
+int ac_shard_degrees_export(ac_shard* s, void* d_out_u32) {
+    return guarded([&] {
+        if (s->phase != 2) throw DeviceError("ac_shard_degrees_export: wrong phase");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->degrees_export(d_out_u32);
+    });
+}
+int ac_shard_build_graph(ac_shard* s, const void* d_degrees_all_u32) {
+    return guarded([&] {
+        if (s->phase != 2) throw DeviceError("ac_shard_build_graph: wrong phase");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->shard_build_graph(d_degrees_all_u32);
+        s->phase = 3;
     });
 }
 uint32_t ac_shard_unitig_count(const ac_shard* s) { return s->b->unitig_count(); }
 int ac_shard_reduce_export(ac_shard* s, void* d_sum_i32, void* d_min_i32) {
     return guarded([&] {
-        if (s->phase != 2) throw DeviceError("ac_shard_reduce_export: wrong phase");
+        if (s->phase != 3) throw DeviceError("ac_shard_reduce_export: wrong phase");
         std::lock_guard<std::mutex> lock(g_build_mutex);
         select_device(s->device);
         s->b->reduce_export((int32_t*)d_sum_i32, (int32_t*)d_min_i32);
@@ -230,32 +249,33 @@ int ac_shard_reduce_export(ac_shard* s, void* d_sum_i32, void* d_min_i32) {
 }
 int ac_shard_reduce_import(ac_shard* s, const void* d_sum_i32, const void* d_min_i32) {
     return guarded([&] {
-        if (s->phase != 2) throw DeviceError("ac_shard_reduce_import: wrong phase");
+        if (s->phase != 3) throw DeviceError("ac_shard_reduce_import: wrong phase");
         std::lock_guard<std::mutex> lock(g_build_mutex);
         select_device(s->device);
         s->b->reduce_import((const int32_t*)d_sum_i32, (const int32_t*)d_min_i32);
-        s->phase = 3;
+        s->phase = 4;
     });
 }
-int ac_shard_finish(ac_shard* s, int want_graph, ac_graph** out) {
+int ac_shard_finish(ac_shard* s, int want, ac_graph** out) {
     return guarded([&] {
-        if (s->phase != 3) throw DeviceError("ac_shard_finish: wrong phase");
+        if (s->phase != 4) throw DeviceError("ac_shard_finish: wrong phase");
         std::lock_guard<std::mutex> lock(g_build_mutex);
         select_device(s->device);
         auto h = std::make_unique<ac_graph>();
         h->seq_ids = s->seq_ids;
         h->seq_lens = s->seq_lens;
-        s->b->shard_finish(&h->g, want_graph != 0);
+        s->b->shard_finish(&h->g, (want & 1) != 0, (want & 2) != 0);
         h->tm = s->b->timings();
-        h->host_arrays = want_graph != 0;
-        s->phase = 4;
+        h->host_arrays = (want & 1) != 0;
+        h->host_paths = (want & 2) != 0;
+        s->phase = 5;
         *out = h.release();
     });
 }
 uint64_t ac_shard_path_entries(const ac_shard* s) { return s->b->path_entry_count(); }
 int ac_shard_paths_export(ac_shard* s, void* d_out_i32) {
     return guarded([&] {
-        if (s->phase != 4) throw DeviceError("ac_shard_paths_export: wrong phase");
+        if (s->phase != 5) throw DeviceError("ac_shard_paths_export: wrong phase");
         std::lock_guard<std::mutex> lock(g_build_mutex);
         select_device(s->device);
         s->b->paths_export(d_out_i32);
@@ -294,6 +314,7 @@ int ac_graph_set_paths(ac_graph* g, uint32_t n_seqs_total, const uint16_t* seq_i
         g->g.path = p;
         g->g.n_path = n;
         g->g.path_off = off;
+        g->host_paths = true;
         g->seq_ids.assign(seq_ids, seq_ids + n_seqs_total);
         g->seq_lens.assign(seq_lens, seq_lens + n_seqs_total);
         g->positions_built = false;
@@ -321,7 +342,7 @@ int ac_unitig(const ac_graph* g, uint32_t idx, const uint8_t** seq, uint32_t* le
 int ac_unitig_positions(ac_graph* g, uint32_t idx, int forward, const ac_position** positions, uint32_t* n) {
     if (idx >= g->g.n_unitigs) { g_err = "unitig index out of range"; return 1; }
     return guarded([&] {
-        if (!g->host_arrays) throw DeviceError("this rank kept no host arrays (sharded build, not the writing rank)");
+        if (!g->host_arrays || !g->host_paths) throw DeviceError("this rank kept no host arrays (sharded build, not the writing rank)");
         if (!g->positions_built) { build_positions(&g->g, g->seq_ids, g->seq_lens); g->positions_built = true; }
         auto& v = forward ? g->g.fwd_positions[idx] : g->g.rev_positions[idx];
         static_assert(sizeof(ac_position) == sizeof(Position), "layout");
@@ -338,7 +359,7 @@ int ac_links(const ac_graph* g, const ac_link** links, uint64_t* n) {
 }
 int ac_path(const ac_graph* g, uint32_t seq_index, const int32_t** signed_unitigs, uint32_t* n) {
     if ((size_t)seq_index + 1 >= g->g.path_off.size()) { g_err = "sequence index out of range"; return 1; }
-    if (!g->host_arrays) { g_err = "this rank kept no host arrays (sharded build, not the writing rank)"; return 1; }
+    if (!g->host_paths) { g_err = "this rank kept no paths on the host (sharded build)"; return 1; }
     uint64_t b = g->g.path_off[seq_index], e = g->g.path_off[seq_index + 1];
     *signed_unitigs = g->g.path + b;
     *n = (uint32_t)(e - b);
@@ -360,18 +381,27 @@ int ac_timings_get(const ac_graph* g, ac_timings* o) {
 }
 void ac_free(ac_graph* g) { delete g; }
 
-int ac_gfa_string(const ac_graph* g, const char* const* filenames, const char* const* headers, char** out, uint64_t* out_len) {
+static int gfa_parts_impl(const ac_graph* g, int parts, const char* const* filenames, const char* const* headers, char** out,
+                          uint64_t* out_len) {
     return guarded([&] {
-        if (!g->host_arrays) throw DeviceError("this rank kept no host arrays (sharded build, not the writing rank)");
+        if ((parts & 1) && !g->host_arrays) throw DeviceError("this rank kept no unitigs / links on the host (sharded build)");
+        if ((parts & 2) && !g->host_paths) throw DeviceError("this rank kept no paths on the host (sharded build)");
         std::vector<SeqMeta> meta(g->seq_ids.size());
         for (size_t i = 0; i < meta.size(); i++) meta[i] = SeqMeta{g->seq_ids[i], g->seq_lens[i], filenames[i], headers[i]};
-        std::string s = gfa_string(g->g, meta);
+        std::string s = gfa_string(g->g, meta, parts);
         char* p = (char*)malloc(s.size() + 1);
         if (!p) throw DeviceError("out of memory");
         memcpy(p, s.data(), s.size()); p[s.size()] = 0;
         *out = p;
         if (out_len) *out_len = s.size();
     });
+}
+int ac_gfa_string(const ac_graph* g, const char* const* filenames, const char* const* headers, char** out, uint64_t* out_len) {
+    return gfa_parts_impl(g, 3, filenames, headers, out, out_len);
+}
+int ac_gfa_string_parts(const ac_graph* g, int parts, const char* const* filenames, const char* const* headers, char** out,
+                        uint64_t* out_len) {
+    return gfa_parts_impl(g, parts, filenames, headers, out, out_len);
 }
 void ac_string_free(char* p) { free(p); }
 
@@ -454,7 +484,7 @@ int ac_compress_dir(const char* assemblies_dir, const char* autocycler_dir, uint
         std::vector<SeqMeta> meta(s.lr.seqs.size());
         for (size_t i = 0; i < meta.size(); i++) meta[i] = SeqMeta{s.lr.seqs[i].id, s.lr.seqs[i].length, s.lr.seqs[i].filename, s.lr.seqs[i].contig_header};
         {
-            std::string gfa = gfa_string(g->g, meta);
+            std::string gfa = gfa_string(g->g, meta, 3);
             std::ofstream f(fs::path(autocycler_dir) / "input_assemblies.gfa", std::ios::binary);
             f.write(gfa.data(), (std::streamsize)gfa.size());
             if (!f) throw UserError("failed to write input_assemblies.gfa");

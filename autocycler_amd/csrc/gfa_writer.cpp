@@ -11,12 +11,13 @@ static inline void put_u64(std::string& s, uint64_t v) {
     while (n) s.push_back(buf[--n]);
 }
 
-std::string gfa_string(const FinalGraph& g, const std::vector<SeqMeta>& seqs) {
+std::string gfa_string(const FinalGraph& g, const std::vector<SeqMeta>& seqs, int parts) {
     std::string out;
     size_t est = 64;
-    est += g.post.total_length + (size_t)g.n_unitigs * 32;
-    est += g.n_links * 32 + g.n_path * 10 + seqs.size() * 256;
+    if (parts & 1) est += g.post.total_length + (size_t)g.n_unitigs * 32 + g.n_links * 32;
+    if (parts & 2) est += g.n_path * 10 + seqs.size() * 256;
     out.reserve(est);
+    if (parts & 1) {
     out += "H\tVN:Z:1.0\tKM:i:"; put_u64(out, g.k); out.push_back('\n');
     for (uint32_t i = 0; i < g.n_unitigs; i++) {
         out += "S\t"; put_u64(out, (uint64_t)i + 1); out.push_back('\t'); out.append(g.seq(i), g.seq_len[i]); out += "\tDP:f:";
@@ -28,6 +29,8 @@ std::string gfa_string(const FinalGraph& g, const std::vector<SeqMeta>& seqs) {
         out += "L\t"; put_u64(out, l.a); out += l.a_fwd ? "\t+\t" : "\t-\t"; put_u64(out, l.b);
         out += l.b_fwd ? "\t+\t0M\n" : "\t-\t0M\n";
     }
+    }
+    if (parts & 2)
     for (size_t s = 0; s < seqs.size(); s++) {
         out += "P\t"; put_u64(out, seqs[s].id); out.push_back('\t');
         for (uint64_t i = g.path_off[s]; i < g.path_off[s + 1]; i++) {

@@ -8,5 +8,6 @@
 
 namespace ac {
 struct SeqMeta { uint16_t id; uint32_t length; std::string filename; std::string contig_header; };
-std::string gfa_string(const FinalGraph& g, const std::vector<SeqMeta>& seqs);
+// parts: bit 0 = H, S and L lines, bit 1 = P lines (a sharded build can keep the P lines of each rank's sequences on that rank)
+std::string gfa_string(const FinalGraph& g, const std::vector<SeqMeta>& seqs, int parts = 3);
 }  // namespace ac

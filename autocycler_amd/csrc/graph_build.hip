@@ -300,8 +300,9 @@ template <int W> AC_D int count_successors(const TextCtx& t, const Table& tb, co
     return n;
 }
 template <int W> struct DegreeFunctor {
-    TextCtx t; Table tb; const u64* npos; u32* kinfo; int any_dots;
+    TextCtx t; Table tb; const u64* npos; u32* kinfo; int any_dots; u64 first;   // handles novel indices first, first+1, ...
     AC_D void operator()(u64 i) const {
+        i += first;
         XKmer<W> x;
         u64 p = npos[i];
         int known_out = -1, known_in = -1;
@@ -1092,9 +1093,12 @@ struct GraphBuilder::Impl {
     template <int W> void insert(const PackedText& t, u32 hint, DBuf<u64>* slots_out, u64* cap_out, u64* n_distinct_out);
     void novel_bitmap(const PackedText& t, const DBuf<u64>& sl, u64 c, DBuf<u64>* bm_out);
     template <int W> void fragments();
-    template <int W> void graph();
+    template <int W> void table();                      // K2, K3 on G
+    template <int W> void degrees(u64 lo, u64 hi);      // K5 for novel indices [lo, hi)
+    template <int W> void unitigs();                    // K6..K11 on G
     template <int W> void walk();
-    template <int W> void tail(FinalGraph* out, bool want_host);
+    template <int W> void tail(FinalGraph* out, bool want_graph, bool want_paths);
+    u64 deg_lo = 0, deg_hi = 0;
 };
 
 // K2 insert.  Capacity from the reference's own capacity hint (assembly_count, kmer_graph.rs:40): similar assemblies
@@ -1201,15 +1205,13 @@ template <int W> void GraphBuilder::Impl::fragments() {
     lap(&tm->fragments);
 }
 
-// K2..K11 on the graph text G: k-mer table, novel list, degrees, unitigs in seed order, links by successor symbol.
-template <int W> void GraphBuilder::Impl::graph() {
+// K2, K3 on the graph text G: k-mer table and sorted novel list.
+template <int W> void GraphBuilder::Impl::table() {
     PackedText& g = *G;
     check_sizes(g);
-    TextCtx t = g.ctx((int)k);
     insert<W>(g, tm->graph_hint, &slots, &cap, &N);
     tm->table_capacity = cap;
     tm->n_distinct = N;
-    Table tb{slots.ptr(), cap - 1};
     lap(G == &loc ? &tm->insert : &tm->union_insert);
 
     // K3 novel-position bitmap -> sorted novel list + rank support
@@ -1221,12 +1223,25 @@ template <int W> void GraphBuilder::Impl::graph() {
     exclusive_scan_u32(wcnt.ptr(), wprefix.ptr(), n_bm_words);
     npos.alloc(N);
     launch(n_bm_words, FillNovelFunctor{bm.ptr(), wprefix.ptr(), npos.ptr()});
-    Novel nv{bm.ptr(), wprefix.ptr()};
-    lap(&tm->collect_sort);
-
-    // K5/K6 degrees + first flags
     kinfo.alloc(N, true);
-    launch(N, DegreeFunctor<W>{t, tb, npos.ptr(), kinfo.ptr(), g.any_dots});
+    lap(&tm->collect_sort);
+}
+
+// K5 out/in degrees of the novel k-mers [lo, hi) (a sharded build computes one slice per rank and all-gathers them).
+template <int W> void GraphBuilder::Impl::degrees(u64 lo, u64 hi) {
+    PackedText& g = *G;
+    Table tb{slots.ptr(), cap - 1};
+    deg_lo = lo; deg_hi = hi;
+    launch(hi - lo, DegreeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kinfo.ptr(), g.any_dots, lo});
+    lap(&tm->degree);
+}
+
+// K6..K11 on G: first flags, unitigs in seed order, links by successor symbol.
+template <int W> void GraphBuilder::Impl::unitigs() {
+    PackedText& g = *G;
+    TextCtx t = g.ctx((int)k);
+    Table tb{slots.ptr(), cap - 1};
+    Novel nv{bm.ptr(), wprefix.ptr()};
     launch(g.n_seqs, FirstFunctor<W>{t, tb, nv, kinfo.ptr(), g.has_flags ? g.seq_flags.ptr() : nullptr});
     lap(&tm->degree);
 
@@ -1295,7 +1310,7 @@ template <int W> void GraphBuilder::Impl::walk() {
 
 // K12..K17 + D2H: sequences, link push order, expand_repeats, both renumberings, final numbering.  Needs depth,
 // min positions and path ends of ALL sequences (reduced over ranks first in a sharded build).
-template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_host) {
+template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph, bool want_paths) {
     PackedText& g = *G;
     const u32 n_seqs = loc.n_seqs;
     // K12 sequences
@@ -1405,14 +1420,16 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_host) 
     out->k = k;
     out->n_kmers = 2 * (u64)N;
     out->n_unitigs = U;
-    if (want_host) {
+    if (want_graph) {
         out->seq_block = PinnedPool::get().alloc(final_total);
         out->meta_block = PinnedPool::get().alloc((size_t)U * 20);
         out->links_block = PinnedPool::get().alloc(n_links * sizeof(Link));
-        out->path_block = PinnedPool::get().alloc(n_ent * 4);
         copy_d2h_async(out->seq_block.p, cur, final_total);
         copy_d2h_async(out->meta_block.p, meta.ptr(), (size_t)U * 20);
         copy_d2h_async(out->links_block.p, links_out.ptr(), n_links * sizeof(Link));
+    }
+    if (want_paths) {
+        out->path_block = PinnedPool::get().alloc(n_ent * 4);
         copy_d2h_async(out->path_block.p, ent_val.ptr(), n_ent * 4);
     }
     std::vector<u64> h_sums = to_host(sums, n_seqs);
@@ -1420,13 +1437,13 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_host) 
     std::vector<u32> errs = to_host(counters, 8);   // synchronises the stream: everything above has landed
     if (errs[3] || errs[4])
         throw DeviceError("internal error: inconsistent unitig ends (codes " + std::to_string(errs[3]) + "/" + std::to_string(errs[4]) + ")");
-    if (want_host) {
+    if (want_graph) {
         out->seq_begin = (const u64*)out->meta_block.p;
         out->depth = (const double*)((const u8*)out->meta_block.p + (size_t)U * 8);
         out->seq_len = (const u32*)((const u8*)out->meta_block.p + (size_t)U * 16);
         out->links = (const Link*)out->links_block.p;
-        out->path = (const int32_t*)out->path_block.p;
     }
+    if (want_paths) out->path = (const int32_t*)out->path_block.p;
     out->n_links = n_links;
     out->n_path = n_ent;
     u64 n_self = errs[5];
@@ -1497,9 +1514,11 @@ void GraphBuilder::build(uint32_t assembly_count_hint, FinalGraph* out) {
     m.check_sizes(m.loc);
     m.loc.pack();
     m.lap(&tm_.pack);
-    AC_DISPATCH_W(graph, ())
+    AC_DISPATCH_W(table, ())
+    AC_DISPATCH_W(degrees, (0, m.N))
+    AC_DISPATCH_W(unitigs, ())
     AC_DISPATCH_W(walk, ())
-    AC_DISPATCH_W(tail, (out, true))
+    AC_DISPATCH_W(tail, (out, true, true))
 }
 
 // ---- sharded build (one compress job over several devices; the collectives between the phases belong to the
@@ -1523,8 +1542,9 @@ void GraphBuilder::fragments_export(void* d_text_out, void* d_meta_out) {
     copy_d2d(d_meta_out, impl_->frag_meta.ptr(), impl_->n_frags * 8);
     stream_sync();
 }
-void GraphBuilder::shard_build_union(uint32_t n_shards, const uint8_t* d_union_text, uint64_t n_union_text, const void* d_meta,
-                                     uint64_t n_frags_total) {
+void GraphBuilder::shard_build_union(uint32_t rank, uint32_t n_shards, const uint8_t* d_union_text, uint64_t n_union_text,
+                                     const void* d_meta, uint64_t n_frags_total) {
+    if (n_shards == 0 || rank >= n_shards) throw DeviceError("invalid rank / shard count");
     Impl& m = *impl_;
     m.t0 = now_s();
     if (n_frags_total == 0 || n_frags_total >= 0xFFFFFFF0ULL) throw DeviceError("invalid fragment count");
@@ -1548,7 +1568,24 @@ void GraphBuilder::shard_build_union(uint32_t n_shards, const uint8_t* d_union_t
     tm_.graph_hint = n_shards;
     m.uni.pack();
     m.lap(&tm_.union_pack);
-    AC_DISPATCH_W(graph, ())
+    AC_DISPATCH_W(table, ())
+    // this rank's slice of the degree computation (the one kernel of the graph stage that is both heavy and
+    // embarrassingly parallel over distinct k-mers); the caller all-gathers the slices
+    u64 lo = m.N * rank / n_shards, hi = m.N * (rank + 1) / n_shards;
+    AC_DISPATCH_W(degrees, (lo, hi))
+}
+uint64_t GraphBuilder::distinct_count() const { return impl_->N; }
+void GraphBuilder::degrees_export(void* d_out) {
+    Impl& m = *impl_;
+    copy_d2d(d_out, m.kinfo.ptr() + m.deg_lo, (m.deg_hi - m.deg_lo) * 4);
+    stream_sync();
+}
+void GraphBuilder::shard_build_graph(const void* d_kinfo_all) {
+    Impl& m = *impl_;
+    m.t0 = now_s();
+    if (d_kinfo_all) copy_d2d(m.kinfo.ptr(), d_kinfo_all, m.N * 4);
+    else if (!(m.deg_lo == 0 && m.deg_hi == m.N)) throw DeviceError("degree slices of the other ranks are missing");
+    AC_DISPATCH_W(unitigs, ())
     AC_DISPATCH_W(walk, ())
 }
 uint32_t GraphBuilder::unitig_count() const { return impl_->U; }
@@ -1563,9 +1600,9 @@ void GraphBuilder::reduce_import(const int32_t* d_sum, const int32_t* d_min) {
     launch(m.U, ReduceImportFunctor{m.depth.ptr(), m.fs0.ptr(), m.fe0.ptr(), m.minpos_fwd.ptr(), m.minpos_rev.ptr(), m.U, d_sum, d_min});
     stream_sync();
 }
-void GraphBuilder::shard_finish(FinalGraph* out, bool want_host) {
+void GraphBuilder::shard_finish(FinalGraph* out, bool want_graph, bool want_paths) {
     impl_->t0 = now_s();
-    AC_DISPATCH_W(tail, (out, want_host))
+    AC_DISPATCH_W(tail, (out, want_graph, want_paths))
 }
 uint64_t GraphBuilder::path_entry_count() const { return impl_->n_ent; }
 void GraphBuilder::paths_export(void* d_out) {

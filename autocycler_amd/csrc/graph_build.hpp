@@ -60,20 +60,26 @@ class GraphBuilder {
     // set_sequences_host as usual; the collectives between the phases are the caller's (torch.distributed / RCCL).
     //   1. shard_begin: pack + insert this rank's sequences, cut its novel runs out as "fragments".
     //      -> all-gather the fragment texts and meta records of all ranks (rank order).
-    //   2. shard_build_union: build the global graph from the union text ('$' + all fragment texts), then walk this
-    //      rank's sequences through it.  -> all-reduce (SUM / MIN) the per-unitig buffers of reduce_export.
-    //   3. reduce_import + shard_finish: the order-sensitive tail (identical on every rank); paths of this rank's
-    //      sequences in final numbers.  -> gather the paths (paths_export) to the rank that writes the GFA.
+    //   2. shard_build_union: k-mer table + novel list of the union text ('$' + all fragment texts), identical on
+    //      every rank, and the out/in degrees of this rank's slice of the novel list.
+    //      -> all-gather the degree slices (degrees_export, 4 bytes per distinct k-mer).
+    //   3. shard_build_graph: unitigs in seed order + links (identical on every rank), then the walk of this rank's
+    //      sequences through them.  -> all-reduce (SUM / MIN) the per-unitig buffers of reduce_export.
+    //   4. reduce_import + shard_finish: the order-sensitive tail (identical on every rank); paths of this rank's
+    //      sequences in final numbers (kept per rank, or gathered with paths_export to the rank that writes the GFA).
     void shard_begin(uint32_t local_assembly_hint);
     uint64_t fragment_text_bytes() const;
     uint64_t fragment_count() const;
     void fragments_export(void* d_text_out, void* d_meta_out);      // device buffers: text bytes, 8 bytes per fragment
-    void shard_build_union(uint32_t n_shards, const uint8_t* d_union_text, uint64_t n_union_text, const void* d_meta,
-                           uint64_t n_frags_total);
+    void shard_build_union(uint32_t rank, uint32_t n_shards, const uint8_t* d_union_text, uint64_t n_union_text,
+                           const void* d_meta, uint64_t n_frags_total);
+    uint64_t distinct_count() const;                                // N: novel indices [N*r/G, N*(r+1)/G) belong to rank r
+    void degrees_export(void* d_out);                               // this rank's slice, u32 per k-mer
+    void shard_build_graph(const void* d_kinfo_all);                // N u32 (nullptr: single rank, nothing to import)
     uint32_t unitig_count() const;
     void reduce_export(int32_t* d_sum, int32_t* d_min);             // 3U and 2U int32
     void reduce_import(const int32_t* d_sum, const int32_t* d_min);
-    void shard_finish(FinalGraph* out, bool want_host);
+    void shard_finish(FinalGraph* out, bool want_graph, bool want_paths);
     uint64_t path_entry_count() const;
     void paths_export(void* d_out);                                 // int32 per entry, final numbers
     const BuildTimings& timings() const { return tm_; }

@@ -7,10 +7,13 @@ the GPU box, "gloo" in the CPU test-suite):
 
     ac_shard_begin          local k-mer insert -> this rank's novel runs ("fragments")
       all-gather            fragment text + 8-byte records of every rank           (∝ distinct content, not ∝ input)
-    ac_shard_build_union    identical global graph on every rank, then the paths of the local sequences
+    ac_shard_build_union    identical k-mer table / novel list on every rank; degrees of this rank's slice of it
+      all-gather            degree slices                                           (4 B per distinct k-mer)
+    ac_shard_build_graph    identical unitigs + links on every rank, then the paths of the local sequences
       all-reduce SUM, MIN   per-unitig depth / path-end counts, smallest positions  (5 x U int32)
     ac_shard_finish         order-sensitive tail (identical on every rank)
-      gather to root        paths of all sequences in final numbers -> the rank that writes the GFA
+      [gather to root]      optional: paths of all sequences in final numbers -> one rank holds the whole GFA;
+                            by default every rank keeps the P lines of its own sequences (Graph.gfa(parts=2))
 
 Nothing here computes: without the library the calls raise HipLibraryMissing."""
 import ctypes as C
@@ -121,9 +124,11 @@ def _check(lib, rc):
         raise _capi.AutocyclerError(lib.ac_last_error().decode(errors="replace"))
 
 
-def sharded_build(lib, shard, comm, device_index=0, root=0):
-    """Runs one sharded compress build.  Returns (Graph, info): on `root` the Graph holds the whole result (all
-    paths, ready for Graph.gfa); on the other ranks it holds the statistics only."""
+def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False):
+    """Runs one sharded compress build.  Returns (Graph, info).  On `root` the Graph holds unitigs, links and
+    statistics; every rank's Graph holds the paths of its own sequences (Graph.gfa(parts=2) -> its P lines), unless
+    gather_paths: then root's Graph holds the paths of ALL sequences (Graph.gfa() is the whole file) and the other
+    ranks keep statistics only."""
     dev = comm.device
     h = C.c_void_p()
     _check(lib, lib.ac_shard_begin(C.c_uint32(shard.k), C.c_uint32(shard.local_assembly_count), C.c_void_p(shard.d_text.data_ptr()),
@@ -142,11 +147,22 @@ def sharded_build(lib, shard, comm, device_index=0, root=0):
         nb_total = 1 + sum(b for _, b in sizes)
         dollar = torch.full((1,), ord("$"), dtype=torch.uint8, device=dev)
         union = torch.cat([dollar] + [p[8 * f:] for p, (f, _) in zip(parts, sizes)])
-        # 8-byte alignment of the records: build them in their own tensor
-        meta = torch.cat([p[:8 * f] for p, (f, _) in zip(parts, sizes)]).contiguous()
-        _check(lib, lib.ac_shard_build_union(h, C.c_uint32(comm.world), C.c_void_p(union.data_ptr()), C.c_uint64(nb_total),
-                                             C.c_void_p(meta.data_ptr()), C.c_uint64(nf_total)))
+        meta = torch.cat([p[:8 * f] for p, (f, _) in zip(parts, sizes)]).contiguous()    # own tensor: 8-byte aligned
+        _check(lib, lib.ac_shard_build_union(h, C.c_uint32(comm.rank), C.c_uint32(comm.world), C.c_void_p(union.data_ptr()),
+                                             C.c_uint64(nb_total), C.c_void_p(meta.data_ptr()), C.c_uint64(nf_total)))
         del parts, mine
+        # degree slices of all ranks
+        N = lib.ac_shard_distinct_count(h)
+        if comm.world > 1:
+            bounds = [N * r // comm.world for r in range(comm.world + 1)]
+            dsz = [bounds[r + 1] - bounds[r] for r in range(comm.world)]
+            dmine = torch.empty(max(dsz[comm.rank], 1), dtype=torch.int32, device=dev)
+            _check(lib, lib.ac_shard_degrees_export(h, C.c_void_p(dmine.data_ptr())))
+            dall = torch.cat(comm.all_gather_padded(dmine, dsz)).contiguous()
+            _check(lib, lib.ac_shard_build_graph(h, C.c_void_p(dall.data_ptr())))
+            del dall, dmine
+        else:
+            _check(lib, lib.ac_shard_build_graph(h, None))
         # per-unitig quantities over all sequences
         U = lib.ac_shard_unitig_count(h)
         red = torch.empty(5 * U, dtype=torch.int32, device=dev)
@@ -155,10 +171,11 @@ def sharded_build(lib, shard, comm, device_index=0, root=0):
         comm.all_reduce(red[3 * U:], "MIN")
         _check(lib, lib.ac_shard_reduce_import(h, C.c_void_p(red.data_ptr()), C.c_void_p(red.data_ptr() + 12 * U)))
         g = C.c_void_p()
-        _check(lib, lib.ac_shard_finish(h, C.c_int(1 if comm.rank == root else 0), C.byref(g)))
+        is_root = comm.rank == root
+        want = (1 if is_root else 0) | (0 if (gather_paths and comm.world > 1) else 2)
+        _check(lib, lib.ac_shard_finish(h, C.c_int(want), C.byref(g)))
         graph = _capi.Graph(lib, g, shard.n_seqs)
-        # paths of all sequences -> root
-        if comm.world > 1:
+        if gather_paths and comm.world > 1:      # paths of all sequences -> root
             ne = lib.ac_shard_path_entries(h)
             psz = comm.all_gather_sizes([ne, shard.n_seqs])
             ent = torch.empty(max(ne, 1), dtype=torch.int32, device=dev)
@@ -168,7 +185,7 @@ def sharded_build(lib, shard, comm, device_index=0, root=0):
                                 device=dev).reshape(-1)
             infos = comm.gather_padded(info, [3 * s for _, s in psz], root)
             ents = comm.gather_padded(ent, [e for e, _ in psz], root)
-            if comm.rank == root:
+            if is_root:
                 all_info = torch.cat(infos).cpu().view(-1, 3)
                 n_total = all_info.shape[0]
                 all_ent = torch.cat(ents).contiguous()
@@ -178,6 +195,6 @@ def sharded_build(lib, shard, comm, device_index=0, root=0):
                 _check(lib, lib.ac_graph_set_paths(g, C.c_uint32(n_total), ids, lens, cnts, C.c_void_p(all_ent.data_ptr()),
                                                    C.c_int(device_index)))
                 graph.n_seqs = n_total
-        return graph, {"fragments": nf_total, "union_text_bytes": nb_total, "unitigs": U, "comm_s": comm.seconds}
+        return graph, {"fragments": nf_total, "union_text_bytes": nb_total, "distinct": N, "unitigs": U, "comm_s": comm.seconds}
     finally:
         lib.ac_shard_free(h)

@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--cpu-sample", type=str, default="4x1000000")
     ap.add_argument("--mode", choices=["auto", "single", "sharded", "independent"], default="auto",
                     help="auto: single-device build at N=1, one sharded job at N>1")
+    ap.add_argument("--gather-paths", action="store_true",
+                    help="sharded mode: gather the paths of all sequences to rank 0 (default: every rank keeps its own P lines)")
     args = ap.parse_args()
 
     import torch
@@ -162,7 +164,8 @@ def main():
 
     def step():
         if shard is not None:
-            g, info = sharded.sharded_build(lib, shard, sharded.Comm(dev), device_index=local_rank, root=0)
+            g, info = sharded.sharded_build(lib, shard, sharded.Comm(dev), device_index=local_rank, root=0,
+                                            gather_paths=args.gather_paths)
             last_info.update(info)
             return g
         h = C.c_void_p()
@@ -221,8 +224,10 @@ def main():
                  ("pack", "insert", "collect_sort", "degree", "segment", "minkey", "rank", "links", "paths", "seqs", "analysis", "expand", "finalize", "d2h",
                   "total_device") + (("fragments", "union_pack", "union_insert") if mode == "sharded" else ())}
         sharding = {"single": "one device", "independent": "by assembly set, one unrelated compress job per GPU",
-                    "sharded": "ONE job sharded by sequence: fragments all-gather + per-unitig all-reduce + paths gather "
-                               "(autocycler_amd/sharded.py)"}[mode]
+                    "sharded": "ONE job sharded by sequence over the ranks: all-gather of novel-run fragments and of degree slices, "
+                               "per-unitig all-reduce; unitigs + links end in rank 0's host RAM, the paths (P lines) " +
+                               ("of all sequences too (gathered)" if args.gather_paths else "of each rank's sequences in that rank's host RAM") +
+                               " (autocycler_amd/sharded.py)"}[mode]
         line = {
             "metric": "Mbp/sec through compress->unitig GFA (k=%d)" % k,
             "value": value, "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

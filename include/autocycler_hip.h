@@ -85,13 +85,18 @@ int ac_compress_build_device(uint32_t k, uint32_t assembly_count, const void* d_
  *                             carry first_position, kmer_graph.rs:57-60)
  *   [all-gather]              fragment texts and 8-byte meta records of all ranks, concatenated in rank order;
  *                             union text = '$' + the concatenated fragment texts
- *   ac_shard_build_union      global k-mer set, unitigs in seed order and links from the union text — identical on every
- *                             rank — then the paths of this rank's sequences through it
+ *   ac_shard_build_union      global k-mer table + sorted novel list from the union text — identical on every rank — and
+ *                             next_kmers / prev_kmers counts (kmer_graph.rs:136-166) for this rank's slice of it:
+ *                             novel indices [N*rank/n_shards, N*(rank+1)/n_shards), N = ac_shard_distinct_count()
+ *   [all-gather]              ac_shard_degrees_export -> the N u32 of all ranks, rank order
+ *   ac_shard_build_graph      unitigs in seed order + links (identical on every rank), then the paths of this rank's
+ *                             sequences through them (d_degrees_all = NULL when n_shards == 1)
  *   [all-reduce SUM, MIN]     ac_shard_reduce_export -> sum buffer (3U int32: depth, path starts, path ends) and min buffer
  *                             (2U int32: smallest forward / reverse position, biased so signed MIN orders them)
  *   ac_shard_reduce_import    the reduced buffers
- *   ac_shard_finish           link order, renumber, expand_repeats, final numbering (identical on every rank); the graph
- *                             handle holds this rank's paths only; want_graph = 0 keeps just the statistics on the host
+ *   ac_shard_finish           link order, renumber, expand_repeats, final numbering (identical on every rank).  want: bit 0 =
+ *                             unitigs + links to host memory, bit 1 = this rank's paths to host memory.  Either every rank
+ *                             keeps the P lines of its own sequences (ac_gfa_string_parts), or:
  *   [gather]                  ac_shard_paths_export (final numbers) -> the writing rank calls ac_graph_set_paths with the
  *                             paths of all sequences in rank order
  * All `d_` pointers are device pointers into caller-owned buffers of the stated sizes. */
@@ -101,12 +106,15 @@ int ac_shard_begin(uint32_t k, uint32_t local_assembly_count, const void* d_text
                    uint32_t n_seqs, int device, ac_shard** out);
 int ac_shard_fragment_sizes(const ac_shard*, uint64_t* text_bytes, uint64_t* n_fragments);
 int ac_shard_fragments_export(ac_shard*, void* d_text_out /* text_bytes */, void* d_meta_out /* 8 * n_fragments */);
-int ac_shard_build_union(ac_shard*, uint32_t n_shards, const void* d_union_text, uint64_t n_union_text, const void* d_meta,
-                         uint64_t n_fragments_total);
+int ac_shard_build_union(ac_shard*, uint32_t rank, uint32_t n_shards, const void* d_union_text, uint64_t n_union_text,
+                         const void* d_meta, uint64_t n_fragments_total);
+uint64_t ac_shard_distinct_count(const ac_shard*);     /* N: distinct canonical k-mers of the whole job */
+int ac_shard_degrees_export(ac_shard*, void* d_out_u32 /* this rank's slice */);
+int ac_shard_build_graph(ac_shard*, const void* d_degrees_all_u32 /* N, or NULL */);
 uint32_t ac_shard_unitig_count(const ac_shard*);       /* U: sizes the reduce buffers */
 int ac_shard_reduce_export(ac_shard*, void* d_sum_i32 /* 3U */, void* d_min_i32 /* 2U */);
 int ac_shard_reduce_import(ac_shard*, const void* d_sum_i32, const void* d_min_i32);
-int ac_shard_finish(ac_shard*, int want_graph, ac_graph** out);
+int ac_shard_finish(ac_shard*, int want, ac_graph** out);
 uint64_t ac_shard_path_entries(const ac_shard*);
 int ac_shard_paths_export(ac_shard*, void* d_out_i32 /* ac_shard_path_entries() */);
 void ac_shard_free(ac_shard*);
@@ -139,6 +147,9 @@ void ac_free(ac_graph*);
  * Sequence::filename / contig_header per input sequence (FN:Z / HD:Z tags).  Free with ac_string_free. */
 int ac_gfa_string(const ac_graph*, const char* const* filenames, const char* const* headers, char** out,
                   uint64_t* out_len);
+/* parts: bit 0 = H, S and L lines, bit 1 = P lines (of the sequences this handle holds paths for). */
+int ac_gfa_string_parts(const ac_graph*, int parts, const char* const* filenames, const char* const* headers, char** out,
+                        uint64_t* out_len);
 void ac_string_free(char*);
 
 /* ---- host side around the hot path ("boundary" and "next" rows of SURVEY.md §8) -------------------------------

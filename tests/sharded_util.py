@@ -34,8 +34,9 @@ def local_shard(lib, k, loaded, lo, hi, assembly_count, device):
                               [q["id"] for q in part], list(d1), list(d2))
 
 
-def run_case(lib_path, k, seqs, filenames, headers, comm, device, repair=True, device_index=0):
-    """All ranks call this with the same inputs.  Returns the GFA text on the root, None elsewhere."""
+def run_case(lib_path, k, seqs, filenames, headers, comm, device, repair=True, device_index=0, gather_paths=True):
+    """All ranks call this with the same inputs.  Returns the whole GFA text on the root, None elsewhere.
+    gather_paths=False: every rank keeps the P lines of its own sequences; the test stitches the parts together."""
     lib = _capi.load_library(lib_path)
     s = O.Seqs.from_raw(k, seqs, filenames=filenames, headers=headers, repair=repair)
     loaded = s.all()
@@ -44,12 +45,21 @@ def run_case(lib_path, k, seqs, filenames, headers, comm, device, repair=True, d
     assert hi > lo, "fewer sequences than ranks"
     local_assemblies = max(1, len({q["filename"] for q in loaded[lo:hi]}))
     shard = local_shard(lib, k, loaded, lo, hi, local_assemblies, device)
-    g, info = sharded.sharded_build(lib, shard, comm, device_index=device_index, root=0)
-    if comm.rank != 0:
-        assert g.stats_post["unitigs"] == info["unitigs"]
-        return None
+    g, info = sharded.sharded_build(lib, shard, comm, device_index=device_index, root=0, gather_paths=gather_paths)
+    assert g.stats_post["unitigs"] == info["unitigs"]
+    if gather_paths or comm.world == 1:
+        if comm.rank != 0:
+            return None
+        gfa_g = g.gfa([q["filename"] for q in loaded], [q["header"] for q in loaded])
+    else:
+        mine = loaded[lo:hi]
+        part = g.gfa([q["filename"] for q in mine], [q["header"] for q in mine], parts=3 if comm.rank == 0 else 2)
+        parts = [None] * comm.world
+        comm.dist.all_gather_object(parts, part)
+        if comm.rank != 0:
+            return None
+        gfa_g = "".join(parts)
     gfa_o, st, _ = s.compress(k)
-    gfa_g = g.gfa([q["filename"] for q in loaded], [q["header"] for q in loaded])
     assert g.kmer_count == st["kmers"]
     assert g.stats_pre == dict(unitigs=st["unitigs_pre"], links=st["links_pre"], total_length=st["length_pre"])
     assert g.stats_post == dict(unitigs=st["unitigs_post"], links=st["links_post"], total_length=st["length_post"])

@@ -37,9 +37,10 @@ def main():
             seqs, fn, hd = seqgen.make_case(seed, k)
         if len(seqs) < world:
             continue
-        for repair in (True, False):
+        for repair, gather in ((True, True), (False, False)):
             comm = sharded.Comm(dev)
-            sharded_util.run_case(lib_path, k, seqs, fn, hd, comm, dev, repair=repair, device_index=dev.index or 0)
+            sharded_util.run_case(lib_path, k, seqs, fn, hd, comm, dev, repair=repair, device_index=dev.index or 0,
+                                  gather_paths=gather)
         done += 1
     dist.barrier()
     dist.destroy_process_group()

@@ -258,6 +258,134 @@ template <int W> struct InsertFunctor {
     }
 };
 
+// ---- K2w: the same insert, one WAVEFRONT per chunk ---------------------------------------------------------------
+// The thread-per-chunk kernel above follows runs with one lane reading two private streams: every 8-byte load is its
+// own memory transaction (PMC: 4.8 GB for 0.37 GB of packed text).  Here the 64 lanes of a wavefront share one chunk:
+//   A. lanes insert positions p .. p+63 for real (one k-mer each: hash, probe, CAS / atomicMin);
+//   B. if any lane met an EARLIER occurrence q of its k-mer, the run is followed from the last such lane: lane i
+//      compares the 32-base word at offset 32 i of the text after p with the word the earlier occurrence continues
+//      with (or its reverse-complement view) — 2048 positions per step from two coalesced 512-byte reads — and a
+//      ballot finds the first disagreement.  Every position inside the verified run is an occurrence of a k-mer
+//      that has an earlier occurrence, so it needs no table access (same argument as above).
+// The table ends in the same state: every canonical k-mer's slot holds its smallest text position.
+template <int W> AC_D u64 insert_one(const TextCtx& t, const Table& tb, u64 p, u32* claimed, u32* err, bool* same) {
+    const int k = t.k;
+    if (text_mask_count(t.mask, p, k) == 0) {
+        Key<W> fwd = text_extract<W>(t.bits, p, k);
+        Key<W> rc = key_rc<W>(fwd, k);
+        bool flipped = key_lt<W>(rc, fwd);
+        Key<W> uk = flipped ? rc : fwd;
+        uk.w[0] |= (u64)255 << 56;
+        return table_insert<W>(t, tb, uk, false, flipped, p, claimed, err, same);
+    }
+    XKmer<W> x;
+    if (xkmer_at<W>(t, p, &x)) {    // else: the window crosses a separator
+        bool flipped, sm;
+        Key<W> uk = xk_canonical<W>(x, k, &flipped);
+        table_insert<W>(t, tb, uk, true, flipped, p, claimed, err, &sm);
+    }
+    return NOREF;                   // dot k-mers sit at sequence ends: never worth following
+}
+// Lane `lane`'s view of one verification step: matching bases (0..32) of its word, 0 when its word lies beyond the run limit.
+AC_HD int wave_match(const TextCtx& t, u64 a, u64 b, bool same, u64 off, u64 maxlen) {
+    if (off >= maxlen) return 0;
+    if (same) return match_word_fwd(t.bits, t.mask, a + off, b + off);
+    if (off > b) return 0;          // ran off the start of the text (position 0 is a separator, so unreachable)
+    return match_word_rev(t.bits, t.mask, a + off, b - off);
+}
+#ifndef AC_EMU
+template <int W>
+__global__ void __launch_bounds__(256) insert_wave_kernel(TextCtx t, Table tb, u64 p_begin, u64 p_end, u32 chunk, InsertStats* stats, u32* err) {
+    const int lane = (int)(threadIdx.x & 63);
+    const u64 wave = ((u64)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u64 c0 = p_begin + wave * (u64)chunk;
+    if (c0 >= p_end) return;                                   // wave-uniform
+    const u64 c1 = (c0 + chunk < p_end) ? c0 + chunk : p_end;
+    const int k = t.k;
+    u32 claimed = 0, real = 0;
+    u64 p = c0;
+    while (p < c1) {
+        const u64 pi = p + (u64)lane;
+        u64 q = NOREF; bool same = false;
+        if (pi < c1) { real++; q = insert_one<W>(t, tb, pi, &claimed, err, &same); }
+        const u64 hits = __ballot(q != NOREF);
+        u64 next = p + 64;
+        if (hits) {
+            const int jl = 63 - __clzll((long long)hits);
+            const u64 qj = (u64)__shfl((unsigned long long)q, jl);
+            const bool sj = __shfl((int)same, jl) != 0;
+            const u64 pj = p + (u64)jl;
+            const u64 maxlen = c1 - 1 - pj;
+            const u64 a = pj + (u64)k, b = sj ? qj + (u64)k : qj - 1;
+            u64 n = 0;
+            while (n < maxlen) {
+                int tmatch = wave_match(t, a, b, sj, n + 32 * (u64)lane, maxlen);
+                const u64 bal = __ballot(tmatch < 32);
+                if (bal == 0) { n += 2048; continue; }
+                const int f = __ffsll((long long)bal) - 1;
+                n += 32 * (u64)f + (u64)__shfl(tmatch, f);
+                break;
+            }
+            if (n > maxlen) n = maxlen;
+            if (pj + 1 + n > next) next = pj + 1 + n;
+        }
+        p = next;
+    }
+    // one pair of atomics per wavefront (64 lanes adding to one address would serialise in L2)
+    for (int o = 32; o; o >>= 1) { real += (u32)__shfl_xor((int)real, o); claimed += (u32)__shfl_xor((int)claimed, o); }
+    if (lane == 0) {
+        InsertStats* st = stats + (wave & 255);
+        atomic_add64(&st->real, (u64)real);
+        if (claimed) atomic_add64(&st->claimed, (u64)claimed);
+    }
+}
+#endif
+// The wavefront kernel's logic with the 64 lanes visited one after the other (CPU emulation: tests only; also the
+// reference the device kernel is read against).
+template <int W> struct InsertWaveEmuFunctor {
+    TextCtx t; Table tb; u64 p_begin, p_end; u32 chunk; InsertStats* stats; u32* err;
+    AC_D void operator()(u64 wave) const {
+        const u64 c0 = p_begin + wave * (u64)chunk;
+        if (c0 >= p_end) return;
+        const u64 c1 = (c0 + chunk < p_end) ? c0 + chunk : p_end;
+        const int k = t.k;
+        u32 claimed = 0, real = 0;
+        u64 p = c0;
+        while (p < c1) {
+            u64 q[64]; bool same[64];
+            int jl = -1;
+            for (int lane = 0; lane < 64; lane++) {
+                q[lane] = NOREF; same[lane] = false;
+                if (p + (u64)lane < c1) { real++; q[lane] = insert_one<W>(t, tb, p + (u64)lane, &claimed, err, &same[lane]); }
+                if (q[lane] != NOREF) jl = lane;
+            }
+            u64 next = p + 64;
+            if (jl >= 0) {
+                const u64 pj = p + (u64)jl;
+                const u64 maxlen = c1 - 1 - pj;
+                const u64 a = pj + (u64)k, b = same[jl] ? q[jl] + (u64)k : q[jl] - 1;
+                u64 n = 0;
+                while (n < maxlen) {
+                    int f = -1, tf = 0;
+                    for (int lane = 0; lane < 64 && f < 0; lane++) {
+                        int tmatch = wave_match(t, a, b, same[jl], n + 32 * (u64)lane, maxlen);
+                        if (tmatch < 32) { f = lane; tf = tmatch; }
+                    }
+                    if (f < 0) { n += 2048; continue; }
+                    n += 32 * (u64)f + (u64)tf;
+                    break;
+                }
+                if (n > maxlen) n = maxlen;
+                if (pj + 1 + n > next) next = pj + 1 + n;
+            }
+            p = next;
+        }
+        InsertStats* st = stats + (wave & 255);
+        atomic_add64(&st->real, (u64)real);
+        if (claimed) atomic_add64(&st->claimed, (u64)claimed);
+    }
+};
+
 // ---- K3: novel-position bitmap -> sorted novel list + rank support ---------------------------------------
 struct MarkFunctor {
     const u64* slots; u32* bm32;
@@ -1019,6 +1147,10 @@ std::vector<uint8_t> layout_text(const std::vector<SeqView>& seqs, uint32_t k, s
 int max_supported_k() { return (64 * 4 - 8) / 2; }   // W <= 4 key words in this build
 
 static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
+// Tuning knobs of the insert (environment, read once): AC_INSERT_VARIANT=1 selects the thread-per-chunk kernel,
+// AC_INSERT_CHUNK the largest wavefront chunk (positions).
+static int insert_variant() { static int v = [] { const char* e = getenv("AC_INSERT_VARIANT"); return e ? atoi(e) : 0; }(); return v; }
+static u64 wave_chunk_max() { static u64 v = [] { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 4096; return (std::max<u64>(x, 256) + 63) & ~63ULL; }(); return v; }
 
 // A text resident in HBM with its sequence table and its 2-bit packing.
 struct PackedText {
@@ -1135,9 +1267,24 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
             u64 pe = (pb == 0) ? first : pb * 2;
             if (pe > p_end_all || p_end_all - pe < (1u << 16)) pe = p_end_all;
             u64 len = pe - pb;
-            u32 chunk = 64;
-            while (chunk < 1024 && len / chunk > (1u << 19)) chunk *= 2;   // >= ~0.5 M threads when the phase is long
-            launch((len + chunk - 1) / chunk, InsertFunctor<W>{t, tb, pb, pe, chunk, istats.ptr(), counters.ptr() + 1});
+            if (insert_variant() == 0) {      // one wavefront per chunk: >= ~16 K wavefronts when the phase is long
+                u64 c = (len / 16384 + 63) & ~63ULL;
+                u32 chunk = (u32)std::min<u64>(std::max<u64>(c, 256), wave_chunk_max());
+                u64 n_waves = (len + chunk - 1) / chunk;
+#ifdef AC_EMU
+                launch(n_waves, InsertWaveEmuFunctor<W>{t, tb, pb, pe, chunk, istats.ptr(), counters.ptr() + 1});
+#else
+                u64 blocks = (n_waves + 3) / 4;
+                if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+                hipLaunchKernelGGL(insert_wave_kernel<W>, dim3((unsigned)blocks), dim3(256), 0, 0, t, tb, pb, pe, chunk, istats.ptr(),
+                                   counters.ptr() + 1);
+                AC_HIP_CHECK(hipGetLastError());
+#endif
+            } else {                          // one thread per chunk (kept for comparison: AC_INSERT_VARIANT=1)
+                u32 chunk = 64;
+                while (chunk < 1024 && len / chunk > (1u << 19)) chunk *= 2;   // >= ~0.5 M threads when the phase is long
+                launch((len + chunk - 1) / chunk, InsertFunctor<W>{t, tb, pb, pe, chunk, istats.ptr(), counters.ptr() + 1});
+            }
             launches++;
             pb = pe;
         }

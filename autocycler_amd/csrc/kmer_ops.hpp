@@ -255,6 +255,21 @@ AC_HD u64 match_run_rev(const u64* bits, const u64* mask, u64 a, u64 b, u64 maxl
     return n < maxlen ? n : maxlen;
 }
 
+// Number of leading bases (0..32) on which the 32-base word at a agrees with the word at b (fwd) / with the reverse-
+// complemented view ending at b (rev), stopping at the first masked position of either side.
+AC_HD int match_word_fwd(const u64* bits, const u64* mask, u64 a, u64 b) {
+    u64 x = text_word(bits, a) ^ text_word(bits, b);
+    u32 m = mask_word(mask, a) | mask_word(mask, b);
+    int d = clz64(x) >> 1, e = ctz32(m);
+    return d < e ? d : e;
+}
+AC_HD int match_word_rev(const u64* bits, const u64* mask, u64 a, u64 b) {
+    u64 x = text_word(bits, a) ^ text_word_rc(bits, b);
+    u32 m = mask_word(mask, a) | mask_word_rev(mask, b);
+    int d = clz64(x) >> 1, e = ctz32(m);
+    return d < e ? d : e;
+}
+
 // ---- extended k-mers (with dots) ----------------------------------------------------------------
 template <int W>
 struct XKmer {

@@ -318,6 +318,57 @@ template <class F> void launch(u64 n, const F& f, stream_t s = 0) {
 #endif
 }
 
+// Same, but every lane of every launched wavefront runs the functor (with valid = false beyond n), so that the functor
+// may use the wavefront-wide helpers below, which need all 64 lanes to arrive together.
+#ifndef AC_EMU
+template <class F>
+__global__ void __launch_bounds__(256) functor_kernel_full(u64 n, F f) {
+    u64 tid = (u64)blockIdx.x * 256 + threadIdx.x;
+    f(tid, tid < n);
+}
+#endif
+template <class F> void launch_full(u64 n, const F& f, stream_t s = 0) {
+    if (n == 0) return;
+#ifdef AC_EMU
+    int order = emu_order();
+    if (order == 1) { for (u64 i = n; i-- > 0;) f(i, true); }
+    else { for (u64 i = 0; i < n; i++) f(i, true); }
+#else
+    u64 blocks = (n + 255) / 256;
+    if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+    hipLaunchKernelGGL(functor_kernel_full<F>, dim3((unsigned)blocks), dim3(256), 0, s, n, f);
+    AC_HIP_CHECK(hipGetLastError());
+#endif
+}
+// Bump allocation from a device counter with ONE atomic per wavefront (a counter hit by every lane serialises in L2).
+// All 64 lanes must call it (amount may be 0).  Returns this lane's offset.
+AC_D u32 wave_alloc32(u32* counter, u32 amount) {
+#ifdef AC_EMU
+    u32 o = *counter; *counter += amount; return o;
+#else
+    const int lane = (int)(threadIdx.x & 63);
+    u32 incl = amount;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { u32 t = (u32)__shfl_up((int)incl, o); if (lane >= o) incl += t; }
+    u32 total = (u32)__shfl((int)incl, 63);
+    u32 base = 0;
+    if (lane == 0 && total) base = atomicAdd(counter, total);
+    base = (u32)__shfl((int)base, 0);
+    return base + incl - amount;
+#endif
+}
+// Adds the wavefront's total of `v` to a device counter with one atomic.  All 64 lanes must call it.
+AC_D void wave_add64(u64* counter, u32 v) {
+#ifdef AC_EMU
+    *counter += v;
+#else
+    u32 t = v;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) t += (u32)__shfl_xor((int)t, o);
+    if ((threadIdx.x & 63) == 0 && t) atomic_add64(counter, (u64)t);
+#endif
+}
+
 // ---- device primitives ----------------------------------------------------------------------------
 // Stable LSD radix sort of (u64 key, u32 value) pairs on key bits [0, end_bit).
 inline void sort_pairs_u64_u32(DBuf<u64>& keys, DBuf<u32>& vals, size_t n, int end_bit, stream_t s = 0) {

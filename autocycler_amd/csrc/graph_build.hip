@@ -593,8 +593,11 @@ template <int W, bool WRITE> struct PathWalkFunctor {
             atomic_add32(&depth[r], 1u);
             u32 f = (u32)(p - t.seq_off[s]);
             u32 other = t.seq_len[s] - uc.ulen[r] - f;   // position of the same occurrence on the opposite strand
-            if (strand) { atomic_min32(&minpos_fwd[r], f); atomic_min32(&minpos_rev[r], other); }
-            else { atomic_min32(&minpos_rev[r], f); atomic_min32(&minpos_fwd[r], other); }
+            // the words only ever decrease, so a plain (possibly stale) read that is already <= ours makes the atomic
+            // redundant: a unitig of depth d settles after a few of its d occurrences
+            u32 vf = strand ? f : other, vr = strand ? other : f;
+            if (vf < minpos_fwd[r]) atomic_min32(&minpos_fwd[r], vf);
+            if (vr < minpos_rev[r]) atomic_min32(&minpos_rev[r], vr);
         }
         idx++;
     }
@@ -855,68 +858,109 @@ struct LevelBoundsFunctor {   // keys sorted by (level, visiting position): firs
         if (i == 0 || (u32)(key[i - 1] >> 32) != lv) bstart[lv] = (u32)i;
     }
 };
+// A unitig strand's current sequence as seen by one junction: the descriptor is read once, after that every character
+// is one independent byte load (the per-character exp_at chain of five dependent loads made every level of a pass
+// latency-bound at ~25 characters x sources).
+struct ExpView { u64 coff; u32 pre_len, clen, pre_off, post_off, len; bool fwd; };
+AC_HD ExpView exp_view(const ExpState& e, int32_t s) {
+    u32 u = idx_of(s);
+    ExpView v;
+    v.coff = e.coff[u]; v.pre_len = e.pre_len[u]; v.clen = e.clen[u]; v.pre_off = e.pre_off[u]; v.post_off = e.post_off[u];
+    v.len = v.pre_len + v.clen + e.post_len[u];
+    v.fwd = s > 0;
+    return v;
+}
+AC_HD u8 view_at(const ExpState& e, const ExpView& v, u32 i) {
+    if (i < v.pre_len) return e.pool[v.pre_off + i];
+    i -= v.pre_len;
+    if (i < v.clen) return e.cur[v.coff + i];
+    return e.pool[v.post_off + (i - v.clen)];
+}
+AC_HD u8 view_from_start(const ExpState& e, const ExpView& v, u32 i) { return v.fwd ? view_at(e, v, i) : comp_base(view_at(e, v, v.len - 1 - i)); }
+AC_HD u8 view_from_end(const ExpState& e, const ExpView& v, u32 i) { return v.fwd ? view_at(e, v, v.len - 1 - i) : comp_base(view_at(e, v, i)); }
+// Gained sequence accumulates in the pool across passes (a side that gains again gets a new piece = new characters +
+// old piece), so the sequences are rewritten contiguously only once, after the last pass.
 struct ExpandFunctor {
-    ExpState e; const u32* clist; u64 begin;
-    AC_D void operator()(u64 i) const {
-        u32 c = clist[begin + i];
-        if (!e.dirty[c]) return;    // unchanged since it last shifted nothing: shifts nothing again
-        e.dirty[c] = 0;
+    ExpState e; const u32* clist; u64 begin; u32 pool_cap; u32* err;
+    AC_D void operator()(u64 i, bool valid) const {
+        u32 c = valid ? clist[begin + i] : 0;
+        bool active = valid && e.dirty[c];    // not dirty: unchanged since it last shifted nothing, shifts nothing again
+        if (active) e.dirty[c] = 0;
         const u32 x = c >> 1;
         const bool inputs = (c & 1) == 0;
-        u32 n;
-        const int32_t* p = e.L.next_of(inputs ? -((int32_t)x + 1) : (int32_t)x + 1, &n);
-        // inputs:  forward_prev(x) = { -l : l in reverse_next(x) }   (graph_simplification.rs:233-255)
-        // outputs: forward_next(x)                                    (:258-280)
+        u32 n = 0;
         int32_t srcs[5];
-        u32 min_len = 0xFFFFFFFFu;
-        bool dup = false;
-        for (u32 j = 0; j < n; j++) {
-            srcs[j] = inputs ? -p[j] : p[j];
-            u32 l = exp_len(e, idx_of(srcs[j]));
-            if (l < min_len) min_len = l;
-            for (u32 q = 0; q < j; q++) if (idx_of(srcs[q]) == idx_of(srcs[j])) dup = true;
-        }
-        // get_common_end_seq (:298-312) / get_common_start_seq (:283-295) of the source strand sequences
+        ExpView sv[5];
         u32 amount = 0;
-        while (amount < min_len) {
-            u8 ch = inputs ? exp_from_end(e, srcs[0], amount) : exp_from_start(e, srcs[0], amount);
-            bool same = true;
-            for (u32 j = 1; j < n; j++) {
-                u8 cj = inputs ? exp_from_end(e, srcs[j], amount) : exp_from_start(e, srcs[j], amount);
-                if (cj != ch) { same = false; break; }
+        if (active) {
+            const int32_t* p = e.L.next_of(inputs ? -((int32_t)x + 1) : (int32_t)x + 1, &n);
+            // inputs:  forward_prev(x) = { -l : l in reverse_next(x) }   (graph_simplification.rs:233-255)
+            // outputs: forward_next(x)                                    (:258-280)
+            u32 min_len = 0xFFFFFFFFu;
+            bool dup = false;
+#pragma unroll
+            for (u32 j = 0; j < 5; j++) {
+                if (j >= n) break;
+                srcs[j] = inputs ? -p[j] : p[j];
+                sv[j] = exp_view(e, srcs[j]);
+                if (sv[j].len < min_len) min_len = sv[j].len;
+                for (u32 q = 0; q < j; q++) if (idx_of(srcs[q]) == idx_of(srcs[j])) dup = true;
             }
-            if (!same) break;
-            amount++;
+            // get_common_end_seq (:298-312) / get_common_start_seq (:283-295) of the source strand sequences, eight
+            // characters per step (the loads of a step are independent of each other)
+            while (amount < min_len) {
+                u32 blk = min_len - amount < 8 ? min_len - amount : 8;
+                u8 c0[8];
+#pragma unroll
+                for (u32 b = 0; b < 8; b++) c0[b] = b < blk ? (inputs ? view_from_end(e, sv[0], amount + b) : view_from_start(e, sv[0], amount + b)) : 0;
+                u32 m = blk;
+                for (u32 j = 1; j < n; j++) {
+#pragma unroll
+                    for (u32 b = 0; b < 8; b++) {
+                        if (b >= blk) break;
+                        u8 cj = inputs ? view_from_end(e, sv[j], amount + b) : view_from_start(e, sv[j], amount + b);
+                        if (cj != c0[b] && b < m) m = b;
+                    }
+                }
+                amount += m;
+                if (m < blk) break;
+            }
+            if (amount > 0) {   // avoid_zero_len_unitigs (:145-161): trim while min_source_len <= len * dup
+                u32 lim = (min_len - 1) / (dup ? 2u : 1u);
+                if (amount > lim) amount = lim;
+            }
+            if (amount > 0) {   // avoid_start_of_path (:164-181): trim while any forward / reverse position <= len
+                u32 m = inputs ? e.minf[x] : e.minr[x];
+                u32 lim = m > 0 ? m - 1 : 0;
+                if (amount > lim) amount = lim;
+            }
         }
-        if (amount > 0) {   // avoid_zero_len_unitigs (:145-161): trim while min_source_len <= len * dup
-            u32 lim = (min_len - 1) / (dup ? 2u : 1u);
-            if (amount > lim) amount = lim;
-        }
-        if (amount > 0) {   // avoid_start_of_path (:164-181): trim while any forward / reverse position <= len
-            u32 m = inputs ? e.minf[x] : e.minr[x];
-            u32 lim = m > 0 ? m - 1 : 0;
-            if (amount > lim) amount = lim;
-        }
+        // the destination's piece on the gaining side: [new characters][old piece] (start) / [old piece][new characters] (end)
+        const u32 old_len = amount ? (inputs ? e.pre_len[x] : e.post_len[x]) : 0;
+        const u32 old_off = amount ? (inputs ? e.pre_off[x] : e.post_off[x]) : 0;
+        const u32 off = wave_alloc32(e.pool_used, amount ? amount + old_len : 0);
+        wave_add64(e.shifted, amount);
         if (amount == 0) return;
-        u32 off = atomic_add32(e.pool_used, amount);
+        if ((u64)off + amount + old_len > (u64)pool_cap) { atomic_or32(err, 64u); return; }
         if (inputs) {   // shift_sequence_1 (:89-119): the LAST `amount` characters of the common suffix move onto x's start
-            for (u32 j = 0; j < amount; j++) e.pool[off + (amount - 1 - j)] = exp_from_end(e, srcs[0], j);
+            for (u32 j = 0; j < amount; j++) e.pool[off + (amount - 1 - j)] = view_from_end(e, sv[0], j);
+            for (u32 j = 0; j < old_len; j++) e.pool[off + amount + j] = e.pool[old_off + j];
             for (u32 j = 0; j < n; j++) {
                 u32 u = idx_of(srcs[j]);
                 if (srcs[j] > 0) { exp_remove_end(e, u, amount); e.minr[u] += amount; }       // unitig.rs:226-233
                 else { exp_remove_start(e, u, amount); e.minf[u] += amount; }                  // unitig.rs:217-224
             }
-            e.pre_off[x] = off; e.pre_len[x] = amount; e.minf[x] -= amount;                    // unitig.rs:235-241
+            e.pre_off[x] = off; e.pre_len[x] = amount + old_len; e.minf[x] -= amount;          // unitig.rs:235-241
         } else {        // shift_sequence_2 (:122-142): the FIRST `amount` characters of the common prefix move onto x's end
-            for (u32 j = 0; j < amount; j++) e.pool[off + j] = exp_from_start(e, srcs[0], j);
+            for (u32 j = 0; j < old_len; j++) e.pool[off + j] = e.pool[old_off + j];
+            for (u32 j = 0; j < amount; j++) e.pool[off + old_len + j] = view_from_start(e, sv[0], j);
             for (u32 j = 0; j < n; j++) {
                 u32 u = idx_of(srcs[j]);
                 if (srcs[j] > 0) { exp_remove_start(e, u, amount); e.minf[u] += amount; }
                 else { exp_remove_end(e, u, amount); e.minr[u] += amount; }
             }
-            e.post_off[x] = off; e.post_len[x] = amount; e.minr[x] -= amount;                  // unitig.rs:243-249
+            e.post_off[x] = off; e.post_len[x] = amount + old_len; e.minr[x] -= amount;        // unitig.rs:243-249
         }
-        atomic_add64(e.shifted, (u64)amount);
         for (u32 j = 0; j <= n; j++) {   // every junction that touches a changed unitig must be looked at again
             u32 u = (j == n) ? x : idx_of(srcs[j]);
             u32 t[4];
@@ -1199,7 +1243,7 @@ struct GraphBuilder::Impl {
     double t0 = 0, t_begin = 0;
     void lap(double* acc) { stream_sync(); double t = now_s(); *acc += t - t0; t0 = t; }
 
-    DBuf<u32> counters;        // [1] insert err, [3] link err, [4] path err, [5] self-mirror links, [6] fragment err
+    DBuf<u32> counters;        // [1] insert err, [3] link err, [4] path err, [5] self-mirror links, [6] fragment err, [7] pool overflow
     // k-mer table and novel list of G
     DBuf<u64> slots; u64 cap = 0; u64 N = 0;
     DBuf<u64> bm; DBuf<u32> wprefix; DBuf<u64> npos;
@@ -1484,7 +1528,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     DBuf<u32> clen(U), pre_off(U, true), pre_len(U, true), post_off(U, true), post_len(U, true);
     copy_d2d(coff.ptr(), useq_off.ptr(), (size_t)U * 8);
     copy_d2d(clen.ptr(), ulen.ptr(), (size_t)U * 4);
-    DBuf<u8> seq_alt(total), pool(total), dirty((u64)U * 2);
+    DBuf<u8> seq_alt(total), pool(std::min<u64>(2 * total + 4096, 0xFFFFFFF0ULL)), dirty((u64)U * 2);
     DBuf<u64> shifted(1); DBuf<u32> pool_used(1);
     copy_d2d(dirty.ptr(), cand.ptr(), (size_t)U * 2);
     u8* cur = useq.ptr(); u8* alt = seq_alt.ptr();
@@ -1522,12 +1566,19 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             hb[n_levels + 1] = (u32)C;
             ExpState e{cur, coff.ptr(), clen.ptr(), pre_off.ptr(), pre_len.ptr(), post_off.ptr(), post_len.ptr(), pool.ptr(),
                        pool_used.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), dirty.ptr(), cand.ptr(), L, shifted.ptr()};
+            pool_used.fill_bytes(0);
+            u64 moved = 0;
             for (;;) {
-                shifted.fill_bytes(0); pool_used.fill_bytes(0);
+                shifted.fill_bytes(0);
                 for (u32 lv = 1; lv <= n_levels; lv++)
-                    launch((u64)(hb[lv + 1] - hb[lv]), ExpandFunctor{e, clist.ptr(), (u64)hb[lv]});
+                    launch_full((u64)(hb[lv + 1] - hb[lv]), ExpandFunctor{e, clist.ptr(), (u64)hb[lv], (u32)pool.size(), counters.ptr() + 7});
                 passes++;
-                if (read_scalar(shifted.ptr()) == 0) break;
+                u64 sh = read_scalar(shifted.ptr());
+                if (sh == 0) break;
+                moved += sh;
+            }
+            if (read_scalar(counters.ptr() + 7)) throw DeviceError("internal error: expand_repeats pool overflow");
+            if (moved) {   // rewrite the sequences contiguously, once
                 launch((u64)U + 1, ExpLenFunctor{e, len64.ptr(), U});
                 exclusive_scan_u64(len64.ptr(), noff.ptr(), (u64)U + 1);
                 final_total = read_scalar(noff.ptr() + U);

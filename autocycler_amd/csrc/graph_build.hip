@@ -870,14 +870,32 @@ AC_HD ExpView exp_view(const ExpState& e, int32_t s) {
     v.fwd = s > 0;
     return v;
 }
-AC_HD u8 view_at(const ExpState& e, const ExpView& v, u32 i) {
-    if (i < v.pre_len) return e.pool[v.pre_off + i];
-    i -= v.pre_len;
-    if (i < v.clen) return e.cur[v.coff + i];
-    return e.pool[v.post_off + (i - v.clen)];
+// Branch-free addressing (selects, no control flow), so that a group of character loads can be issued back to back:
+// with branches every load waited for the previous one and a level's kernel became one long latency chain.
+AC_HD const u8* view_ptr(const ExpState& e, const ExpView& v, u32 i) {
+    u32 i2 = i - v.pre_len;
+    const u8* p_pre = e.pool + v.pre_off + i;
+    const u8* p_core = e.cur + v.coff + i2;
+    const u8* p_post = e.pool + v.post_off + (i2 - v.clen);
+    return i < v.pre_len ? p_pre : (i2 < v.clen ? p_core : p_post);
 }
-AC_HD u8 view_from_start(const ExpState& e, const ExpView& v, u32 i) { return v.fwd ? view_at(e, v, i) : comp_base(view_at(e, v, v.len - 1 - i)); }
-AC_HD u8 view_from_end(const ExpState& e, const ExpView& v, u32 i) { return v.fwd ? view_at(e, v, v.len - 1 - i) : comp_base(view_at(e, v, i)); }
+AC_HD u8 comp_sel(u8 c) { u8 r = 'N'; r = c == 'A' ? (u8)'T' : r; r = c == 'C' ? (u8)'G' : r; r = c == 'G' ? (u8)'C' : r; r = c == 'T' ? (u8)'A' : r; return r; }
+// Characters start .. start+7 counted from the strand's start (from_end = false) or backwards from its end (true);
+// indices beyond the sequence are clamped (callers ignore those slots).
+AC_HD void view_load8(const ExpState& e, const ExpView& v, bool from_end, u32 start, u8 out[8]) {
+    const u32 last = v.len - 1;
+#pragma unroll
+    for (u32 b = 0; b < 8; b++) {
+        u32 i = start + b;
+        i = i > last ? last : i;
+        u32 pos = (from_end == v.fwd) ? last - i : i;      // forward strand read from its end, or reverse strand read from its start
+        out[b] = *view_ptr(e, v, pos);
+    }
+    if (!v.fwd) {
+#pragma unroll
+        for (u32 b = 0; b < 8; b++) out[b] = comp_sel(out[b]);
+    }
+}
 // Gained sequence accumulates in the pool across passes (a side that gains again gets a new piece = new characters +
 // old piece), so the sequences are rewritten contiguously only once, after the last pass.
 struct ExpandFunctor {
@@ -910,17 +928,16 @@ struct ExpandFunctor {
             // characters per step (the loads of a step are independent of each other)
             while (amount < min_len) {
                 u32 blk = min_len - amount < 8 ? min_len - amount : 8;
-                u8 c0[8];
+                u8 c0[8], cj[4][8];
+                view_load8(e, sv[0], inputs, amount, c0);
 #pragma unroll
-                for (u32 b = 0; b < 8; b++) c0[b] = b < blk ? (inputs ? view_from_end(e, sv[0], amount + b) : view_from_start(e, sv[0], amount + b)) : 0;
+                for (u32 j = 1; j < 5; j++) if (j < n) view_load8(e, sv[j], inputs, amount, cj[j - 1]);
                 u32 m = blk;
-                for (u32 j = 1; j < n; j++) {
 #pragma unroll
-                    for (u32 b = 0; b < 8; b++) {
-                        if (b >= blk) break;
-                        u8 cj = inputs ? view_from_end(e, sv[j], amount + b) : view_from_start(e, sv[j], amount + b);
-                        if (cj != c0[b] && b < m) m = b;
-                    }
+                for (u32 j = 1; j < 5; j++) {
+                    if (j >= n) break;
+#pragma unroll
+                    for (u32 b = 0; b < 8; b++) if (b < m && cj[j - 1][b] != c0[b]) m = b;
                 }
                 amount += m;
                 if (m < blk) break;
@@ -943,7 +960,12 @@ struct ExpandFunctor {
         if (amount == 0) return;
         if ((u64)off + amount + old_len > (u64)pool_cap) { atomic_or32(err, 64u); return; }
         if (inputs) {   // shift_sequence_1 (:89-119): the LAST `amount` characters of the common suffix move onto x's start
-            for (u32 j = 0; j < amount; j++) e.pool[off + (amount - 1 - j)] = view_from_end(e, sv[0], j);
+            for (u32 j0 = 0; j0 < amount; j0 += 8) {
+                u8 ch[8];
+                view_load8(e, sv[0], true, j0, ch);
+#pragma unroll
+                for (u32 b = 0; b < 8; b++) if (j0 + b < amount) e.pool[off + (amount - 1 - (j0 + b))] = ch[b];
+            }
             for (u32 j = 0; j < old_len; j++) e.pool[off + amount + j] = e.pool[old_off + j];
             for (u32 j = 0; j < n; j++) {
                 u32 u = idx_of(srcs[j]);
@@ -953,7 +975,12 @@ struct ExpandFunctor {
             e.pre_off[x] = off; e.pre_len[x] = amount + old_len; e.minf[x] -= amount;          // unitig.rs:235-241
         } else {        // shift_sequence_2 (:122-142): the FIRST `amount` characters of the common prefix move onto x's end
             for (u32 j = 0; j < old_len; j++) e.pool[off + j] = e.pool[old_off + j];
-            for (u32 j = 0; j < amount; j++) e.pool[off + old_len + j] = view_from_start(e, sv[0], j);
+            for (u32 j0 = 0; j0 < amount; j0 += 8) {
+                u8 ch[8];
+                view_load8(e, sv[0], false, j0, ch);
+#pragma unroll
+                for (u32 b = 0; b < 8; b++) if (j0 + b < amount) e.pool[off + old_len + j0 + b] = ch[b];
+            }
             for (u32 j = 0; j < n; j++) {
                 u32 u = idx_of(srcs[j]);
                 if (srcs[j] > 0) { exp_remove_start(e, u, amount); e.minf[u] += amount; }

@@ -754,6 +754,48 @@ struct UnitigLess {
     }
 };
 
+// The same order without a comparator sort: two stable LSD radix passes on (length desc | first 32 bases asc | depth desc) —
+// exact whenever the sequence is at most 32 long or differs from its neighbours within the first 32 bases — then a
+// stable insertion sort with the full comparator inside the (rare, small) groups of longer unitigs that agree on
+// length and on their first 32 bases.  Both sorts being stable, equal elements keep the incoming order.
+struct RenumKeyFunctor {
+    const u32* len; const u64* off; const u8* seq; u64* prefix;
+    AC_HD void operator()(u64 u) const {
+        u32 l = len[u];
+        const u8* p = seq + off[u];
+        u64 w = 0;
+        u32 m = l < 32 ? l : 32;
+        for (u32 i = 0; i < m; i++) { u32 ch = p[i]; w |= (u64)(((ch >> 1) ^ (ch >> 2)) & 3u) << (62 - 2 * i); }
+        prefix[u] = w;
+    }
+};
+struct RenumPassFunctor {   // key of the element currently at position i: pass 0 = (prefix low | ~depth), pass 1 = (~len | prefix high)
+    const u32* order; const u32* len; const u32* depth; const u64* prefix; int pass; u64* key;
+    AC_HD void operator()(u64 i) const {
+        u32 u = order[i];
+        key[i] = pass == 0 ? ((prefix[u] << 32) | (u64)(~depth[u])) : (((u64)(~len[u]) << 32) | (prefix[u] >> 32));
+    }
+};
+static const u32 RENUM_MAX_GROUP = 64;
+struct RenumTieFunctor {
+    u32* order; u64 n; const u32* len; const u64* prefix; UnitigLess less; u32* too_big;
+    AC_HD bool same(u32 a, u32 b) const { return len[a] == len[b] && prefix[a] == prefix[b]; }
+    AC_D void operator()(u64 i) const {
+        u32 u = order[i];
+        if (len[u] <= 32) return;                                 // the radix key was the whole comparator
+        if (i > 0 && same(order[i - 1], u)) return;               // not the first of its group
+        u64 e = i + 1;
+        while (e < n && e - i <= RENUM_MAX_GROUP && same(order[e], u)) e++;
+        if (e - i > RENUM_MAX_GROUP) { atomic_or32(too_big, 1u); return; }
+        for (u64 a = i + 1; a < e; a++) {                         // stable insertion sort of order[i, e)
+            u32 v = order[a];
+            u64 b = a;
+            while (b > i && less(v, order[b - 1])) { order[b] = order[b - 1]; b--; }
+            order[b] = v;
+        }
+    }
+};
+
 // ---- K17: expand_repeats on the device (graph_simplification.rs:26-142, shift primitives unitig.rs:217-249) ---------
 // The reference visits junctions sequentially (unitigs in first-renumber order, inputs side then outputs side) and
 // the result depends on that order only where two junctions touch a common unitig.  A junction (x, side) reads and
@@ -1217,6 +1259,27 @@ std::vector<uint8_t> layout_text(const std::vector<SeqView>& seqs, uint32_t k, s
 
 int max_supported_k() { return (64 * 4 - 8) / 2; }   // W <= 4 key words in this build
 
+// renumber_unitigs (unitig_graph.rs:295-315): stable sort of `order` by (length desc, sequence asc, depth desc).
+static void renumber_sort(DBuf<u32>& order, u32 U, const u32* len, const u64* off, const u8* seq, const u32* depth, u32* flag) {
+    if (U <= 1) return;
+    DBuf<u32> backup(U);
+    copy_d2d(backup.ptr(), order.ptr(), (size_t)U * 4);
+    DBuf<u64> prefix(U), key(U);
+    launch(U, RenumKeyFunctor{len, off, seq, prefix.ptr()});
+    for (int pass = 0; pass < 2; pass++) {
+        launch(U, RenumPassFunctor{order.ptr(), len, depth, prefix.ptr(), pass, key.ptr()});
+        sort_pairs_u64_u32(key, order, U, 64);
+    }
+    UnitigLess less{len, off, seq, depth};
+    launch(U, RenumTieFunctor{order.ptr(), U, len, prefix.ptr(), less, flag});
+    if (read_scalar(flag)) {    // a large group of long unitigs sharing length and 32-base prefix: comparator merge sort
+        copy_d2d(order.ptr(), backup.ptr(), (size_t)U * 4);
+        sort_keys_cmp(order, U, less);
+        u32 zero = 0;
+        copy_h2d(flag, &zero, 4);
+    }
+}
+
 static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 // Tuning knobs of the insert (environment, read once): AC_INSERT_VARIANT=1 selects the thread-per-chunk kernel,
 // AC_INSERT_CHUNK the largest wavefront chunk (positions).
@@ -1547,7 +1610,8 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     launch((u64)U * 2, CandFunctor{L, fixed_start.ptr(), fixed_end.ptr(), cand.ptr()});
     DBuf<u32> order1(U);
     launch(U, IotaFunctor{order1.ptr()});
-    sort_keys_cmp(order1, U, UnitigLess{ulen.ptr(), useq_off.ptr(), useq.ptr(), depth.ptr()});
+    DBuf<u32> renum_flag(1, true);
+    renumber_sort(order1, U, ulen.ptr(), useq_off.ptr(), useq.ptr(), depth.ptr(), renum_flag.ptr());
     lap(&tm->analysis);
 
     // K17 expand_repeats, level-scheduled (see the kernels)
@@ -1623,7 +1687,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     // sequences; K16 per-unitig outputs in final order, links in get_links_for_gfa order, paths in final numbers
     DBuf<u32> order2(U);
     copy_d2d(order2.ptr(), order1.ptr(), (size_t)U * 4);
-    sort_keys_cmp(order2, U, UnitigLess{clen.ptr(), coff.ptr(), cur, depth.ptr()});
+    renumber_sort(order2, U, clen.ptr(), coff.ptr(), cur, depth.ptr(), renum_flag.ptr());
     DBuf<u64> number_len(U), lcount((u64)U + 1), loff((u64)U + 1);
     DBuf<u8> meta((size_t)U * 20);
     u64* d_seq_begin = (u64*)meta.ptr();

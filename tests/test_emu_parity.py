@@ -93,3 +93,23 @@ def test_errors(emu):
         compress_build(9, 1, [], lib_path=emu)
     with pytest.raises(AutocyclerError, match="not supported"):
         compress_build(201, 1, [(b"." * 100 + b"A" * 300 + b"." * 100, 300, 1)], lib_path=emu)
+
+
+def shared_prefix_case(n, k, seed=3):
+    """n contigs that all start with the same 40 bases and are otherwise random: every contig is one unitig, all of the
+    same length and with the same 32-base prefix — the tie groups of the radix-key renumbering (insertion sort up to
+    64 members, comparator merge sort beyond)."""
+    import random
+    r = random.Random(seed)
+    z = seqgen.rand_seq(r, 40)
+    seqs = [z + seqgen.rand_seq(r, 2 * k + 8) for _ in range(n)]
+    seqs += [seqs[0][:k + 30] + seqgen.rand_seq(r, 5), seqs[1]]      # shared k-mers and an exact duplicate as well
+    return seqs, [f"a{i % 7}.fasta" for i in range(len(seqs))], [f"c{i}" for i in range(len(seqs))]
+
+
+@pytest.mark.parametrize("n", [3, 20, 70, 150])
+@pytest.mark.parametrize("k", [51, 101])
+def test_renumber_tie_groups(emu, n, k):
+    seqs, fn, hd = shared_prefix_case(n, k)
+    parity_util.check_case(k, seqs, fn, hd, lib_path=emu, repair=False)
+    parity_util.check_case(k, seqs, fn, hd, lib_path=emu, repair=True)

@@ -51,3 +51,12 @@ def test_synthetic_assemblies_medium(k):
     seqs, fn, hd = _synth_case(8, 200_000, 8_000, 1e-3, 1e-4, 4242)
     g, gfa, _ = parity_util.check_case(k, seqs, fn, hd)
     assert g.stats_post["unitigs"] > 100
+
+
+@pytest.mark.parametrize("n", [20, 70, 150])
+@pytest.mark.parametrize("k", [51, 101])
+def test_renumber_tie_groups(n, k):
+    from test_emu_parity import shared_prefix_case
+    seqs, fn, hd = shared_prefix_case(n, k)
+    parity_util.check_case(k, seqs, fn, hd, repair=False)
+    parity_util.check_case(k, seqs, fn, hd, repair=True)

@@ -283,6 +283,59 @@ template <class T> T read_scalar(const T* dptr, stream_t s = 0) {
     return v;
 }
 
+// A second stream for device -> host copies that overlap the kernels of stream 0 (the final D2H is PCIe-bound: the
+// sooner each result array starts to move, the less of the copy is exposed).  Created without the implicit
+// synchronisation with stream 0; ordering is by events.
+class SideStream {
+  public:
+    static SideStream& get() { static SideStream s; return s; }
+    stream_t stream() {
+#ifndef AC_EMU
+        int dev = 0;
+        AC_HIP_CHECK(hipGetDevice(&dev));
+        if (!created_ || dev != dev_) {
+            destroy();
+            AC_HIP_CHECK(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
+            for (auto& e : ev_) AC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            created_ = true; dev_ = dev;
+        }
+        return s_;
+#else
+        return 0;
+#endif
+    }
+    // Everything enqueued on stream 0 so far happens before whatever is enqueued on the side stream from now on.
+    void after_main() {
+#ifndef AC_EMU
+        stream_t s = stream();
+        hipEvent_t e = ev_[next_++ % 16];
+        AC_HIP_CHECK(hipEventRecord(e, 0));
+        AC_HIP_CHECK(hipStreamWaitEvent(s, e, 0));
+#endif
+    }
+    void sync() noexcept {
+#ifndef AC_EMU
+        if (created_) (void)hipStreamSynchronize(s_);
+#endif
+    }
+    struct Guard { ~Guard() { SideStream::get().sync(); } };   // no copy may outlive the scope that owns its destination
+
+  private:
+    SideStream() {}
+    void destroy() {
+#ifndef AC_EMU
+        if (created_) { (void)hipStreamDestroy(s_); for (auto& e : ev_) (void)hipEventDestroy(e); created_ = false; }
+#endif
+    }
+#ifndef AC_EMU
+    hipStream_t s_ = nullptr;
+    hipEvent_t ev_[16];
+#endif
+    bool created_ = false;
+    int dev_ = -1;
+    unsigned next_ = 0;
+};
+
 // ---- functor launcher -----------------------------------------------------------------------------
 // One logical thread per index, 256-thread workgroups (4 wavefronts); every launch in the pipeline
 // has >> 256 workgroups at the benchmark sizes, so the 256 CUs / 8 XCDs fill from the grid alone.

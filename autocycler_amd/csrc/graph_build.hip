@@ -1098,17 +1098,24 @@ struct LinkOutFunctor {     // get_links_for_gfa (unitig_graph.rs:333-350): per 
         }
     }
 };
-struct RemapFunctor {       // 64 path entries per thread: seed numbers -> final numbers, per-sequence length sums
-    int32_t* path; const u64* number_len; const u64* path_off; u32 n_seqs; u64 n_ent; u64* sums;
-    AC_D void operator()(u64 tid) const {
-        u64 i0 = tid * 64, i1 = i0 + 64;
-        if (i1 > n_ent) i1 = n_ent;
-        if (i0 >= i1) return;
-        u32 lo = 0, hi = n_seqs;   // largest s with path_off[s] <= i0
-        while (hi - lo > 1) { u32 mid = lo + ((hi - lo) >> 1); if (path_off[mid] <= i0) lo = mid; else hi = mid; }
-        u32 s = lo;
+struct RemapFunctor {       // seed numbers -> final numbers, per-sequence length sums.  A wavefront owns 4096 consecutive
+    int32_t* path; const u64* number_len; const u64* path_off; u32 n_seqs; u64 n_ent; u64* sums; u64 first_wave;   // entries; lane l takes l, l+64, ...
+    AC_D void operator()(u64 tid, bool valid) const {
+        if (!valid) return;   // the launch is a whole number of wavefronts, so this is wavefront-uniform
+        const u64 wave = first_wave + (tid >> 6);
+        const u32 lane = (u32)(tid & 63);
+        const u64 w0 = wave * 4096;
+        u64 w1 = w0 + 4096;
+        if (w1 > n_ent) w1 = n_ent;
+        u32 s = 0;
         u64 acc = 0;
-        for (u64 i = i0; i < i1; i++) {
+        u64 i = w0 + lane;
+        if (i < w1) {
+            u32 lo = 0, hi = n_seqs;   // largest s with path_off[s] <= i
+            while (hi - lo > 1) { u32 mid = lo + ((hi - lo) >> 1); if (path_off[mid] <= i) lo = mid; else hi = mid; }
+            s = lo;
+        }
+        for (; i < w1; i += 64) {
             while (s + 1 < n_seqs && i >= path_off[s + 1]) { if (acc) atomic_add64(&sums[s], acc); acc = 0; s++; }
             int32_t v = path[i];
             u64 nl = number_len[idx_of(v)];
@@ -1116,6 +1123,17 @@ struct RemapFunctor {       // 64 path entries per thread: seed numbers -> final
             path[i] = v > 0 ? f : -f;
             acc += nl >> 32;
         }
+#ifndef AC_EMU
+        // usually the whole wavefront ends inside one sequence: one atomic instead of 64 to the same address
+        const u32 s0 = (u32)__shfl((int)s, 0);
+        if (__all(s == s0 || acc == 0)) {
+            u64 t = acc;
+#pragma unroll
+            for (int o = 32; o; o >>= 1) t += (u64)__shfl_xor((unsigned long long)t, o);
+            if (lane == 0 && t) atomic_add64(&sums[s0], t);
+            return;
+        }
+#endif
         if (acc) atomic_add64(&sums[s], acc);
     }
 };
@@ -1694,36 +1712,56 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     double* d_depth = (double*)(meta.ptr() + (size_t)U * 8);
     u32* d_seq_len = (u32*)(meta.ptr() + (size_t)U * 16);
     lcount.fill_bytes(0);
-    launch(U, FinalMetaFunctor{order2.ptr(), coff.ptr(), clen.ptr(), depth.ptr(), lcnt.ptr(), number_len.ptr(), d_seq_begin, d_depth,
-                               d_seq_len, lcount.ptr()});
-    exclusive_scan_u64(lcount.ptr(), loff.ptr(), (u64)U + 1);
-    u64 n_links = read_scalar(loff.ptr() + U);
-    DBuf<Link> links_out(n_links);
-    launch(U, LinkOutFunctor{order2.ptr(), L, number_len.ptr(), loff.ptr(), links_out.ptr()});
-    DBuf<u64> sums(n_seqs);
-    sums.fill_bytes(0);
-    launch((n_ent + 63) / 64, RemapFunctor{ent_val.ptr(), number_len.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr()});
-    lap(&tm->finalize);
-
-    // D2H straight into pinned blocks owned by the result
+    // D2H on a second stream, each array as soon as it is final, straight into pinned blocks owned by the result; the
+    // paths go in four chunks, each copied while the next is still being renumbered.
+    SideStream& side = SideStream::get();
+    SideStream::Guard side_guard;
     out->k = k;
     out->n_kmers = 2 * (u64)N;
     out->n_unitigs = U;
     if (want_graph) {
         out->seq_block = PinnedPool::get().alloc(final_total);
+        side.after_main();     // sequences are final since the materialise step
+        copy_d2h_async(out->seq_block.p, cur, final_total, side.stream());
+    }
+    launch(U, FinalMetaFunctor{order2.ptr(), coff.ptr(), clen.ptr(), depth.ptr(), lcnt.ptr(), number_len.ptr(), d_seq_begin, d_depth,
+                               d_seq_len, lcount.ptr()});
+    if (want_graph) {
         out->meta_block = PinnedPool::get().alloc((size_t)U * 20);
+        side.after_main();
+        copy_d2h_async(out->meta_block.p, meta.ptr(), (size_t)U * 20, side.stream());
+    }
+    exclusive_scan_u64(lcount.ptr(), loff.ptr(), (u64)U + 1);
+    u64 n_links = read_scalar(loff.ptr() + U);
+    DBuf<Link> links_out(n_links);
+    launch(U, LinkOutFunctor{order2.ptr(), L, number_len.ptr(), loff.ptr(), links_out.ptr()});
+    if (want_graph) {
         out->links_block = PinnedPool::get().alloc(n_links * sizeof(Link));
-        copy_d2h_async(out->seq_block.p, cur, final_total);
-        copy_d2h_async(out->meta_block.p, meta.ptr(), (size_t)U * 20);
-        copy_d2h_async(out->links_block.p, links_out.ptr(), n_links * sizeof(Link));
+        side.after_main();
+        copy_d2h_async(out->links_block.p, links_out.ptr(), n_links * sizeof(Link), side.stream());
     }
-    if (want_paths) {
-        out->path_block = PinnedPool::get().alloc(n_ent * 4);
-        copy_d2h_async(out->path_block.p, ent_val.ptr(), n_ent * 4);
+    DBuf<u64> sums(n_seqs);
+    sums.fill_bytes(0);
+    if (want_paths) out->path_block = PinnedPool::get().alloc(n_ent * 4);
+    {
+        const u64 n_waves = (n_ent + 4095) / 4096;
+        const u64 per_chunk = std::max<u64>((n_waves + 3) / 4, 64);
+        for (u64 w = 0; w < n_waves; w += per_chunk) {
+            u64 cnt = std::min<u64>(per_chunk, n_waves - w);
+            launch_full(cnt * 64, RemapFunctor{ent_val.ptr(), number_len.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr(), w});
+            if (want_paths) {
+                u64 b = w * 4096, e2 = std::min<u64>((w + cnt) * 4096, n_ent);
+                side.after_main();
+                copy_d2h_async((int32_t*)out->path_block.p + b, ent_val.ptr() + b, (e2 - b) * 4, side.stream());
+            }
+        }
     }
+    lap(&tm->finalize);
+
     std::vector<u64> h_sums = to_host(sums, n_seqs);
     out->path_off = to_host(path_off, (size_t)n_seqs + 1);
-    std::vector<u32> errs = to_host(counters, 8);   // synchronises the stream: everything above has landed
+    std::vector<u32> errs = to_host(counters, 8);   // synchronises stream 0
+    side.sync();                                    // ... and the copies: everything above has landed
     if (errs[3] || errs[4])
         throw DeviceError("internal error: inconsistent unitig ends (codes " + std::to_string(errs[3]) + "/" + std::to_string(errs[4]) + ")");
     if (want_graph) {

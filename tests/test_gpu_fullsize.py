@@ -1,0 +1,117 @@
+"""BASELINE.json's full-size configurations on the device, checked through size-independent properties (the oracle, like
+the reference, needs minutes to hours at these sizes): config B = 12 x 5 Mbp and config C = 96 x 5 Mbp, k = 51.
+
+  * decompress property (tests.rs:114-127, unitig_graph.rs:362-388): the unitig strand sequences along every path spell
+    the input sequence, byte for byte;
+  * every step of every path is a link, links come in reverse-complement pairs (check_links, unitig_graph.rs:752-793);
+  * depth == number of path occurrences (unitig.rs:149-156), unitigs are in renumber_unitigs order (unitig_graph.rs:295-315);
+  * the printed statistics are consistent (link_count, total_length, kmers.len() == 2 x sum of pre-simplification lengths);
+  * config B only: GFA save -> load -> save is the identity (tests.rs:108-112) through the oracle's loader/writer, and a
+    scaled-down replica of the same generator is byte-identical to the oracle (test_gpu_parity)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+COMP = np.zeros(256, dtype=np.uint8)
+for a, b in zip(b"ACGT", b"TGCA"):
+    COMP[a] = b
+
+
+def build(n_assemblies, k=51):
+    import torch
+    import bench
+    from autocycler_amd import _capi, synth
+    lib = _capi.load_library()
+    lib.ac_seqs_views.restype = C.POINTER(_capi.SeqView)
+    lib.ac_seqs_count.restype = C.c_uint32
+    lib.ac_seqs_free.argtypes = [C.c_void_p]
+    seqs, fn, hd = [], [], []
+    for i, contigs in enumerate(synth.make_assemblies(n_assemblies, seed=51_000)):
+        for header, s in contigs:
+            seqs.append(np.ascontiguousarray(s)); fn.append(f"assembly_{i:04d}.fasta"); hd.append(header)
+    h = bench.prepare(lib, k, seqs, fn, hd, n_assemblies, threads=32)
+    n = lib.ac_seqs_count(h)
+    views = lib.ac_seqs_views(h)
+    n_text = lib.ac_text_size(C.c_uint32(k), views, C.c_uint32(n))
+    text = np.empty(n_text, dtype=np.uint8)
+    off = (C.c_uint64 * n)(); d1 = (C.c_uint16 * n)(); d2 = (C.c_uint16 * n)()
+    assert lib.ac_layout_text(C.c_uint32(k), views, C.c_uint32(n), text.ctypes.data_as(C.c_void_p), off, d1, d2) == 0
+    lens = (C.c_uint32 * n)(*[views[i].length for i in range(n)])
+    ids = (C.c_uint16 * n)(*[views[i].id for i in range(n)])
+    d_text = torch.from_numpy(text).to("cuda:0")
+    g = C.c_void_p()
+    rc = lib.ac_compress_build_device(C.c_uint32(k), C.c_uint32(n_assemblies), C.c_void_p(d_text.data_ptr()), C.c_uint64(n_text),
+                                      off, lens, ids, d1, d2, C.c_uint32(n), C.c_int(0), C.byref(g))
+    assert rc == 0, lib.ac_last_error()
+    lib.ac_seqs_free(h)
+    return _capi.Graph(lib, g, n), seqs, fn, hd
+
+
+def check_properties(g, seqs, k):
+    U = g.unitig_count
+    ulen = np.empty(U, dtype=np.int64); depth = np.empty(U, dtype=np.float64)
+    pieces = []
+    for i in range(U):
+        s, d = g.unitig(i)
+        pieces.append(s); ulen[i] = len(s); depth[i] = d
+    useq = np.frombuffer(b"".join(pieces), dtype=np.uint8)
+    uoff = np.cumsum(ulen) - ulen
+    assert (ulen > 0).all()
+    # renumber_unitigs order: length descending, then sequence ascending (then depth descending)
+    assert (np.diff(ulen) <= 0).all()
+    for i in np.nonzero(np.diff(ulen) == 0)[0][:20000]:
+        a, b = pieces[i], pieces[i + 1]
+        assert a < b or (a == b and depth[i] >= depth[i + 1]), i
+    # links: reverse-complement pairs; one-way count as link_count() defines it
+    links = g.links()
+    la = np.array([(a if af else -a, b if bf else -b) for a, af, b, bf in links], dtype=np.int64)
+    code = lambda x, y: (x + (1 << 31)) * (1 << 32) + (y + (1 << 31))
+    lset = np.unique(code(la[:, 0], la[:, 1]))
+    assert len(lset) == len(la)                                     # no duplicate links
+    assert np.isin(code(-la[:, 1], -la[:, 0]), lset).all()          # a -> b  <=>  -b -> -a
+    self_mirror = int((la[:, 0] == -la[:, 1]).sum())
+    assert g.stats_post["links"] == (len(la) + self_mirror) // 2
+    assert g.stats_post["total_length"] == int(ulen.sum())
+    assert g.stats_pre["unitigs"] == g.stats_post["unitigs"] == U
+    assert g.kmer_count == 2 * g.stats_pre["total_length"]          # trimmed length == number of k-mers (unitig.rs:158-166)
+    # paths: spell the inputs, follow links, define the depths
+    occ = np.zeros(U, dtype=np.int64)
+    for s, orig in enumerate(seqs):
+        p = np.asarray(g.path(s), dtype=np.int64)
+        idx = np.abs(p) - 1
+        fwd = p > 0
+        occ += np.bincount(idx, minlength=U)
+        assert np.isin(code(p[:-1], p[1:]), lset).all(), f"path {s} leaves the links"
+        ln = ulen[idx]
+        assert int(ln.sum()) == len(orig)
+        starts = np.cumsum(ln) - ln
+        within = np.arange(len(orig), dtype=np.int64) - np.repeat(starts, ln)
+        f = np.repeat(fwd, ln)
+        src = np.repeat(uoff[idx], ln) + np.where(f, within, np.repeat(ln, ln) - 1 - within)
+        out = useq[src]
+        out = np.where(f, out, COMP[out])
+        assert np.array_equal(out, orig), f"sequence {s} is not reproduced by its path"
+    assert np.array_equal(occ.astype(np.float64), depth)
+    return U
+
+
+def test_config_b_12_assemblies():
+    import oracle_lib as O
+    g, seqs, fn, hd = build(12)
+    U = check_properties(g, seqs, 51)
+    assert U > 1000
+    gfa = g.gfa(fn, hd)
+    assert O.gfa_resave(gfa) == gfa          # save -> load -> save identity (tests.rs:108-112)
+    dec = O.decompress(gfa)                  # decompress.rs through the oracle: (filename, header, sequence) per contig
+    assert len(dec) == len(seqs)
+    assert [d[2].encode() for d in dec] == [s.tobytes() for s in seqs]
+
+
+def test_config_c_96_assemblies():
+    g, seqs, fn, hd = build(96)
+    U = check_properties(g, seqs, 51)
+    assert U > 10000
+    assert g.stats_post["total_length"] < g.stats_pre["total_length"]

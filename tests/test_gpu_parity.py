@@ -60,3 +60,10 @@ def test_renumber_tie_groups(n, k):
     seqs, fn, hd = shared_prefix_case(n, k)
     parity_util.check_case(k, seqs, fn, hd, repair=False)
     parity_util.check_case(k, seqs, fn, hd, repair=True)
+
+
+def test_synthetic_many_path_entries():
+    # > 262 144 path entries: several renumbering chunks, each copied to the host while the next is renumbered
+    seqs, fn, hd = _synth_case(12, 300_000, 10_000, 5e-3, 2e-4, 777)
+    g, gfa, _ = parity_util.check_case(51, seqs, fn, hd)
+    assert g.timings()["n_path_entries"] > 262_144

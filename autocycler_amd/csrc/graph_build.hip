@@ -46,6 +46,9 @@ struct TextCtx {
 struct Table {
     u64* slots;
     u64 cap_mask;
+    const u64* occ;   // optional (lookups after the insert): bit s set <=> slot s is occupied.  2 MB for 16 M slots, so it
+                      // stays in L2 and answers the majority of the lookups of ABSENT k-mers (their first slot is empty
+                      // with probability 1 - load) without touching the table, which only lives in the Infinity Cache
 };
 
 // Largest s with off[s] <= p; valid iff p is a k-mer start of that sequence.
@@ -99,6 +102,7 @@ template <int W> AC_HD FindResult table_find(const TextCtx& t, const Table& tb, 
     u64 tag = slot_make(h, isdot, 0);
     u64 s = h & tb.cap_mask;
     FindResult r; r.found = false; r.pos = 0; r.claimant_flipped = 0;
+    if (tb.occ && !((tb.occ[s >> 6] >> (s & 63)) & 1)) return r;
     for (int probes = 0; probes < MAX_PROBES; probes++) {
         u64 v = tb.slots[s];
         if (v == SLOT_EMPTY) return r;
@@ -387,13 +391,18 @@ template <int W> struct InsertWaveEmuFunctor {
 };
 
 // ---- K3: novel-position bitmap -> sorted novel list + rank support ---------------------------------------
-struct MarkFunctor {
-    const u64* slots; u32* bm32;
-    AC_D void operator()(u64 s) const {
-        u64 v = slots[s];
-        if (v == SLOT_EMPTY) return;
-        u64 pos = slot_pos(v);
-        atomic_or32(&bm32[pos >> 5], 1u << (pos & 31));
+struct MarkFunctor {      // also writes the slot-occupancy bitmap (one ballot word per wavefront; `occ` zeroed beforehand)
+    const u64* slots; u32* bm32; u64* occ;
+    AC_D void operator()(u64 s, bool valid) const {
+        u64 v = valid ? slots[s] : SLOT_EMPTY;
+        bool full = v != SLOT_EMPTY;
+        if (full) { u64 pos = slot_pos(v); atomic_or32(&bm32[pos >> 5], 1u << (pos & 31)); }
+#ifdef AC_EMU
+        if (full) occ[s >> 6] |= 1ULL << (s & 63);
+#else
+        u64 b = __ballot(full);
+        if ((s & 63) == 0 && valid) occ[s >> 6] = b;
+#endif
     }
 };
 struct PopcFunctor {
@@ -1375,7 +1384,9 @@ struct GraphBuilder::Impl {
         if (t.n_seqs == 0 || t.n_text < (u64)k + 2) throw DeviceError("no sequences");
     }
     template <int W> void insert(const PackedText& t, u32 hint, DBuf<u64>* slots_out, u64* cap_out, u64* n_distinct_out);
-    void novel_bitmap(const PackedText& t, const DBuf<u64>& sl, u64 c, DBuf<u64>* bm_out);
+    void novel_bitmap(const PackedText& t, const DBuf<u64>& sl, u64 c, DBuf<u64>* bm_out, DBuf<u64>* occ_out);
+    DBuf<u64> occ;             // slot-occupancy bitmap of the graph table
+    Table graph_table() const { return Table{const_cast<u64*>(slots.ptr()), cap - 1, occ.ptr()}; }
     template <int W> void fragments();
     template <int W> void table();                      // K2, K3 on G
     template <int W> void degrees(u64 lo, u64 hi);      // K5 for novel indices [lo, hi)
@@ -1403,7 +1414,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
         sl.fill_bytes(0xFF);
         counters.fill_bytes(0);
         istats.fill_bytes(0);
-        Table tb{sl.ptr(), c - 1};
+        Table tb{sl.ptr(), c - 1, nullptr};
         stream_sync();
 #ifndef AC_EMU
         hipEvent_t e0, e1;
@@ -1466,11 +1477,13 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
 }
 
 // K3a: bit p set <=> text position p is the smallest occurrence of its canonical k-mer.
-void GraphBuilder::Impl::novel_bitmap(const PackedText& t, const DBuf<u64>& sl, u64 c, DBuf<u64>* bm_out) {
+void GraphBuilder::Impl::novel_bitmap(const PackedText& t, const DBuf<u64>& sl, u64 c, DBuf<u64>* bm_out, DBuf<u64>* occ_out) {
     u64 n_bm_words = t.n_text / 64 + 1;
     bm_out->alloc(n_bm_words);
     bm_out->fill_bytes(0);
-    launch(c, MarkFunctor{sl.ptr(), (u32*)bm_out->ptr()});
+    occ_out->alloc((c + 63) / 64);
+    occ_out->fill_bytes(0);
+    launch_full(c, MarkFunctor{sl.ptr(), (u32*)bm_out->ptr(), occ_out->ptr()});
 }
 
 // Sharded phase 1 (after the local insert): novel runs of this rank -> fragment text + one meta record per fragment.
@@ -1479,7 +1492,8 @@ template <int W> void GraphBuilder::Impl::fragments() {
     insert<W>(loc, tm->local_hint, &lslots, &lcap, &ln);
     tm->n_local_distinct = ln;
     lap(&tm->insert);
-    novel_bitmap(loc, lslots, lcap, &lbm);
+    DBuf<u64> locc;
+    novel_bitmap(loc, lslots, lcap, &lbm, &locc);
     u64 nw = loc.n_text / 64 + 1;
     DBuf<u32> ns(nw + 1), ne(nw + 1), so(nw + 1), eo(nw + 1);
     ns.fill_bytes(0); ne.fill_bytes(0);
@@ -1515,7 +1529,7 @@ template <int W> void GraphBuilder::Impl::table() {
 
     // K3 novel-position bitmap -> sorted novel list + rank support
     u64 n_bm_words = g.n_text / 64 + 1;
-    novel_bitmap(g, slots, cap, &bm);
+    novel_bitmap(g, slots, cap, &bm, &occ);
     DBuf<u32> wcnt(n_bm_words);
     wprefix.alloc(n_bm_words);
     launch(n_bm_words, PopcFunctor{bm.ptr(), wcnt.ptr()});
@@ -1529,7 +1543,7 @@ template <int W> void GraphBuilder::Impl::table() {
 // K5 out/in degrees of the novel k-mers [lo, hi) (a sharded build computes one slice per rank and all-gathers them).
 template <int W> void GraphBuilder::Impl::degrees(u64 lo, u64 hi) {
     PackedText& g = *G;
-    Table tb{slots.ptr(), cap - 1};
+    Table tb = graph_table();
     deg_lo = lo; deg_hi = hi;
     launch(hi - lo, DegreeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kinfo.ptr(), g.any_dots, lo});
     lap(&tm->degree);
@@ -1539,7 +1553,7 @@ template <int W> void GraphBuilder::Impl::degrees(u64 lo, u64 hi) {
 template <int W> void GraphBuilder::Impl::unitigs() {
     PackedText& g = *G;
     TextCtx t = g.ctx((int)k);
-    Table tb{slots.ptr(), cap - 1};
+    Table tb = graph_table();
     Novel nv{bm.ptr(), wprefix.ptr()};
     launch(g.n_seqs, FirstFunctor<W>{t, tb, nv, kinfo.ptr(), g.has_flags ? g.seq_flags.ptr() : nullptr});
     lap(&tm->degree);
@@ -1583,7 +1597,7 @@ template <int W> void GraphBuilder::Impl::unitigs() {
 // K10 paths of this rank's sequences against the graph: count, scan, write; first / last unitig of every path.
 template <int W> void GraphBuilder::Impl::walk() {
     TextCtx t = loc.ctx((int)k), g = G->ctx((int)k);
-    Table tb{slots.ptr(), cap - 1};
+    Table tb = graph_table();
     Novel nv{bm.ptr(), wprefix.ptr()};
     UnitigCtx uc{head.ptr(), scan.ptr(), rank.ptr(), uorient.ptr(), ustart.ptr(), ulen.ptr(), U, N};
     const u32 PC = 256;

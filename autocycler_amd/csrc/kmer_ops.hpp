@@ -70,15 +70,20 @@ AC_HD u64 rev2_64(u64 x) {
     return x;
 }
 
-// Multiword logical shift right by s bits (0 <= s < 64*W).
+// Multiword logical shift right by s bits (0 <= s < 64*W).  Constant word indices only: a run-time index into the key
+// makes the compiler keep every key that flows through here in scratch (private) memory — 24 bytes per lane, written and
+// re-read for every candidate k-mer, which showed up as ~1.4 GB of HBM writes per build in the degree kernel alone.
 template <int W> AC_HD Key<W> key_shr(const Key<W>& a, int s) {
     Key<W> r;
-    int ws = s >> 6, bs = s & 63;
+    const int ws = s >> 6, bs = s & 63;
 #pragma unroll
     for (int i = 0; i < W; i++) {
-        int src = i - ws;
-        u64 lo = (src >= 0) ? a.w[src] : 0;
-        u64 hi = (src - 1 >= 0) ? a.w[src - 1] : 0;
+        u64 lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+            lo = (j == i - ws) ? a.w[j] : lo;
+            hi = (j == i - ws - 1) ? a.w[j] : hi;
+        }
         r.w[i] = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
     }
     return r;
@@ -131,7 +136,9 @@ template <int W> AC_HD void key_roll_rc(Key<W>& a, u32 c, int k) {
     a.w[0] >>= 2;
     int bit = 2 * (k - 1);
     int wi = W - 1 - (bit >> 6);
-    a.w[wi] |= (u64)(3 - c) << (bit & 63);
+    u64 v = (u64)(3 - c) << (bit & 63);
+#pragma unroll
+    for (int i = 0; i < W; i++) a.w[i] |= (i == wi) ? v : 0;   // constant indices only (see key_shr)
 }
 
 // ---- packed text --------------------------------------------------------------------------------

@@ -92,6 +92,7 @@ const char* ac_version(void) {
     return "autocycler_amd 0.1 (gfx950)";
 #endif
 }
+void ac_set_stage_timing(int on) { set_stage_timing(on != 0); }
 uint32_t ac_max_kmer(void) { int m = max_supported_k(); return (uint32_t)(m % 2 ? m : m - 1); }
 int ac_device_count(void) {
 #ifndef AC_EMU

@@ -27,6 +27,9 @@ static double now_s() {
 
 
 static const int MAX_PROBES = 1 << 14;
+static bool g_stage_timing = false;
+void set_stage_timing(bool on) { g_stage_timing = on; }
+bool stage_timing() { return g_stage_timing; }
 
 // kinfo bits (per novel k-mer, relative to the text orientation T of its smallest occurrence)
 static const u32 KI_OUT_MASK = 7u, KI_IN_SHIFT = 3, KI_FIRST_T = 1u << 6, KI_FIRST_RCT = 1u << 7;
@@ -436,6 +439,27 @@ template <int W> AC_D int count_successors(const TextCtx& t, const Table& tb, co
     }
     return n;
 }
+// Is the real (dot-free) k-mer with strands (f, r) in the set?
+template <int W> AC_D bool real_kmer_exists(const TextCtx& t, const Table& tb, const Key<W>& f, const Key<W>& r) {
+    Key<W> uk = key_lt<W>(r, f) ? r : f;
+    uk.w[0] |= (u64)255 << 56;
+    return table_find<W>(t, tb, uk, false).found;
+}
+// The four real successors of a real k-mer with strands (fwd, rc): both strands of a candidate follow from the parent's
+// by one rolling step each — no reverse complement per candidate (the degree kernel was instruction-bound on those).
+template <int W> AC_D int count_real_successors(const TextCtx& t, const Table& tb, const Key<W>& fwd, const Key<W>& rc, int known) {
+    const Key<W> km = key_kmask<W>(t.k);
+    int n = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        if (c == known) { n++; continue; }
+        Key<W> f = fwd, r = rc;
+        key_roll_fwd<W>(f, (u32)c, km);
+        key_roll_rc<W>(r, (u32)c, t.k);
+        if (real_kmer_exists<W>(t, tb, f, r)) n++;
+    }
+    return n;
+}
 template <int W> struct DegreeFunctor {
     TextCtx t; Table tb; const u64* npos; u32* kinfo; int any_dots; u64 first;   // handles novel indices first, first+1, ...
     AC_D void operator()(u64 i) const {
@@ -443,16 +467,28 @@ template <int W> struct DegreeFunctor {
         XKmer<W> x;
         u64 p = npos[i];
         int known_out = -1, known_in = -1;
+        int out, in;
         if (text_mask_count(t.mask, p, t.k) == 0) {
             x.fwd = text_extract<W>(t.bits, p, t.k); x.ld = 0; x.td = 0;
             // an unmasked neighbour base means the neighbouring window is a real k-mer of the same sequence
             if (!text_mask(t.mask, p + (u64)t.k)) known_out = (int)text_code(t.bits, p + (u64)t.k);
             if (!text_mask(t.mask, p - 1)) known_in = 3 - (int)text_code(t.bits, p - 1);
-        } else if (!xkmer_at<W>(t, p, &x)) return;
-        int max_c = any_dots ? 5 : 4;
-        int out = count_successors<W>(t, tb, x, max_c, known_out);
-        XKmer<W> r = xk_rc<W>(x, t.k);
-        int in = count_successors<W>(t, tb, r, max_c, known_in);
+            Key<W> rc = key_rc<W>(x.fwd, t.k);
+            out = count_real_successors<W>(t, tb, x.fwd, rc, known_out);
+            in = count_real_successors<W>(t, tb, rc, x.fwd, known_in);       // in(X) = out(rc X), and rc(rc X) = X
+            if (any_dots) {   // the '.' successor / predecessor (kmer_graph.rs:142,158): a dot k-mer, generic path
+                XKmer<W> y; u64 pos; bool rel;
+                if (xk_next<W>(x, t.k, 4, &y) && find_xk<W>(t, tb, y, &pos, &rel)) out++;
+                XKmer<W> r = xk_rc<W>(x, t.k);
+                if (xk_next<W>(r, t.k, 4, &y) && find_xk<W>(t, tb, y, &pos, &rel)) in++;
+            }
+        } else {
+            if (!xkmer_at<W>(t, p, &x)) return;
+            int max_c = any_dots ? 5 : 4;
+            out = count_successors<W>(t, tb, x, max_c, known_out);
+            XKmer<W> r = xk_rc<W>(x, t.k);
+            in = count_successors<W>(t, tb, r, max_c, known_in);
+        }
         kinfo[i] |= (u32)out | ((u32)in << KI_IN_SHIFT);
     }
 };
@@ -551,7 +587,7 @@ struct UnitigCtx {
 // a successor of a's last k-mer), stored BY SUCCESSOR SYMBOL so the path kernel can walk them ----------------
 template <int W> struct LinksFunctor {
     TextCtx t; Table tb; Novel nv; UnitigCtx uc; const u32* order; const u64* npos; int any_dots;
-    int32_t* links; u32* err;
+    int32_t* links; u64* wlinks; u32* err;    // wlinks: [length of the target:32][signed number:32], one load per step of a walk
     AC_D void operator()(u64 idx) const {
         u32 r = (u32)(idx >> 1);
         int side = (int)(idx & 1);           // 0: forward strand's end, 1: reverse strand's end
@@ -567,6 +603,7 @@ template <int W> struct LinksFunctor {
         int max_c = any_dots ? 5 : 4;
         for (int c = 0; c < 5; c++) {
             int32_t val = 0;
+            u32 tlen = 0;
             XKmer<W> y;
             u64 pos; bool rel_same;
             if (c < max_c && xk_next<W>(e, t.k, c, &y) && find_xk<W>(t, tb, y, &pos, &rel_same)) {
@@ -577,8 +614,10 @@ template <int W> struct LinksFunctor {
                 bool is_tail = (j + 1 == uc.n_novel) || uc.head[j + 1] != 0;
                 if (!(rel_same ? is_head : is_tail)) atomic_or32(err, 4u);   // successor of an end must start a unitig strand
                 val = strand ? (int32_t)(rv + 1) : -(int32_t)(rv + 1);
+                tlen = uc.ulen[rv];
             }
             links[idx * 5 + (u64)c] = val;
+            wlinks[idx * 5 + (u64)c] = ((u64)tlen << 32) | (u64)(u32)val;
         }
     }
 };
@@ -587,37 +626,35 @@ template <int W> struct LinksFunctor {
 // simplify_seqs positions, unitig.rs:136-147) ------------------------------------------------------------------
 // Every occurrence of a unitig's first k-mer is followed by the whole unitig, so a sequence
 // path is walked unitig by unitig: ONE table lookup locates the walker inside its first unitig, after that the
-// next unitig is links[(current strand end)][next text symbol] — an L2-resident gather, no hashing.  Thread tid
-// owns the unitig heads that fall into text positions [tid*PC, (tid+1)*PC); pass 1 counts them, an exclusive
-// scan turns counts into offsets, pass 2 writes them, so entries come out in text order without a sort.
+// next unitig (and its length) is wlinks[(current strand end)][next text symbol] — one gather, no hashing.  Thread tid
+// owns the unitig heads that fall into text positions [tid*PC, (tid+1)*PC) and writes them to its own staging slots;
+// an exclusive scan of the counts and a compaction put them in text order without a sort or a second walk.
 // `t` is the text being walked (this rank's sequences), `g` the text the graph was built from (the same text for a
 // single-device build, the union of all ranks' novel fragments for a sharded one): table slots point into `g`.
-template <int W, bool WRITE> struct PathWalkFunctor {
-    TextCtx t; TextCtx g; Table tb; Novel nv; UnitigCtx uc; const int32_t* links; u32 pc;
-    u64* cnt;                 // pass 1: out (entries per thread); pass 2: in (exclusive offsets)
-    int32_t* ent_val; u64* path_off; u32* depth; u32* minpos_fwd; u32* minpos_rev; u32* err;
-    AC_D void emit(u64& idx, u64 p, u32 s, u32 r, bool strand) const {
-        if (WRITE) {
-            ent_val[idx] = strand ? (int32_t)(r + 1) : -(int32_t)(r + 1);
-            atomic_add32(&depth[r], 1u);
-            u32 f = (u32)(p - t.seq_off[s]);
-            u32 other = t.seq_len[s] - uc.ulen[r] - f;   // position of the same occurrence on the opposite strand
-            // the words only ever decrease, so a plain (possibly stale) read that is already <= ours makes the atomic
-            // redundant: a unitig of depth d settles after a few of its d occurrences
-            u32 vf = strand ? f : other, vr = strand ? other : f;
-            if (vf < minpos_fwd[r]) atomic_min32(&minpos_fwd[r], vf);
-            if (vr < minpos_rev[r]) atomic_min32(&minpos_rev[r], vr);
-        }
-        idx++;
+template <int W> struct PathWalkFunctor {
+    TextCtx t; TextCtx g; Table tb; Novel nv; UnitigCtx uc; const u64* wlinks; u32 pc;
+    int32_t* stage; u64* cnt;         // stage[tid * pc + j]: j-th entry of walker tid; cnt[tid]: how many
+    u32* seq_tid; u32* seq_j;         // where each sequence's path starts: (walker, index in its staging slots)
+    u32* depth; u32* minpos_fwd; u32* minpos_rev; u32* err;
+    AC_D void emit(u64 tid, u32& j, u64 p, u32 s, u32 r, bool strand) const {
+        stage[tid * (u64)pc + j] = strand ? (int32_t)(r + 1) : -(int32_t)(r + 1);
+        j++;
+        atomic_add32(&depth[r], 1u);
+        u32 f = (u32)(p - t.seq_off[s]);
+        u32 other = t.seq_len[s] - uc.ulen[r] - f;   // position of the same occurrence on the opposite strand
+        // the words only ever decrease, so a plain (possibly stale) read that is already <= ours makes the atomic
+        // redundant: a unitig of depth d settles after a few of its d occurrences
+        u32 vf = strand ? f : other, vr = strand ? other : f;
+        if (vf < minpos_fwd[r]) atomic_min32(&minpos_fwd[r], vf);
+        if (vr < minpos_rev[r]) atomic_min32(&minpos_rev[r], vr);
     }
     AC_D void operator()(u64 tid) const {
         const int k = t.k;
         u64 p0 = tid * (u64)pc;
-        if (p0 >= t.n_text) { if (!WRITE) cnt[tid] = 0; return; }
+        u32 j = 0;
+        if (p0 >= t.n_text) { cnt[tid] = 0; return; }
         u64 p1 = p0 + (u64)pc;
         if (p1 > t.n_text) p1 = t.n_text;
-        u64 idx = WRITE ? cnt[tid] : 0;
-        const u64 idx0 = idx;
         // first sequence whose k-mer starts are not all below p0
         u32 lo = 0, hi = t.n_seqs;
         while (lo < hi) { u32 mid = lo + ((hi - lo) >> 1); if (t.seq_off[mid] + (u64)t.seq_len[mid] <= p0) lo = mid + 1; else hi = mid; }
@@ -627,36 +664,49 @@ template <int W, bool WRITE> struct PathWalkFunctor {
             u64 s_begin = t.seq_off[s], s_end = s_begin + (u64)t.seq_len[s];
             if (p < s_begin) p = s_begin;
             if (p >= p1) break;
-            if (WRITE && p == s_begin) path_off[s] = idx;
+            if (p == s_begin) { seq_tid[s] = (u32)tid; seq_j[s] = j; }
             // locate the walker: which unitig strand covers the k-mer at p, and where does that unitig end here?
             XKmer<W> x;
             u64 pos; bool rel_same;
             if (!xkmer_at<W>(t, p, &x) || !find_xk<W>(g, tb, x, &pos, &rel_same)) { atomic_or32(err, 8u); break; }
-            u32 j = novel_rank(nv, pos);
-            u32 u = uc.scan[j] - 1;
+            u32 jn = novel_rank(nv, pos);
+            u32 u = uc.scan[jn] - 1;
             u32 a = uc.ustart[u];
             u32 b = (u + 1 < uc.n_unitigs) ? uc.ustart[u + 1] : (u32)uc.n_novel;
             u32 r = uc.rank[u];
             bool strand = rel_same ? (uc.uorient[r] != 0) : (uc.uorient[r] == 0);
-            if (rel_same) { if (j == a) emit(idx, p, s, r, strand); p += (u64)(b - j); }
-            else { if (j == b - 1) emit(idx, p, s, r, strand); p += (u64)(j - a + 1); }
+            if (rel_same) { if (jn == a) emit(tid, j, p, s, r, strand); p += (u64)(b - jn); }
+            else { if (jn == b - 1) emit(tid, j, p, s, r, strand); p += (u64)(jn - a + 1); }
             // walk the links
             bool bad = false;
             while (p < s_end && p < p1) {
                 u64 e = p + (u64)k - 1;
                 u32 c = text_mask(t.mask, e) ? 4u : text_code(t.bits, e);
-                int32_t val = links[((u64)r * 2 + (strand ? 0 : 1)) * 5 + c];
+                u64 wl = wlinks[((u64)r * 2 + (strand ? 0 : 1)) * 5 + c];
+                int32_t val = (int32_t)(u32)wl;
                 if (val == 0) { atomic_or32(err, 16u); bad = true; break; }
                 strand = val > 0;
                 r = (u32)(strand ? val : -val) - 1;
-                emit(idx, p, s, r, strand);
-                p += (u64)uc.ulen[r];
+                emit(tid, j, p, s, r, strand);
+                p += wl >> 32;
             }
             if (bad) break;
             if (p >= s_end) s++; else break;   // p >= p1
         }
-        if (!WRITE) cnt[tid] = idx - idx0;
+        cnt[tid] = j;
     }
+};
+struct PathCompactFunctor {
+    const int32_t* stage; const u64* cnt; const u64* woff; u32 pc; int32_t* ent_val;
+    AC_HD void operator()(u64 tid) const {
+        u64 n = cnt[tid], o = woff[tid];
+        const int32_t* src = stage + tid * (u64)pc;
+        for (u64 j = 0; j < n; j++) ent_val[o + j] = src[j];
+    }
+};
+struct PathOffFunctor {
+    const u32* seq_tid; const u32* seq_j; const u64* woff; u64* path_off;
+    AC_HD void operator()(u64 s) const { path_off[s] = woff[seq_tid[s]] + (u64)seq_j[s]; }
 };
 
 // ---- K13: create_links' push order (unitig_graph.rs:248-286), a function of seed numbers only:
@@ -1358,7 +1408,9 @@ struct GraphBuilder::Impl {
     PackedText* G = &loc;      // the text the graph is built from
     BuildTimings* tm = nullptr;
     double t0 = 0, t_begin = 0;
-    void lap(double* acc) { stream_sync(); double t = now_s(); *acc += t - t0; t0 = t; }
+    // Stage timers need a stream synchronisation per stage (~20-40 us of idle GPU each, ~0.3 ms per build): they run only
+    // when asked for (ac_set_stage_timing); the event-timed insert kernel and total_device are always measured.
+    void lap(double* acc) { if (!g_stage_timing) return; stream_sync(); double t = now_s(); *acc += t - t0; t0 = t; }
 
     DBuf<u32> counters;        // [1] insert err, [3] link err, [4] path err, [5] self-mirror links, [6] fragment err, [7] pool overflow
     // k-mer table and novel list of G
@@ -1368,7 +1420,7 @@ struct GraphBuilder::Impl {
     u32 U = 0;
     DBuf<u32> kinfo, head, scan, ustart, order, rank, ulen;
     DBuf<u64> ustartpos, useq_off; DBuf<u8> uorient;
-    DBuf<int32_t> links;
+    DBuf<int32_t> links; DBuf<u64> wlinks;
     // per-occurrence quantities from the walk over loc
     DBuf<u32> depth, minpos_fwd, minpos_rev; DBuf<u64> path_off; DBuf<int32_t> ent_val; u64 n_ent = 0;
     DBuf<u8> fs0, fe0;
@@ -1589,8 +1641,8 @@ template <int W> void GraphBuilder::Impl::unitigs() {
     lap(&tm->rank);
 
     // K11 links by successor symbol
-    links.alloc((u64)U * 10);
-    launch((u64)U * 2, LinksFunctor<W>{t, tb, nv, uc, order.ptr(), npos.ptr(), g.any_dots, links.ptr(), counters.ptr() + 3});
+    links.alloc((u64)U * 10); wlinks.alloc((u64)U * 10);
+    launch((u64)U * 2, LinksFunctor<W>{t, tb, nv, uc, order.ptr(), npos.ptr(), g.any_dots, links.ptr(), wlinks.ptr(), counters.ptr() + 3});
     lap(&tm->links);
 }
 
@@ -1605,15 +1657,17 @@ template <int W> void GraphBuilder::Impl::walk() {
     depth.alloc(U, true); minpos_fwd.alloc(U); minpos_rev.alloc(U);
     minpos_fwd.fill_bytes(0xFF); minpos_rev.fill_bytes(0xFF);
     DBuf<u64> wcount(n_walkers + 1), woff(n_walkers + 1);
+    DBuf<int32_t> stage(n_walkers * PC);
+    DBuf<u32> seq_tid(loc.n_seqs), seq_j(loc.n_seqs);
     path_off.alloc((u64)loc.n_seqs + 1);
     wcount.fill_bytes(0);
-    launch(n_walkers, PathWalkFunctor<W, false>{t, g, tb, nv, uc, links.ptr(), PC, wcount.ptr(), nullptr, nullptr, nullptr, nullptr,
-                                               nullptr, counters.ptr() + 4});
+    launch(n_walkers, PathWalkFunctor<W>{t, g, tb, nv, uc, wlinks.ptr(), PC, stage.ptr(), wcount.ptr(), seq_tid.ptr(), seq_j.ptr(),
+                                        depth.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), counters.ptr() + 4});
     exclusive_scan_u64(wcount.ptr(), woff.ptr(), n_walkers + 1);
     n_ent = read_scalar(woff.ptr() + n_walkers);
     ent_val.alloc(n_ent);
-    launch(n_walkers, PathWalkFunctor<W, true>{t, g, tb, nv, uc, links.ptr(), PC, woff.ptr(), ent_val.ptr(), path_off.ptr(), depth.ptr(),
-                                              minpos_fwd.ptr(), minpos_rev.ptr(), counters.ptr() + 4});
+    launch(n_walkers, PathCompactFunctor{stage.ptr(), wcount.ptr(), woff.ptr(), PC, ent_val.ptr()});
+    launch(loc.n_seqs, PathOffFunctor{seq_tid.ptr(), seq_j.ptr(), woff.ptr(), path_off.ptr()});
     tm->n_path_entries = n_ent;
     copy_h2d(path_off.ptr() + loc.n_seqs, &n_ent, 8);
     fs0.alloc(U, true); fe0.alloc(U, true);

@@ -97,5 +97,7 @@ std::vector<uint8_t> layout_text(const std::vector<SeqView>& seqs, uint32_t k, s
                                  std::vector<uint32_t>* len, std::vector<uint16_t>* d1, std::vector<uint16_t>* d2);
 
 int max_supported_k();
+void set_stage_timing(bool on);   // per-stage timers (a stream sync per stage); off by default
+bool stage_timing();
 
 }  // namespace ac

@@ -181,19 +181,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if os.environ.get("BENCH_STAGE_TIMING"):      # experiment: keep the per-stage syncs inside the timed loop
+        lib.ac_set_stage_timing(C.c_int(1))
     for _ in range(args.warmup):
         step().close()
     barrier()
     t_start = time.perf_counter()
     tms = []
     g = None
+    step_s = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         if g is not None:
             g.close()
         g = step()
+        step_s.append(time.perf_counter() - ts)      # the build call returns with the graph in host RAM
         tms.append(g.timings())
     barrier()
     elapsed = time.perf_counter() - t_start
+    # stage breakdown from two extra, untimed, instrumented builds (a stream sync per stage costs ~0.3 ms per build)
+    lib.ac_set_stage_timing(C.c_int(1))
+    stage_tms = []
+    for _ in range(2):
+        g.close()
+        g = step()
+        stage_tms.append(g.timings())
+    lib.ac_set_stage_timing(C.c_int(0))
+    barrier()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -220,7 +234,7 @@ def main():
             pj = json.loads(pmc.read_text())
             traffic = pj["traffic_bytes_per_build"]
             traffic_src = "profiles/pmc_traffic.json (rocprofv3 PMC passes; FETCH_SIZE x2 per the gfx950 calibration, + WRITE_SIZE)"
-        stage = {key: sum(t[key] for t in tms) / len(tms) for key in
+        stage = {key: sum(t[key] for t in stage_tms) / len(stage_tms) for key in
                  ("pack", "insert", "collect_sort", "degree", "segment", "minkey", "rank", "links", "paths", "seqs", "analysis", "expand", "finalize", "d2h",
                   "total_device") + (("fragments", "union_pack", "union_insert") if mode == "sharded" else ())}
         sharding = {"single": "one device", "independent": "by assembly set, one unrelated compress job per GPU",
@@ -242,7 +256,9 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": ins_ms,
                          "whole_path_frac": alg_bytes / (elapsed / args.steps) / HBM_PEAK},
-            "stages_s": stage,
+            "total_device_timed_ms": sum(t["total_device"] for t in tms) / len(tms) * 1e3,
+            "step_ms": {"min": min(step_s) * 1e3, "median": sorted(step_s)[len(step_s) // 2] * 1e3, "max": max(step_s) * 1e3},
+            "stages_s": stage, "stages_note": "from 2 extra untimed builds with per-stage stream syncs (total_device there includes them)",
             "graph": {**g.stats_post, "kmers": g.kmer_count, "distinct_canonical": tms[-1]["n_distinct"],
                       "path_entries": tms[-1]["n_path_entries"], "table_capacity": tms[-1]["table_capacity"],
                       "simplify_passes": tms[-1]["simplify_passes"]},

@@ -41,7 +41,9 @@ typedef struct { uint32_t pos; uint16_t seq_id_and_strand; } ac_position; /* pos
 typedef struct { uint32_t a; uint8_t a_fwd; uint32_t b; uint8_t b_fwd; } ac_link;
 typedef struct { uint32_t unitigs; uint64_t links_one_way; uint64_t total_length; } ac_stats;
 
-/* Seconds spent in each stage of the last build (device stages are bracketed by stream syncs). */
+/* Seconds spent in each stage of the last build.  The per-stage fields are only filled while stage timing is on
+ * (ac_set_stage_timing(1): one stream synchronisation per stage, ~0.3 ms per build); total_device, insert_kernel_ms and
+ * the counts are always filled. */
 typedef struct {
     double h2d, pack, insert, collect_sort, degree, segment, minkey, rank, paths, links, seqs, d2h;
     double total_device; /* pack .. d2h: the whole replaced region */
@@ -175,6 +177,7 @@ int ac_compress_seqs(uint32_t k, const ac_seqs*, int device, ac_graph** out);
 int ac_compress_dir(const char* assemblies_dir, const char* autocycler_dir, uint32_t k, uint32_t max_contigs,
                     int threads, int device, ac_graph** graph_out, double* times);
 
+void ac_set_stage_timing(int on);   /* off by default */
 const char* ac_last_error(void);
 int ac_device_count(void);       /* number of visible HIP devices (0 if none / no driver) */
 uint32_t ac_max_kmer(void);      /* largest --kmer this build supports */

@@ -95,6 +95,14 @@ class Arena {
             blocks_.back().used = 0;
         }
     }
+    // First build of a process: one block of about the size the build will need, so that neither this build grows the
+    // arena block by block nor the next one pays for coalescing (hipFree + hipMalloc of gigabytes).
+    void reserve(size_t bytes) {
+        if (capacity() >= bytes || total_used() != 0) return;
+        release_all();
+        Block b; b.cap = bytes; b.used = 0; b.p = raw_alloc(bytes);
+        blocks_.push_back(b);
+    }
     void release_all() {
         for (auto& b : blocks_) raw_free(b.p);
         blocks_.clear();
@@ -153,6 +161,7 @@ class PinnedPool {
         }
         if (!b.p) {
             size_t cap = bytes + bytes / 8 + 4096;
+            if (getenv("AC_DEBUG_ARENA")) fprintf(stderr, "pinned pool: new block of %zu bytes (%zu free entries)\n", cap, free_.size());
 #ifdef AC_EMU
             b.p = malloc(cap);
             if (!b.p) throw DeviceError("out of host memory");

@@ -1358,6 +1358,9 @@ static void renumber_sort(DBuf<u32>& order, u32 U, const u32* len, const u64* of
 }
 
 static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
+// Device memory one build of an n_text-byte text needs, roughly: packed text + bitmaps (~0.6 B/position), staging slots
+// of the path walk (4 B/position), k-mer table and per-k-mer arrays (sized by distinct content), unitig-sized buffers.
+static size_t arena_estimate(u64 n_text, bool owns_text) { return (size_t)n_text * (owns_text ? 8 : 7) + ((size_t)768 << 20); }
 // Tuning knobs of the insert (environment, read once): AC_INSERT_VARIANT=1 selects the thread-per-chunk kernel,
 // AC_INSERT_CHUNK the largest wavefront chunk (positions).
 static int insert_variant() { static int v = [] { const char* e = getenv("AC_INSERT_VARIANT"); return e ? atoi(e) : 0; }(); return v; }
@@ -1429,6 +1432,7 @@ struct GraphBuilder::Impl {
 
     void begin(BuildTimings* t) {
         tm = t; t_begin = t0 = now_s();
+
         counters.alloc(8); counters.fill_bytes(0);
     }
     void check_sizes(const PackedText& t) const {
@@ -1853,6 +1857,8 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             throw DeviceError("internal error: path length mismatch for sequence " + std::to_string(s + 1));
     lap(&tm->d2h);
     tm->total_device = now_s() - t_begin;
+    if (getenv("AC_DEBUG_ARENA"))
+        fprintf(stderr, "arena: used %.1f MB of %.1f MB (n_text %.1f MB)\n", Arena::device().total_used() / 1e6, Arena::device().capacity() / 1e6, loc.n_text / 1e6);
 }
 
 // ---- GraphBuilder ------------------------------------------------------------------------------------------------
@@ -1875,6 +1881,7 @@ void GraphBuilder::set_sequences_host(const std::vector<SeqView>& seqs) {
     std::vector<uint64_t> off; std::vector<uint32_t> len; std::vector<uint16_t> d1, d2;
     std::vector<uint8_t> text = layout_text(seqs, impl_->k, &off, &len, &d1, &d2);
     impl_->loc.n_text = text.size();
+    Arena::device().reserve(arena_estimate(text.size(), true));
     impl_->text_owned.alloc(text.size());
     copy_h2d(impl_->text_owned.ptr(), text.data(), text.size());
     impl_->loc.d_text = impl_->text_owned.ptr();
@@ -1886,6 +1893,7 @@ void GraphBuilder::set_text_device(const uint8_t* d_text, uint64_t n_text, const
                                    const std::vector<uint16_t>& d2) {
     impl_->loc.d_text = d_text;
     impl_->loc.n_text = n_text;
+    Arena::device().reserve(arena_estimate(n_text, false));
     impl_->loc.set_table(off, len, d1, d2);
 }
 

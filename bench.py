@@ -85,7 +85,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--assemblies", type=int, default=96)
     ap.add_argument("--genome", type=int, default=5_000_000)
     ap.add_argument("--plasmid", type=int, default=100_000)
@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--cpu-sample", type=str, default="4x1000000")
     ap.add_argument("--mode", choices=["auto", "single", "sharded", "independent"], default="auto",
                     help="auto: single-device build at N=1, one sharded job at N>1")
+    ap.add_argument("--init-builds", type=int, default=2, help="untimed builds before the warmup (one-time process initialisation)")
     ap.add_argument("--gather-paths", action="store_true",
                     help="sharded mode: gather the paths of all sequences to rank 0 (default: every rank keeps its own P lines)")
     args = ap.parse_args()
@@ -181,6 +182,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # One-time initialisation outside both the warmup and the timed region: the first two builds of a process load
+    # the code objects, create the pinned result pool and the copy stream (60-180 ms and ~20 ms instead of ~9 ms).
+    for _ in range(args.init_builds):
+        step().close()
     if os.environ.get("BENCH_STAGE_TIMING"):      # experiment: keep the per-stage syncs inside the timed loop
         lib.ac_set_stage_timing(C.c_int(1))
     for _ in range(args.warmup):
@@ -257,6 +262,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": ins_ms,
                          "whole_path_frac": alg_bytes / (elapsed / args.steps) / HBM_PEAK},
             "total_device_timed_ms": sum(t["total_device"] for t in tms) / len(tms) * 1e3,
+            "step_ms_list": [round(x * 1e3, 2) for x in step_s],
             "step_ms": {"min": min(step_s) * 1e3, "median": sorted(step_s)[len(step_s) // 2] * 1e3, "max": max(step_s) * 1e3},
             "stages_s": stage, "stages_note": "from 2 extra untimed builds with per-stage stream syncs (total_device there includes them)",
             "graph": {**g.stats_post, "kmers": g.kmer_count, "distinct_canonical": tms[-1]["n_distinct"],
@@ -267,6 +273,8 @@ def main():
         if mode == "sharded":
             line["sharded"] = {**last_info, "fragments_rank0": tms[-1]["n_fragments"], "fragment_bytes_rank0": tms[-1]["fragment_bytes"],
                                "local_distinct_rank0": tms[-1]["n_local_distinct"]}
+        if os.environ.get("BENCH_STAGE_TIMING"):
+            line["timed_stage_ms"] = [{kk: round(vv * 1e3, 2) for kk, vv in t.items() if isinstance(vv, float) and vv > 2e-4 and kk != "insert_kernel_ms"} for t in tms]
         if not args.no_cpu_baseline and world == 1:
             a, b2 = args.cpu_sample.split("x")
             line["cpu_baseline"] = cpu_baseline(k, int(a), int(b2))

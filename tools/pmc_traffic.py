@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json from the two per-kernel PMC summaries of tools/pmc_round.sh (FETCH_SIZE and WRITE_SIZE passes,
+values in KiB per build): HBM-side bytes per build of the kernel bench.py prices the roofline on, calibrated on PackFunctor
+whose bytes are known exactly (reads n_text bytes, writes 0.375 n_text).
+
+    python tools/pmc_traffic.py FETCH.csv WRITE.csv N_TEXT TAG > profiles/pmc_traffic.json"""
+import csv
+import json
+import sys
+
+
+def load(path):
+    return {r["Name"]: float(r[[c for c in r if c.endswith("_per_build")][0]]) * 1024 for r in csv.DictReader(open(path))}
+
+
+def main(fetch_csv, write_csv, n_text, tag):
+    f, w = load(fetch_csv), load(write_csv)
+    pick = lambda d, pat: sum(v for k, v in d.items() if pat in k)
+    n_text = int(n_text)
+    pf, pw = pick(f, "PackFunctor"), pick(w, "PackFunctor")
+    fcal, wcal = pf / n_text, pw / (0.375 * n_text)
+    fcorr = 2.0 if 0.4 < fcal < 0.6 else 1.0     # gfx950: 128-B requests tallied at 64 B (MI355X_MICROARCH.md, HBM section)
+    kf, kw = pick(f, "insert_wave_kernel"), pick(w, "insert_wave_kernel")
+    table = {k: {"fetch_raw": f.get(k, 0.0), "write_raw": w.get(k, 0.0), "hbm_side_bytes": f.get(k, 0.0) * fcorr + w.get(k, 0.0)}
+             for k in sorted(set(f) | set(w), key=lambda k: -(f.get(k, 0.0) * fcorr + w.get(k, 0.0)))[:12]}
+    print(json.dumps({
+        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), python bench.py --steps 2 "
+                  f"--warmup 1 --no-cpu-baseline on MI355X; profiles/{tag}_pmc_*_configC.csv",
+        "kernel": "insert_wave_kernel<2> (8 phase launches per build, summed)",
+        "fetch_size_raw_bytes": kf, "write_size_raw_bytes": kw,
+        "calibration": {"kernel": "functor_kernel<PackFunctor>: reads n_text bytes with 16 B/lane loads, writes 0.375*n_text bytes",
+                        "n_text": n_text, "fetch_raw_over_known": fcal, "write_raw_over_known": wcal},
+        "fetch_correction": fcorr, "write_correction": 1.0,
+        "traffic_bytes_per_build": kf * fcorr + kw,
+        "per_kernel_per_build": table,
+        "note": "FETCH_SIZE on gfx950 tallies 128-B requests at 64 B (confirmed here on PackFunctor), so fetches are doubled; "
+                "the doubled figure is an upper bound for kernels whose reads are narrow and random (lower bound = raw)."}, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:5])

@@ -327,6 +327,25 @@ int ac_path_counts(const ac_graph* g, uint64_t* counts) {   // entries per seque
     return 0;
 }
 
+// sequence_end_repair (compress.rs:202-270) on a device-resident text of padded, unrepaired sequences.
+int ac_end_repair_device(uint32_t k, void* d_text, uint64_t n_text, const uint64_t* seq_off, const uint32_t* seq_len,
+                         uint16_t* seq_d1, uint16_t* seq_d2, uint32_t n_seqs, int device, double* seconds, uint64_t* n_matches) {
+    return guarded([&] {
+        if (!d_text || n_seqs == 0) throw DeviceError("no sequences found in input assemblies");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
+        select_device(device);
+        std::vector<uint64_t> off(seq_off, seq_off + n_seqs);
+        std::vector<uint32_t> len(seq_len, seq_len + n_seqs);
+        std::vector<uint16_t> d1(seq_d1, seq_d1 + n_seqs), d2(seq_d2, seq_d2 + n_seqs);
+        RepairTimings tm;
+        end_repair_device(k, (uint8_t*)d_text, n_text, off, len, &d1, &d2, &tm);
+        for (uint32_t i = 0; i < n_seqs; i++) { seq_d1[i] = d1[i]; seq_d2[i] = d2[i]; }
+        if (seconds) *seconds = tm.total;
+        if (n_matches) *n_matches = tm.matches;
+    });
+}
+
 uint64_t ac_kmer_count(const ac_graph* g) { return g->g.n_kmers; }
 ac_stats ac_stats_pre(const ac_graph* g) { return ac_stats{g->g.pre.unitigs, g->g.pre.links_one_way, g->g.pre.total_length}; }
 ac_stats ac_stats_post(const ac_graph* g) { return ac_stats{g->g.post.unitigs, g->g.post.links_one_way, g->g.post.total_length}; }
@@ -473,13 +492,44 @@ int ac_compress_dir(const char* assemblies_dir, const char* autocycler_dir, uint
         std::error_code ec;
         fs::create_directories(autocycler_dir, ec);
         if (ec) throw UserError(std::string("failed to create directory ") + autocycler_dir + "\n" + ec.message());
+        // load (host) -> text layout -> H2D -> end repair on the device text -> graph build from the same buffer
+        const bool host_repair = getenv("AC_HOST_REPAIR") != nullptr;      // the host implementation, kept for comparison
         ac_seqs s;
-        s.lr = load_sequences(assemblies_dir, k, max_contigs, threads);
+        s.lr = load_sequences(assemblies_dir, k, max_contigs, threads, host_repair);
         s.make_views();
         double t0 = now();
         ac_graph* g = nullptr;
-        if (ac_compress_build(k, s.lr.assembly_count, s.views.data(), (uint32_t)s.views.size(), device, &g) != 0)
-            throw DeviceError(g_err);
+        if (host_repair) {
+            if (ac_compress_build(k, s.lr.assembly_count, s.views.data(), (uint32_t)s.views.size(), device, &g) != 0)
+                throw DeviceError(g_err);
+        } else {
+            const uint32_t n = (uint32_t)s.views.size();
+            if (n == 0) throw DeviceError("no sequences found in input assemblies");
+            std::vector<SeqView> v(n);
+            std::vector<uint16_t> ids(n);
+            for (uint32_t i = 0; i < n; i++) { v[i] = SeqView{s.views[i].fwd, s.views[i].length}; ids[i] = s.views[i].id; }
+            std::vector<uint64_t> off; std::vector<uint32_t> len; std::vector<uint16_t> d1, d2;
+            std::vector<uint8_t> text = layout_text(v, k, &off, &len, &d1, &d2);
+            select_device(device);
+#ifdef AC_EMU
+            struct DevText { void* p = nullptr; ~DevText() { free(p); } } dt;
+            dt.p = malloc(text.size());
+            if (!dt.p) throw DeviceError("out of memory");
+            memcpy(dt.p, text.data(), text.size());
+#else
+            struct DevText { void* p = nullptr; ~DevText() { if (p) (void)hipFree(p); } } dt;
+            AC_HIP_CHECK(hipMalloc(&dt.p, text.size()));
+            AC_HIP_CHECK(hipMemcpy(dt.p, text.data(), text.size(), hipMemcpyHostToDevice));
+#endif
+            double secs = 0;
+            if (ac_end_repair_device(k, dt.p, text.size(), off.data(), len.data(), d1.data(), d2.data(), n, device, &secs, nullptr) != 0)
+                throw DeviceError(g_err);
+            s.lr.repair_seconds = now() - t0;        // H2D of the text + the repair itself
+            t0 = now();
+            if (ac_compress_build_device(k, s.lr.assembly_count, dt.p, text.size(), off.data(), len.data(), ids.data(), d1.data(), d2.data(),
+                                         n, device, &g) != 0)
+                throw DeviceError(g_err);
+        }
         std::unique_ptr<ac_graph> guard(g);
         double t1 = now();
         std::vector<SeqMeta> meta(s.lr.seqs.size());

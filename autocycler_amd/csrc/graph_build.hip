@@ -15,6 +15,9 @@
 #include "graph_build.hpp"
 
 #include <chrono>
+#include <map>
+#include <string>
+#include <algorithm>
 
 #include "device_rt.hpp"
 
@@ -2011,6 +2014,227 @@ uint64_t GraphBuilder::path_entry_count() const { return impl_->n_ent; }
 void GraphBuilder::paths_export(void* d_out) {
     copy_d2d(d_out, impl_->ent_val.ptr(), impl_->n_ent * 4);
     stream_sync();
+}
+
+// =============================================================================================================
+// sequence_end_repair on the device (compress.rs:202-270; SURVEY.md §8 "next" row f-1).
+// The reference runs 2S regexes (one per sequence end: k/2 wildcards next to k/2 literal bases) over all 2S forward and
+// reverse sequences: 4·S·B regex bytes.  Here the S·2 literals (and their reverse complements, which stand for the
+// reverse haystacks) go into one small hash table and ONE pass over the packed forward text finds every occurrence;
+// the few thousand hits are turned into leftmost non-overlapping matches, tallied and chosen (find_best_match: fewest
+// dots, most frequent, first alphabetically) on the host, and the winners are patched into the device text in place.
+struct WindowGatherFunctor {     // m bytes from each listed text position
+    const u8* text; u64 n_text; const u64* pos; u32 m; u64 n; u8* out;
+    AC_HD void operator()(u64 idx) const {
+        u64 w = idx / m, t = idx % m;
+        u64 p = pos[w] + t;
+        out[idx] = p < n_text ? text[p] : (u8)'$';
+    }
+};
+struct WindowPatchFunctor {      // the reverse: m bytes into each listed text position
+    u8* text; const u64* pos; u32 m; const u8* src;
+    AC_HD void operator()(u64 idx) const { text[pos[idx / m] + idx % m] = src[idx]; }
+};
+struct EndScanFunctor {          // a thread owns the literal-length windows starting in 256 consecutive text positions
+    const u64* bits; const u64* mask; u64 n_text; int lit;
+    const u64* filter; const u64* tkeys; const u32* tent; u64 tmask;
+    u64* hits; u32 cap; u32* n_hits;
+    AC_D void operator()(u64 tid) const {
+        u64 p0 = tid * 256, p1 = p0 + 256;
+        if (p1 > n_text) p1 = n_text;
+        u64 bend = p1 + (u64)lit - 1;
+        if (bend > n_text) bend = n_text;
+        const Key<2> km = key_kmask<2>(lit);
+        Key<2> key; key.w[0] = 0; key.w[1] = 0;
+        int run = 0;
+        for (u64 b = p0; b < bend; b++) {
+            if (text_mask(mask, b)) { run = 0; continue; }
+            key_roll_fwd<2>(key, text_code(bits, b), km);
+            if (++run < lit) continue;
+            u64 h = key_hash<2>(key);
+            u64 fb = h >> 44;                                       // 2^20-bit filter
+            if (!((filter[fb >> 6] >> (fb & 63)) & 1)) continue;
+            for (u64 s = h & tmask;; s = (s + 1) & tmask) {
+                u32 e = tent[s];
+                if (e == 0xFFFFFFFFu) break;
+                if (tkeys[2 * s] == key.w[0] && tkeys[2 * s + 1] == key.w[1]) {
+                    u32 i = atomic_add32(n_hits, 1u);
+                    if (i < cap) hits[i] = ((u64)e << 40) | (b + 1 - (u64)lit);
+                    break;
+                }
+            }
+        }
+    }
+};
+
+static inline char repair_comp(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c == '.' ? '.' : 'N'; }   // misc.rs:358-376
+
+void end_repair_device(uint32_t k, uint8_t* d_text, uint64_t n_text, const std::vector<uint64_t>& off, const std::vector<uint32_t>& len,
+                       std::vector<uint16_t>* d1, std::vector<uint16_t>* d2, RepairTimings* tm) {
+    double t_begin = now_s();
+    const u32 S = (u32)off.size();
+    const u32 m = k - 1, h = k / 2, lit = m - h;
+    if (tm) *tm = RepairTimings();
+    if (m == 0 || S == 0) return;
+    if (lit > 64 || lit == 0) throw DeviceError("end repair: unsupported k");
+    if (n_text >= POS_MASK) throw DeviceError("input too large for 40-bit text positions");
+    Arena::device().reset();     // nothing of an earlier build is alive while the repair runs
+    Arena::device().reserve(arena_estimate(n_text, false));
+    auto plen = [&](u32 s) { return (u64)len[s] + k - 1; };
+
+    // the 2S pattern windows: first / last m bytes of every padded sequence (pattern 2s = start, 2s+1 = end)
+    std::vector<u64> wpos(2 * (size_t)S);
+    for (u32 s = 0; s < S; s++) { wpos[2 * s] = off[s]; wpos[2 * s + 1] = off[s] + plen(s) - m; }
+    DBuf<u64> d_wpos(2 * (size_t)S);
+    DBuf<u8> d_win((size_t)2 * S * m);
+    copy_h2d(d_wpos.ptr(), wpos.data(), wpos.size() * 8);
+    launch((u64)2 * S * m, WindowGatherFunctor{d_text, n_text, d_wpos.ptr(), m, (u64)2 * S, d_win.ptr()});
+    std::vector<u8> win((size_t)2 * S * m);
+    copy_d2h(win.data(), d_win.ptr(), win.size());
+
+    // literal table: key -> entry; entry -> the (pattern, orientation) pairs with that literal
+    struct Use { u32 pid; u32 rev; };
+    std::vector<std::vector<Use>> uses;
+    std::vector<Key<2>> ekeys;
+    auto code_of = [](u8 ch, bool* ok) -> u32 { if (!(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T')) *ok = false; return ((ch >> 1) ^ (ch >> 2)) & 3u; };
+    const Key<2> km = key_kmask<2>((int)lit);
+    u64 tcap = next_pow2((u64)8 * S + 16);
+    std::vector<u64> tkeys(2 * tcap, 0); std::vector<u32> tent(tcap, 0xFFFFFFFFu);
+    std::vector<u64> filter((1u << 20) / 64, 0);
+    auto add = [&](const Key<2>& key, u32 pid, u32 rev) {
+        u64 hh = key_hash<2>(key);
+        for (u64 s = hh & (tcap - 1);; s = (s + 1) & (tcap - 1)) {
+            if (tent[s] == 0xFFFFFFFFu) {
+                tent[s] = (u32)ekeys.size(); tkeys[2 * s] = key.w[0]; tkeys[2 * s + 1] = key.w[1];
+                ekeys.push_back(key); uses.push_back({});
+                u64 fb = hh >> 44; filter[fb >> 6] |= 1ULL << (fb & 63);
+            }
+            if (tkeys[2 * s] == key.w[0] && tkeys[2 * s + 1] == key.w[1]) { uses[tent[s]].push_back(Use{pid, rev}); return; }
+        }
+    };
+    for (u32 pid = 0; pid < 2 * S; pid++) {
+        const u8* w = &win[(size_t)pid * m];
+        const u8* L = (pid & 1) ? w : w + h;          // start pattern: h wildcards then the literal; end pattern: literal first
+        Key<2> key; key.w[0] = key.w[1] = 0;
+        bool ok = true;
+        for (u32 i = 0; i < lit; i++) key_roll_fwd<2>(key, code_of(L[i], &ok), km);
+        if (!ok) throw DeviceError("end repair: a sequence end holds something else than bases");
+        add(key, pid, 0);
+        add(key_rc<2>(key, (int)lit), pid, 1);         // an occurrence of rc(L) in a forward sequence = an occurrence of L in its reverse
+    }
+    if (ekeys.size() >= (1u << 24)) throw DeviceError("end repair: too many patterns");
+
+    // one pass over the packed text
+    PackedText pt;
+    pt.d_text = d_text; pt.n_text = n_text;
+    pt.pack();
+    DBuf<u64> d_filter(filter.size()), d_tkeys(tkeys.size()); DBuf<u32> d_tent(tent.size()), d_nhits(1);
+    copy_h2d(d_filter.ptr(), filter.data(), filter.size() * 8);
+    copy_h2d(d_tkeys.ptr(), tkeys.data(), tkeys.size() * 8);
+    copy_h2d(d_tent.ptr(), tent.data(), tent.size() * 4);
+    u32 cap = 1u << 20;
+    std::vector<u64> hits;
+    double t_scan = now_s();
+    for (;;) {
+        DBuf<u64> d_hits(cap);
+        d_nhits.fill_bytes(0);
+        launch((n_text + 255) / 256, EndScanFunctor{pt.bits.ptr(), pt.mask.ptr(), n_text, (int)lit, d_filter.ptr(), d_tkeys.ptr(), d_tent.ptr(),
+                                                   tcap - 1, d_hits.ptr(), cap, d_nhits.ptr()});
+        u32 n = read_scalar(d_nhits.ptr());
+        if (n > cap) { if (n >= 0xFFFFFFF0u) throw DeviceError("end repair: too many literal occurrences"); cap = n; continue; }
+        hits.resize(n);
+        copy_d2h(hits.data(), d_hits.ptr(), (size_t)n * 8);
+        break;
+    }
+    if (tm) { tm->scan_ms = (now_s() - t_scan) * 1e3; tm->hits = hits.size(); tm->patterns = 2 * S; }
+
+    // hits -> candidate matches (pattern, haystack, start) in haystack coordinates (regex semantics: the h wildcards may
+    // cover dots, the literal only bases; the match must lie inside the haystack)
+    struct Cand { u32 pid; u32 hay; u64 i; u64 fpos; };      // fpos: text position of the forward window the match spells
+    std::vector<Cand> cands;
+    for (u64 hv : hits) {
+        u32 e = (u32)(hv >> 40);
+        u64 jt = hv & POS_MASK;
+        u32 s = (u32)(std::upper_bound(off.begin(), off.end(), jt) - off.begin()) - 1;
+        u64 jj = jt - off[s], pl = plen(s);
+        if (jj + lit > pl) continue;      // cannot happen: masked separators end every run
+        for (const Use& u : uses[e]) {
+            u64 j = u.rev ? pl - jj - lit : jj;                 // literal start in the haystack's own coordinates
+            bool start_pat = (u.pid & 1) == 0;
+            if (start_pat && j < h) continue;
+            u64 i = start_pat ? j - h : j;
+            if (i + m > pl) continue;
+            u64 f = u.rev ? pl - i - m : i;                     // where the forward sequence spells this match
+            cands.push_back(Cand{u.pid, 2 * s + u.rev, i, off[s] + f});
+        }
+    }
+    std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) {
+        if (a.pid != b.pid) return a.pid < b.pid;
+        if (a.hay != b.hay) return a.hay < b.hay;
+        return a.i < b.i;
+    });
+    std::vector<Cand> acc;       // find_iter: leftmost, non-overlapping, per (regex, haystack)
+    for (size_t a = 0; a < cands.size();) {
+        size_t b = a;
+        u64 next_free = 0;
+        while (b < cands.size() && cands[b].pid == cands[a].pid && cands[b].hay == cands[a].hay) {
+            if (cands[b].i >= next_free) { acc.push_back(cands[b]); next_free = cands[b].i + m; }
+            b++;
+        }
+        a = b;
+    }
+    if (tm) tm->matches = acc.size();
+
+    // the matched strings
+    std::vector<u64> apos(acc.size());
+    for (size_t i = 0; i < acc.size(); i++) apos[i] = acc[i].fpos;
+    std::vector<u8> astr(acc.size() * (size_t)m);
+    if (!acc.empty()) {
+        DBuf<u64> d_apos(acc.size()); DBuf<u8> d_astr(astr.size());
+        copy_h2d(d_apos.ptr(), apos.data(), apos.size() * 8);
+        launch((u64)astr.size(), WindowGatherFunctor{d_text, n_text, d_apos.ptr(), m, (u64)acc.size(), d_astr.ptr()});
+        copy_d2h(astr.data(), d_astr.ptr(), astr.size());
+    }
+    // find_best_match (compress.rs:239-270) per pattern, then the splices (compress.rs:225,234)
+    std::vector<u8> patch((size_t)2 * S * m);
+    size_t a = 0;
+    for (u32 pid = 0; pid < 2 * S; pid++) {
+        std::map<std::string, u32> tally;
+        while (a < acc.size() && acc[a].pid == pid) {
+            std::string str((const char*)&astr[a * (size_t)m], m);
+            if (acc[a].hay & 1) { std::reverse(str.begin(), str.end()); for (char& c : str) c = repair_comp(c); }
+            tally[str]++;
+            a++;
+        }
+        if (tally.empty()) throw DeviceError("internal error: an end-repair pattern does not match its own sequence");
+        const std::string* best = nullptr; size_t best_dots = 0; u32 best_cnt = 0;
+        for (auto& kv : tally) {   // std::map iterates alphabetically: the first of equals wins the tie
+            size_t dots = (size_t)std::count(kv.first.begin(), kv.first.end(), '.');
+            if (!best || dots < best_dots || (dots == best_dots && kv.second > best_cnt)) { best = &kv.first; best_dots = dots; best_cnt = kv.second; }
+        }
+        memcpy(&patch[(size_t)pid * m], best->data(), m);
+    }
+    // starts first, then ends (the reference splices in that order)
+    DBuf<u8> d_patch(patch.size());
+    copy_h2d(d_patch.ptr(), patch.data(), patch.size());
+    for (int which = 0; which < 2; which++) {
+        std::vector<u64> ppos(S); std::vector<u8> psrc((size_t)S * m);
+        for (u32 s = 0; s < S; s++) { ppos[s] = wpos[2 * s + which]; memcpy(&psrc[(size_t)s * m], &patch[(size_t)(2 * s + which) * m], m); }
+        DBuf<u64> d_ppos(S); DBuf<u8> d_psrc(psrc.size());
+        copy_h2d(d_ppos.ptr(), ppos.data(), ppos.size() * 8);
+        copy_h2d(d_psrc.ptr(), psrc.data(), psrc.size());
+        launch((u64)S * m, WindowPatchFunctor{d_text, d_ppos.ptr(), m, d_psrc.ptr()});
+        stream_sync();
+    }
+    // surviving dots (what layout_text would count on the repaired sequences)
+    for (u32 s = 0; s < S; s++) {
+        const u8* st = &patch[(size_t)(2 * s) * m]; const u8* en = &patch[(size_t)(2 * s + 1) * m];
+        u16 a1 = 0, b1 = 0;
+        while (a1 < m && st[a1] == '.') a1++;
+        while (b1 < m && en[m - 1 - b1] == '.') b1++;
+        (*d1)[s] = a1; (*d2)[s] = b1;
+    }
+    if (tm) tm->total = now_s() - t_begin;
 }
 
 }  // namespace ac

@@ -96,6 +96,12 @@ class GraphBuilder {
 std::vector<uint8_t> layout_text(const std::vector<SeqView>& seqs, uint32_t k, std::vector<uint64_t>* off,
                                  std::vector<uint32_t>* len, std::vector<uint16_t>* d1, std::vector<uint16_t>* d2);
 
+// sequence_end_repair (compress.rs:202-270) on the device.  d_text: the PADDED, unrepaired sequences in the text layout above;
+// it is patched in place and d1 / d2 (surviving dots) are updated.
+struct RepairTimings { double total = 0, scan_ms = 0; uint64_t hits = 0, matches = 0; uint32_t patterns = 0; };
+void end_repair_device(uint32_t k, uint8_t* d_text, uint64_t n_text, const std::vector<uint64_t>& off, const std::vector<uint32_t>& len,
+                       std::vector<uint16_t>* d1, std::vector<uint16_t>* d2, RepairTimings* tm);
+
 int max_supported_k();
 void set_stage_timing(bool on);   // per-stage timers (a stream sync per stage); off by default
 bool stage_timing();

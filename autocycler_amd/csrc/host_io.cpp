@@ -233,7 +233,7 @@ void sequence_end_repair(std::vector<LoadedSeq>& seqs, uint32_t k, int threads) 
 }
 
 // compress.rs:84-133
-LoadResult load_sequences(const std::string& assemblies_dir, uint32_t k, uint32_t max_contigs, int threads) {
+LoadResult load_sequences(const std::string& assemblies_dir, uint32_t k, uint32_t max_contigs, int threads, bool repair) {
     LoadResult lr;
     double t0 = now_s();
     std::vector<std::string> assemblies = find_all_assemblies(assemblies_dir);
@@ -278,7 +278,7 @@ LoadResult load_sequences(const std::string& assemblies_dir, uint32_t k, uint32_
                         std::to_string(max_contigs) + "). Are your input assemblies fragmented or contaminated?");
     }
     double t1 = now_s();
-    sequence_end_repair(lr.seqs, k, threads);
+    if (repair) sequence_end_repair(lr.seqs, k, threads);
     lr.load_seconds = t1 - t0;
     lr.repair_seconds = now_s() - t1;
     return lr;

@@ -34,7 +34,8 @@ std::vector<std::string> find_all_assemblies(const std::string& dir);
 std::vector<std::array<std::string, 3>> load_fasta(const std::string& filename);   // (name, header, sequence)
 void pad_sequence(LoadedSeq* s, const std::string& seq, uint32_t k);               // sequence.rs:31-59
 void sequence_end_repair(std::vector<LoadedSeq>& seqs, uint32_t k, int threads);
-LoadResult load_sequences(const std::string& assemblies_dir, uint32_t k, uint32_t max_contigs, int threads);
+// repair = false: the padded sequences as Sequence::new_with_seq leaves them (the device end repair then works on the text)
+LoadResult load_sequences(const std::string& assemblies_dir, uint32_t k, uint32_t max_contigs, int threads, bool repair = true);
 std::string metrics_yaml(const LoadResult& lr, uint32_t unitig_count, uint64_t unitig_total_length);
 void check_compress_settings(const std::string& assemblies_dir, const std::string& autocycler_dir, uint32_t k, int threads);
 std::string format_duration(double seconds);   // misc.rs:379-385

@@ -44,8 +44,8 @@ def make_inputs(args, rank, sharded_job):
     return seqs, fn, hd
 
 
-def prepare(lib, k, seqs, fn, hd, n_assemblies, threads):
-    """Sequence::new_with_seq + sequence_end_repair on the host (upstream of the timed region)."""
+def prepare(lib, k, seqs, fn, hd, n_assemblies, threads, repair=1):
+    """Sequence::new_with_seq (+ sequence_end_repair on the host when repair=1) — upstream of the timed region."""
     from autocycler_amd import _capi
     n = len(seqs)
     ptrs = (C.c_void_p * n)(*[s.ctypes.data for s in seqs])
@@ -53,7 +53,7 @@ def prepare(lib, k, seqs, fn, hd, n_assemblies, threads):
     f = (C.c_char_p * n)(*[x.encode() for x in fn])
     h = (C.c_char_p * n)(*[x.encode() for x in hd])
     out = C.c_void_p()
-    rc = lib.ac_seqs_from_raw(C.c_uint32(k), C.c_uint32(n), ptrs, lens, f, h, C.c_uint32(n_assemblies), C.c_int(1),
+    rc = lib.ac_seqs_from_raw(C.c_uint32(k), C.c_uint32(n), ptrs, lens, f, h, C.c_uint32(n_assemblies), C.c_int(repair),
                               C.c_int(threads), C.byref(out))
     if rc:
         raise RuntimeError(lib.ac_last_error().decode())
@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--mode", choices=["auto", "single", "sharded", "independent"], default="auto",
                     help="auto: single-device build at N=1, one sharded job at N>1")
     ap.add_argument("--init-builds", type=int, default=2, help="untimed builds before the warmup (one-time process initialisation)")
+    ap.add_argument("--repair", choices=["device", "host"], default="device",
+                    help="where sequence_end_repair runs (upstream of the timed region): on the device text, or the host implementation")
     ap.add_argument("--gather-paths", action="store_true",
                     help="sharded mode: gather the paths of all sequences to rank 0 (default: every rank keeps its own P lines)")
     args = ap.parse_args()
@@ -131,7 +133,7 @@ def main():
     t0 = time.time()
     seqs, fn, hd = make_inputs(args, rank, mode == "sharded")
     t_gen = time.time() - t0
-    h_seqs = prepare(lib, k, seqs, fn, hd, args.assemblies, threads=os.cpu_count() or 1)
+    h_seqs = prepare(lib, k, seqs, fn, hd, args.assemblies, threads=os.cpu_count() or 1, repair=1 if args.repair == "host" else 0)
     del seqs
     n = lib.ac_seqs_count(h_seqs)
     views = lib.ac_seqs_views(h_seqs)
@@ -149,6 +151,17 @@ def main():
     d_text = torch.from_numpy(text).to(dev)      # inputs resident in HBM before the timed region
     torch.cuda.synchronize()
     t_h2d = time.time() - t1
+    repair_info = {"where": args.repair, "seconds": t_repair}
+    if args.repair == "device":      # sequence_end_repair on the device text, in place (upstream of the timed region)
+        secs, nm = C.c_double(), C.c_uint64()
+        t2 = time.time()
+        if lib.ac_end_repair_device(C.c_uint32(k), C.c_void_p(d_text.data_ptr()), C.c_uint64(n_text), off, lens, d1, d2, C.c_uint32(n),
+                                    C.c_int(local_rank), C.byref(secs), C.byref(nm)):
+            raise RuntimeError(lib.ac_last_error().decode())
+        lib.ac_end_repair_device(C.c_uint32(k), C.c_void_p(d_text.data_ptr()), C.c_uint64(n_text), off, lens, d1, d2, C.c_uint32(n),
+                                 C.c_int(local_rank), C.byref(secs), C.byref(nm))      # idempotent on a repaired text: steady-state time
+        repair_info = {"where": "device", "first_call_s": time.time() - t2 - secs.value, "seconds": secs.value, "matches": nm.value}
+        t_repair = secs.value
 
     shard = None
     if mode == "sharded":
@@ -274,7 +287,7 @@ def main():
             "graph": {**g.stats_post, "kmers": g.kmer_count, "distinct_canonical": tms[-1]["n_distinct"],
                       "path_entries": tms[-1]["n_path_entries"], "table_capacity": tms[-1]["table_capacity"],
                       "simplify_passes": tms[-1]["simplify_passes"]},
-            "prep_s": {"generate": t_gen, "end_repair": t_repair, "h2d": t_h2d, "h2d_GBps": n_text / t_h2d / 1e9},
+            "prep_s": {"generate": t_gen, "end_repair": t_repair, "end_repair_info": repair_info, "h2d": t_h2d, "h2d_GBps": n_text / t_h2d / 1e9},
         }
         if mode == "sharded":
             line["sharded"] = {**last_info, "fragments_rank0": tms[-1]["n_fragments"], "fragment_bytes_rank0": tms[-1]["fragment_bytes"],

@@ -126,6 +126,13 @@ int ac_graph_set_paths(ac_graph*, uint32_t n_seqs_total, const uint16_t* seq_ids
 uint32_t ac_graph_seq_count(const ac_graph*);
 int ac_path_counts(const ac_graph*, uint64_t* counts /* ac_graph_seq_count() */);   /* path entries per sequence */
 
+/* sequence_end_repair (compress.rs:202-270) on the device, for a text that is already resident there: d_text holds the
+ * PADDED, UNREPAIRED sequences (Sequence::new_with_seq, sequence.rs:31-59) in the layout above; the chosen matches are
+ * patched into it in place and seq_d1 / seq_d2 (dots surviving at each end) are updated, so the same buffer can go straight
+ * into ac_compress_build_device / ac_shard_begin.  One pass over the packed text replaces the reference's 2S regex scans. */
+int ac_end_repair_device(uint32_t k, void* d_text, uint64_t n_text, const uint64_t* seq_off, const uint32_t* seq_len,
+                         uint16_t* seq_d1, uint16_t* seq_d2, uint32_t n_seqs, int device, double* seconds, uint64_t* n_matches);
+
 /* Host helper: lay sequences out as the text described above.  text must hold ac_text_size() bytes. */
 uint64_t ac_text_size(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs);
 int ac_layout_text(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs, uint8_t* text, uint64_t* seq_off,

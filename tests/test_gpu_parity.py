@@ -67,3 +67,38 @@ def test_synthetic_many_path_entries():
     seqs, fn, hd = _synth_case(12, 300_000, 10_000, 5e-3, 2e-4, 777)
     g, gfa, _ = parity_util.check_case(51, seqs, fn, hd)
     assert g.timings()["n_path_entries"] > 262_144
+
+
+@pytest.mark.parametrize("k", [5, 21, 51, 101])
+def test_end_repair_device(k):
+    # sequence_end_repair on the device text against the oracle's restatement of compress.rs:202-270
+    import autocycler_amd
+    import repair_util
+    for seed in range(24):
+        seqs, fn, hd = seqgen.make_case(seed, k)
+        repair_util.check_repair(autocycler_amd.LIB_PATH, k, seqs, fn, hd, device="cuda:0")
+
+
+def test_end_repair_then_build_on_the_same_device_text():
+    # the whole device flow: padded text -> ac_end_repair_device (in place) -> ac_compress_build_device -> GFA == oracle
+    import ctypes as C
+    import autocycler_amd
+    import oracle_lib as O
+    import repair_util
+    from autocycler_amd import _capi
+    k = 51
+    seqs, fn, hd = _synth_case(8, 200_000, 8_000, 1e-3, 1e-4, 4242)
+    d_text, off, lens, d1, d2, n_matches, _ = repair_util.check_repair(autocycler_amd.LIB_PATH, k, seqs, fn, hd, device="cuda:0")
+    assert n_matches >= 2 * len(seqs)
+    lib = _capi.load_library()
+    n = len(seqs)
+    ids = (C.c_uint16 * n)(*range(1, n + 1))
+    g = C.c_void_p()
+    rc = lib.ac_compress_build_device(C.c_uint32(k), C.c_uint32(8), C.c_void_p(d_text.data_ptr()), C.c_uint64(d_text.numel()), off, lens, ids,
+                                      d1, d2, C.c_uint32(n), C.c_int(0), C.byref(g))
+    assert rc == 0, lib.ac_last_error()
+    graph = _capi.Graph(lib, g, n)
+    s = O.Seqs.from_raw(k, seqs, filenames=fn, headers=hd, repair=True)
+    gfa_o, _, _ = s.compress(k)
+    loaded = s.all()
+    assert graph.gfa([q["filename"] for q in loaded], [q["header"] for q in loaded]) == gfa_o

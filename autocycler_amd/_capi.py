@@ -70,6 +70,12 @@ def load_library(path=None):
     if not path.exists():
         raise HipLibraryMissing(f"{path} not found: build the HIP extension first (make -C autocycler_amd/csrc). "
                                 "There is no CPU fallback.")
+    try:
+        # PyTorch bundles its own HIP runtime; when ours (/opt/rocm) is loaded first, torch later finds "no HIP GPUs".
+        # Importing torch first makes the dynamic loader resolve our libamdhip64 dependency to the copy torch loaded.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(key)
     lib.ac_last_error.restype = C.c_char_p
     lib.ac_version.restype = C.c_char_p

@@ -540,6 +540,35 @@ inline void reduce_by_segment(const u32* seg, const V* vals, size_t n, V* out, s
 #endif
 }
 
+// Arg-min per segment: `seg` holds non-decreasing segment ids (any values; a new id starts a new segment), the candidates of
+// position i is the index i itself, `op(a, b)` returns whichever of two indices wins.  No value array is materialised: the
+// indices come from a counting iterator and the operator looks at whatever the indices stand for.
+template <class Op>
+inline void segment_argmin(const u32* seg, size_t n, u32* out, size_t n_segments, Op op, stream_t s = 0) {
+    if (!n) return;
+#ifdef AC_EMU
+    size_t r = 0;
+    for (size_t i = 0; i < n;) {
+        u32 acc = (u32)i;
+        size_t j = i + 1;
+        while (j < n && seg[j] == seg[i]) { acc = op(acc, (u32)j); j++; }
+        out[r++] = acc;
+        i = j;
+    }
+    if (r != n_segments) throw DeviceError("segment_argmin: segment count mismatch");
+#else
+    DBuf<u32> uniq(n_segments);
+    DBuf<u32> cnt(1);
+    rocprim::counting_iterator<u32> idx(0);
+    size_t tmp_bytes = 0;
+    AC_HIP_CHECK(rocprim::reduce_by_key(nullptr, tmp_bytes, seg, idx, n, uniq.ptr(), out, cnt.ptr(), op, rocprim::equal_to<u32>(), s));
+    DBuf<u8> tmp(tmp_bytes);
+    AC_HIP_CHECK(rocprim::reduce_by_key(tmp.ptr(), tmp_bytes, seg, idx, n, uniq.ptr(), out, cnt.ptr(), op, rocprim::equal_to<u32>(), s));
+    u32 c = read_scalar(cnt.ptr(), s);
+    if (c != n_segments) throw DeviceError("segment_argmin: segment count mismatch");
+#endif
+}
+
 // Sort (key struct, u32 value) pairs with a comparator.
 template <class K, class Cmp>
 inline void sort_by_key_cmp(DBuf<K>& keys, DBuf<u32>& vals, size_t n, Cmp cmp, stream_t s = 0) {

@@ -30,9 +30,19 @@ static double now_s() {
 
 
 static const int MAX_PROBES = 1 << 14;
-static bool g_stage_timing = false;
+// This file is compiled once per key width (-DAC_W_ONLY=1,2,3,4,8,16: the kernels and the stage code of that width only) and
+// once as the main unit (AC_W_ONLY=0: everything that does not depend on the width, and the dispatch), so that the widths
+// build in parallel.  The CPU emulation compiles it once with everything in.
+#ifndef AC_W_ONLY
+#define AC_W_ONLY 0
+#endif
+#if AC_W_ONLY == 0
+bool g_stage_timing = false;
 void set_stage_timing(bool on) { g_stage_timing = on; }
 bool stage_timing() { return g_stage_timing; }
+#else
+extern bool g_stage_timing;
+#endif
 
 // kinfo bits (per novel k-mer, relative to the text orientation T of its smallest occurrence)
 static const u32 KI_OUT_MASK = 7u, KI_IN_SHIFT = 3, KI_FIRST_T = 1u << 6, KI_FIRST_RCT = 1u << 7;
@@ -544,24 +554,56 @@ template <int W> struct MinOp {
 template <int W> struct MinValLess {
     AC_HD bool operator()(const MinVal<W>& a, const MinVal<W>& b) const { return key_lt<W>(a.key, b.key); }
 };
-template <int W> struct CKeyFunctor {
+// Canonical key of the k-mer at a novel position (all-ones if the position is not a k-mer start: cannot happen).
+template <int W> AC_D Key<W> canonical_at(const TextCtx& t, u64 p, bool* flipped) {
+    XKmer<W> x;
+    bool ok = true;
+    if (text_mask_count(t.mask, p, t.k) == 0) { x.fwd = text_extract<W>(t.bits, p, t.k); x.ld = 0; x.td = 0; }
+    else ok = xkmer_at<W>(t, p, &x);
+    *flipped = false;
+    if (ok) return xk_canonical<W>(x, t.k, flipped);
+    Key<W> bad;
+#pragma unroll
+    for (int j = 0; j < W; j++) bad.w[j] = ~0ULL;
+    return bad;
+}
+// Which of two novel k-mers (given by their indices in the novel list) has the smaller canonical key?  The keys are
+// recomputed from the packed text on every call: cheaper than writing and re-reading a 16..136-byte key per k-mer.
+template <int W> struct MinIdxOp {
+    TextCtx t; const u64* npos;
+    AC_D u32 operator()(const u32& a, const u32& b) const {
+        bool fa, fb;
+        Key<W> ka = canonical_at<W>(t, npos[a], &fa), kb = canonical_at<W>(t, npos[b], &fb);
+        return key_lt<W>(kb, ka) ? b : a;
+    }
+};
+template <int W> struct CKeyFunctor {        // narrow keys (W <= 4): materialise (key, strand) per novel k-mer for a plain segmented min
     TextCtx t; const u64* npos; const u32* scan; MinVal<W>* vals; u32* seg;
     AC_D void operator()(u64 i) const {
-        XKmer<W> x;
-        u64 p = npos[i];
-        bool ok = true;
-        if (text_mask_count(t.mask, p, t.k) == 0) { x.fwd = text_extract<W>(t.bits, p, t.k); x.ld = 0; x.td = 0; }
-        else ok = xkmer_at<W>(t, p, &x);
+        bool flipped;
         MinVal<W> v;
-        bool flipped = false;
-        if (ok) v.key = xk_canonical<W>(x, t.k, &flipped);
-        else { for (int j = 0; j < W; j++) v.key.w[j] = ~0ULL; }
+        v.key = canonical_at<W>(t, npos[i], &flipped);
         v.flipped = flipped ? 1u : 0u; v.pad = 0;
         vals[i] = v;
         seg[i] = scan[i] - 1;
     }
 };
+template <int W> struct UnitigMinFunctor {   // the winner's key and strand, per unitig
+    TextCtx t; const u64* npos; const u32* umin_idx; MinVal<W>* umin;
+    AC_D void operator()(u64 u) const {
+        bool flipped;
+        MinVal<W> v;
+        v.key = canonical_at<W>(t, npos[umin_idx[u]], &flipped);
+        v.flipped = flipped ? 1u : 0u; v.pad = 0;
+        umin[u] = v;
+    }
+};
+template <int W> struct MinValIdxLess {      // indirect comparison for keys too wide to be moved around by the sort
+    const MinVal<W>* umin;
+    AC_HD bool operator()(const u32& a, const u32& b) const { return key_lt<W>(umin[a].key, umin[b].key); }
+};
 struct IotaFunctor { u32* a; AC_HD void operator()(u64 i) const { a[i] = (u32)i; } };
+template <int W> struct GatherMinFunctor { const u32* order; const MinVal<W>* in; MinVal<W>* out; AC_HD void operator()(u64 r) const { out[r] = in[order[r]]; } };
 
 // ---- K9: per-unitig metadata in seed (rank) order ---------------------------------------------------------
 template <int W> struct UnitigMetaFunctor {
@@ -1314,6 +1356,7 @@ struct ReduceImportFunctor {
 };
 
 // =============================================================================================================
+#if AC_W_ONLY == 0
 std::vector<uint8_t> layout_text(const std::vector<SeqView>& seqs, uint32_t k, std::vector<uint64_t>* off,
                                  std::vector<uint32_t>* len, std::vector<uint16_t>* d1, std::vector<uint16_t>* d2) {
     u64 n = 1;
@@ -1337,7 +1380,9 @@ std::vector<uint8_t> layout_text(const std::vector<SeqView>& seqs, uint32_t k, s
     return text;
 }
 
-int max_supported_k() { return (64 * 4 - 8) / 2; }   // W <= 4 key words in this build
+int max_supported_k() { return 501; }   // the reference's own limit (compress.rs:56-60); keys of 1, 2, 3, 4, 8 or 16 words
+#endif
+static int key_words(int k) { int w = words_for_k(k); return w <= 4 ? w : (w <= 8 ? 8 : 16); }
 
 // renumber_unitigs (unitig_graph.rs:295-315): stable sort of `order` by (length desc, sequence asc, depth desc).
 static void renumber_sort(DBuf<u32>& order, u32 U, const u32* len, const u64* off, const u8* seq, const u32* depth, u32* flag) {
@@ -1396,7 +1441,7 @@ struct PackedText {
     }
     TextCtx ctx(int k) const { return TextCtx{bits.ptr(), mask.ptr(), n_text, k, seq_off.ptr(), seq_len.ptr(), seq_d1.ptr(), seq_d2.ptr(), n_seqs}; }
     void pack() {   // K1
-        u64 n_bits_words = n_text / 32 + 8, n_mask_words = n_text / 64 + 4;   // slack for W <= 4 key words
+        u64 n_bits_words = n_text / 32 + 24, n_mask_words = n_text / 64 + 12;   // slack for W <= 16 key words
         bits.alloc(n_bits_words); mask.alloc(n_mask_words);
         bits.fill_bytes(0);
         mask.fill_bytes(0xFF);
@@ -1536,7 +1581,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
 }
 
 // K3a: bit p set <=> text position p is the smallest occurrence of its canonical k-mer.
-void GraphBuilder::Impl::novel_bitmap(const PackedText& t, const DBuf<u64>& sl, u64 c, DBuf<u64>* bm_out, DBuf<u64>* occ_out) {
+inline void GraphBuilder::Impl::novel_bitmap(const PackedText& t, const DBuf<u64>& sl, u64 c, DBuf<u64>* bm_out, DBuf<u64>* occ_out) {
     u64 n_bm_words = t.n_text / 64 + 1;
     bm_out->alloc(n_bm_words);
     bm_out->fill_bytes(0);
@@ -1628,17 +1673,28 @@ template <int W> void GraphBuilder::Impl::unitigs() {
 
     // K8 min canonical k-mer per unitig
     DBuf<MinVal<W>> umin(U);
-    {
+    if constexpr (W <= 4) {
         DBuf<MinVal<W>> vals(N); DBuf<u32> seg(N);
         launch(N, CKeyFunctor<W>{t, npos.ptr(), scan.ptr(), vals.ptr(), seg.ptr()});
         reduce_by_segment(seg.ptr(), vals.ptr(), N, umin.ptr(), U, MinOp<W>());
+    } else {      // wide keys: arg-min over indices, the keys recomputed from the text inside the operator
+        DBuf<u32> umin_idx(U);
+        segment_argmin(scan.ptr(), N, umin_idx.ptr(), U, MinIdxOp<W>{t, npos.ptr()});      // scan[i] = unitig of novel k-mer i
+        launch(U, UnitigMinFunctor<W>{t, npos.ptr(), umin_idx.ptr(), umin.ptr()});
     }
     lap(&tm->minkey);
 
     // K9 seed order = rank of the smallest k-mer
     order.alloc(U);
     launch(U, IotaFunctor{order.ptr()});
-    sort_by_key_cmp(umin, order, U, MinValLess<W>());
+    if constexpr (W <= 4) {
+        sort_by_key_cmp(umin, order, U, MinValLess<W>());
+    } else {      // wide keys stay where they are: sort the indices, then gather
+        sort_keys_cmp(order, U, MinValIdxLess<W>{umin.ptr()});
+        DBuf<MinVal<W>> sorted(U);
+        launch(U, GatherMinFunctor<W>{order.ptr(), umin.ptr(), sorted.ptr()});
+        umin = std::move(sorted);
+    }
     rank.alloc(U); ulen.alloc(U); ustartpos.alloc(U); useq_off.alloc((u64)U + 1); uorient.alloc(U);
     DBuf<u64> ulen64((u64)U + 1);
     launch((u64)U + 1, UnitigMetaFunctor<W>{order.ptr(), ustart.ptr(), npos.ptr(), umin.ptr(), U, N, rank.ptr(), ulen.ptr(),
@@ -1864,6 +1920,29 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         fprintf(stderr, "arena: used %.1f MB of %.1f MB (n_text %.1f MB)\n", Arena::device().total_used() / 1e6, Arena::device().capacity() / 1e6, loc.n_text / 1e6);
 }
 
+// The width-dependent stages behind one explicitly instantiated type per width.  The main unit only sees declarations, so it
+// cannot instantiate (or inline) anything width-dependent itself.
+template <int W> struct Stages {
+    static void table(GraphBuilder::Impl& m);
+    static void degrees(GraphBuilder::Impl& m, u64 lo, u64 hi);
+    static void unitigs(GraphBuilder::Impl& m);
+    static void walk(GraphBuilder::Impl& m);
+    static void tail(GraphBuilder::Impl& m, FinalGraph* out, bool want_graph, bool want_paths);
+    static void fragments(GraphBuilder::Impl& m);
+};
+#if AC_W_ONLY != 0 || defined(AC_EMU)
+template <int W> void Stages<W>::table(GraphBuilder::Impl& m) { m.template table<W>(); }
+template <int W> void Stages<W>::degrees(GraphBuilder::Impl& m, u64 lo, u64 hi) { m.template degrees<W>(lo, hi); }
+template <int W> void Stages<W>::unitigs(GraphBuilder::Impl& m) { m.template unitigs<W>(); }
+template <int W> void Stages<W>::walk(GraphBuilder::Impl& m) { m.template walk<W>(); }
+template <int W> void Stages<W>::tail(GraphBuilder::Impl& m, FinalGraph* out, bool want_graph, bool want_paths) { m.template tail<W>(out, want_graph, want_paths); }
+template <int W> void Stages<W>::fragments(GraphBuilder::Impl& m) { m.template fragments<W>(); }
+#endif
+#if AC_W_ONLY != 0
+template struct Stages<AC_W_ONLY>;
+#endif
+
+#if AC_W_ONLY == 0
 // ---- GraphBuilder ------------------------------------------------------------------------------------------------
 GraphBuilder::GraphBuilder(uint32_t k) : impl_(new Impl) {
     // A builder owns the arenas for its lifetime (the C ABI serialises builds): whatever the previous build
@@ -1901,11 +1980,13 @@ void GraphBuilder::set_text_device(const uint8_t* d_text, uint64_t n_text, const
 }
 
 #define AC_DISPATCH_W(NAME, ARGS)                                        \
-    switch (words_for_k((int)impl_->k)) {                                \
-        case 1: impl_->template NAME<1> ARGS; break;                     \
-        case 2: impl_->template NAME<2> ARGS; break;                     \
-        case 3: impl_->template NAME<3> ARGS; break;                     \
-        case 4: impl_->template NAME<4> ARGS; break;                     \
+    switch (key_words((int)impl_->k)) {                                  \
+        case 1: Stages<1>::NAME ARGS; break;                             \
+        case 2: Stages<2>::NAME ARGS; break;                             \
+        case 3: Stages<3>::NAME ARGS; break;                             \
+        case 4: Stages<4>::NAME ARGS; break;                             \
+        case 8: Stages<8>::NAME ARGS; break;                             \
+        case 16: Stages<16>::NAME ARGS; break;                           \
         default: throw DeviceError("unsupported k");                     \
     }
 
@@ -1920,11 +2001,11 @@ void GraphBuilder::build(uint32_t assembly_count_hint, FinalGraph* out) {
     m.check_sizes(m.loc);
     m.loc.pack();
     m.lap(&tm_.pack);
-    AC_DISPATCH_W(table, ())
-    AC_DISPATCH_W(degrees, (0, m.N))
-    AC_DISPATCH_W(unitigs, ())
-    AC_DISPATCH_W(walk, ())
-    AC_DISPATCH_W(tail, (out, true, true))
+    AC_DISPATCH_W(table, (*impl_))
+    AC_DISPATCH_W(degrees, (*impl_, 0, m.N))
+    AC_DISPATCH_W(unitigs, (*impl_))
+    AC_DISPATCH_W(walk, (*impl_))
+    AC_DISPATCH_W(tail, (*impl_, out, true, true))
 }
 
 // ---- sharded build (one compress job over several devices; the collectives between the phases belong to the
@@ -1939,7 +2020,7 @@ void GraphBuilder::shard_begin(uint32_t local_assembly_hint) {
     m.check_sizes(m.loc);
     m.loc.pack();
     m.lap(&tm_.pack);
-    AC_DISPATCH_W(fragments, ())
+    AC_DISPATCH_W(fragments, (*impl_))
 }
 uint64_t GraphBuilder::fragment_text_bytes() const { return impl_->frag_bytes; }
 uint64_t GraphBuilder::fragment_count() const { return impl_->n_frags; }
@@ -1974,11 +2055,11 @@ void GraphBuilder::shard_build_union(uint32_t rank, uint32_t n_shards, const uin
     tm_.graph_hint = n_shards;
     m.uni.pack();
     m.lap(&tm_.union_pack);
-    AC_DISPATCH_W(table, ())
+    AC_DISPATCH_W(table, (*impl_))
     // this rank's slice of the degree computation (the one kernel of the graph stage that is both heavy and
     // embarrassingly parallel over distinct k-mers); the caller all-gathers the slices
     u64 lo = m.N * rank / n_shards, hi = m.N * (rank + 1) / n_shards;
-    AC_DISPATCH_W(degrees, (lo, hi))
+    AC_DISPATCH_W(degrees, (*impl_, lo, hi))
 }
 uint64_t GraphBuilder::distinct_count() const { return impl_->N; }
 void GraphBuilder::degrees_export(void* d_out) {
@@ -1991,8 +2072,8 @@ void GraphBuilder::shard_build_graph(const void* d_kinfo_all) {
     m.t0 = now_s();
     if (d_kinfo_all) copy_d2d(m.kinfo.ptr(), d_kinfo_all, m.N * 4);
     else if (!(m.deg_lo == 0 && m.deg_hi == m.N)) throw DeviceError("degree slices of the other ranks are missing");
-    AC_DISPATCH_W(unitigs, ())
-    AC_DISPATCH_W(walk, ())
+    AC_DISPATCH_W(unitigs, (*impl_))
+    AC_DISPATCH_W(walk, (*impl_))
 }
 uint32_t GraphBuilder::unitig_count() const { return impl_->U; }
 void GraphBuilder::reduce_export(int32_t* d_sum, int32_t* d_min) {
@@ -2008,7 +2089,7 @@ void GraphBuilder::reduce_import(const int32_t* d_sum, const int32_t* d_min) {
 }
 void GraphBuilder::shard_finish(FinalGraph* out, bool want_graph, bool want_paths) {
     impl_->t0 = now_s();
-    AC_DISPATCH_W(tail, (out, want_graph, want_paths))
+    AC_DISPATCH_W(tail, (*impl_, out, want_graph, want_paths))
 }
 uint64_t GraphBuilder::path_entry_count() const { return impl_->n_ent; }
 void GraphBuilder::paths_export(void* d_out) {
@@ -2035,7 +2116,7 @@ struct WindowPatchFunctor {      // the reverse: m bytes into each listed text p
     u8* text; const u64* pos; u32 m; const u8* src;
     AC_HD void operator()(u64 idx) const { text[pos[idx / m] + idx % m] = src[idx]; }
 };
-struct EndScanFunctor {          // a thread owns the literal-length windows starting in 256 consecutive text positions
+template <int WL> struct EndScanFunctor {   // a thread owns the literal-length windows starting in 256 consecutive text positions
     const u64* bits; const u64* mask; u64 n_text; int lit;
     const u64* filter; const u64* tkeys; const u32* tent; u64 tmask;
     u64* hits; u32 cap; u32* n_hits;
@@ -2044,20 +2125,25 @@ struct EndScanFunctor {          // a thread owns the literal-length windows sta
         if (p1 > n_text) p1 = n_text;
         u64 bend = p1 + (u64)lit - 1;
         if (bend > n_text) bend = n_text;
-        const Key<2> km = key_kmask<2>(lit);
-        Key<2> key; key.w[0] = 0; key.w[1] = 0;
+        const Key<WL> km = key_kmask<WL>(lit);
+        Key<WL> key;
+#pragma unroll
+        for (int i = 0; i < WL; i++) key.w[i] = 0;
         int run = 0;
         for (u64 b = p0; b < bend; b++) {
             if (text_mask(mask, b)) { run = 0; continue; }
-            key_roll_fwd<2>(key, text_code(bits, b), km);
+            key_roll_fwd<WL>(key, text_code(bits, b), km);
             if (++run < lit) continue;
-            u64 h = key_hash<2>(key);
+            u64 h = key_hash<WL>(key);
             u64 fb = h >> 44;                                       // 2^20-bit filter
             if (!((filter[fb >> 6] >> (fb & 63)) & 1)) continue;
             for (u64 s = h & tmask;; s = (s + 1) & tmask) {
                 u32 e = tent[s];
                 if (e == 0xFFFFFFFFu) break;
-                if (tkeys[2 * s] == key.w[0] && tkeys[2 * s + 1] == key.w[1]) {
+                bool eq = true;
+#pragma unroll
+                for (int i = 0; i < WL; i++) eq = eq && tkeys[WL * s + i] == key.w[i];
+                if (eq) {
                     u32 i = atomic_add32(n_hits, 1u);
                     if (i < cap) hits[i] = ((u64)e << 40) | (b + 1 - (u64)lit);
                     break;
@@ -2069,14 +2155,15 @@ struct EndScanFunctor {          // a thread owns the literal-length windows sta
 
 static inline char repair_comp(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c == '.' ? '.' : 'N'; }   // misc.rs:358-376
 
-void end_repair_device(uint32_t k, uint8_t* d_text, uint64_t n_text, const std::vector<uint64_t>& off, const std::vector<uint32_t>& len,
-                       std::vector<uint16_t>* d1, std::vector<uint16_t>* d2, RepairTimings* tm) {
+template <int WL>
+static void end_repair_impl(uint32_t k, uint8_t* d_text, uint64_t n_text, const std::vector<uint64_t>& off, const std::vector<uint32_t>& len,
+                            std::vector<uint16_t>* d1, std::vector<uint16_t>* d2, RepairTimings* tm) {
     double t_begin = now_s();
     const u32 S = (u32)off.size();
     const u32 m = k - 1, h = k / 2, lit = m - h;
     if (tm) *tm = RepairTimings();
     if (m == 0 || S == 0) return;
-    if (lit > 64 || lit == 0) throw DeviceError("end repair: unsupported k");
+    if (lit > 32u * WL || lit == 0) throw DeviceError("end repair: unsupported k");
     if (n_text >= POS_MASK) throw DeviceError("input too large for 40-bit text positions");
     Arena::device().reset();     // nothing of an earlier build is alive while the repair runs
     Arena::device().reserve(arena_estimate(n_text, false));
@@ -2095,32 +2182,34 @@ void end_repair_device(uint32_t k, uint8_t* d_text, uint64_t n_text, const std::
     // literal table: key -> entry; entry -> the (pattern, orientation) pairs with that literal
     struct Use { u32 pid; u32 rev; };
     std::vector<std::vector<Use>> uses;
-    std::vector<Key<2>> ekeys;
+    std::vector<Key<WL>> ekeys;
     auto code_of = [](u8 ch, bool* ok) -> u32 { if (!(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T')) *ok = false; return ((ch >> 1) ^ (ch >> 2)) & 3u; };
-    const Key<2> km = key_kmask<2>((int)lit);
+    const Key<WL> km = key_kmask<WL>((int)lit);
     u64 tcap = next_pow2((u64)8 * S + 16);
-    std::vector<u64> tkeys(2 * tcap, 0); std::vector<u32> tent(tcap, 0xFFFFFFFFu);
+    std::vector<u64> tkeys((size_t)WL * tcap, 0); std::vector<u32> tent(tcap, 0xFFFFFFFFu);
     std::vector<u64> filter((1u << 20) / 64, 0);
-    auto add = [&](const Key<2>& key, u32 pid, u32 rev) {
-        u64 hh = key_hash<2>(key);
+    auto add = [&](const Key<WL>& key, u32 pid, u32 rev) {
+        u64 hh = key_hash<WL>(key);
         for (u64 s = hh & (tcap - 1);; s = (s + 1) & (tcap - 1)) {
             if (tent[s] == 0xFFFFFFFFu) {
-                tent[s] = (u32)ekeys.size(); tkeys[2 * s] = key.w[0]; tkeys[2 * s + 1] = key.w[1];
+                tent[s] = (u32)ekeys.size();
+                for (int i = 0; i < WL; i++) tkeys[(size_t)WL * s + i] = key.w[i];
                 ekeys.push_back(key); uses.push_back({});
                 u64 fb = hh >> 44; filter[fb >> 6] |= 1ULL << (fb & 63);
             }
-            if (tkeys[2 * s] == key.w[0] && tkeys[2 * s + 1] == key.w[1]) { uses[tent[s]].push_back(Use{pid, rev}); return; }
+            if (key_eq<WL>(ekeys[tent[s]], key)) { uses[tent[s]].push_back(Use{pid, rev}); return; }
         }
     };
     for (u32 pid = 0; pid < 2 * S; pid++) {
         const u8* w = &win[(size_t)pid * m];
         const u8* L = (pid & 1) ? w : w + h;          // start pattern: h wildcards then the literal; end pattern: literal first
-        Key<2> key; key.w[0] = key.w[1] = 0;
+        Key<WL> key;
+        for (int i = 0; i < WL; i++) key.w[i] = 0;
         bool ok = true;
-        for (u32 i = 0; i < lit; i++) key_roll_fwd<2>(key, code_of(L[i], &ok), km);
+        for (u32 i = 0; i < lit; i++) key_roll_fwd<WL>(key, code_of(L[i], &ok), km);
         if (!ok) throw DeviceError("end repair: a sequence end holds something else than bases");
         add(key, pid, 0);
-        add(key_rc<2>(key, (int)lit), pid, 1);         // an occurrence of rc(L) in a forward sequence = an occurrence of L in its reverse
+        add(key_rc<WL>(key, (int)lit), pid, 1);         // an occurrence of rc(L) in a forward sequence = an occurrence of L in its reverse
     }
     if (ekeys.size() >= (1u << 24)) throw DeviceError("end repair: too many patterns");
 
@@ -2138,7 +2227,7 @@ void end_repair_device(uint32_t k, uint8_t* d_text, uint64_t n_text, const std::
     for (;;) {
         DBuf<u64> d_hits(cap);
         d_nhits.fill_bytes(0);
-        launch((n_text + 255) / 256, EndScanFunctor{pt.bits.ptr(), pt.mask.ptr(), n_text, (int)lit, d_filter.ptr(), d_tkeys.ptr(), d_tent.ptr(),
+        launch((n_text + 255) / 256, EndScanFunctor<WL>{pt.bits.ptr(), pt.mask.ptr(), n_text, (int)lit, d_filter.ptr(), d_tkeys.ptr(), d_tent.ptr(),
                                                    tcap - 1, d_hits.ptr(), cap, d_nhits.ptr()});
         u32 n = read_scalar(d_nhits.ptr());
         if (n > cap) { if (n >= 0xFFFFFFF0u) throw DeviceError("end repair: too many literal occurrences"); cap = n; continue; }
@@ -2236,5 +2325,14 @@ void end_repair_device(uint32_t k, uint8_t* d_text, uint64_t n_text, const std::
     }
     if (tm) tm->total = now_s() - t_begin;
 }
+
+void end_repair_device(uint32_t k, uint8_t* d_text, uint64_t n_text, const std::vector<uint64_t>& off, const std::vector<uint32_t>& len,
+                       std::vector<uint16_t>* d1, std::vector<uint16_t>* d2, RepairTimings* tm) {
+    if (k < 1 || (int)k > max_supported_k()) throw DeviceError("end repair: unsupported k");
+    if ((k - 1) - k / 2 <= 64) end_repair_impl<2>(k, d_text, n_text, off, len, d1, d2, tm);
+    else end_repair_impl<8>(k, d_text, n_text, off, len, d1, d2, tm);      // literals of up to 250 bases (k <= 501)
+}
+
+#endif   // AC_W_ONLY == 0
 
 }  // namespace ac

@@ -86,8 +86,9 @@ class GraphBuilder {
     uint64_t n_text() const;
     uint64_t n_bases() const;   // sum of unpadded lengths
 
+    struct Impl;   // all device state of one build (graph_build.hip)
+
   private:
-    struct Impl;
     Impl* impl_;
     BuildTimings tm_;
 };

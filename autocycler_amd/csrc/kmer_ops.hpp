@@ -27,6 +27,11 @@
 #define AC_D __device__ inline
 #endif
 
+// Loops over the W words of a key: fully unrolled for the common narrow keys (the key then lives in registers with constant
+// indices), left as loops for wide keys (k > 123) where straight-line code for 8 or 16 words per operation inlined into every
+// kernel made the compile take tens of minutes.
+#define AC_UNROLL_W _Pragma("unroll (W <= 4 ? 4 : 1)")
+
 namespace ac {
 
 typedef uint64_t u64;
@@ -44,12 +49,12 @@ struct Key {
 
 template <int W> AC_HD bool key_eq(const Key<W>& a, const Key<W>& b) {
     bool e = true;
-#pragma unroll
+AC_UNROLL_W
     for (int i = 0; i < W; i++) e = e && (a.w[i] == b.w[i]);
     return e;
 }
 template <int W> AC_HD bool key_lt(const Key<W>& a, const Key<W>& b) {
-#pragma unroll
+AC_UNROLL_W
     for (int i = 0; i < W; i++) {
         if (a.w[i] != b.w[i]) return a.w[i] < b.w[i];
     }
@@ -76,15 +81,24 @@ AC_HD u64 rev2_64(u64 x) {
 template <int W> AC_HD Key<W> key_shr(const Key<W>& a, int s) {
     Key<W> r;
     const int ws = s >> 6, bs = s & 63;
-#pragma unroll
-    for (int i = 0; i < W; i++) {
-        u64 lo = 0, hi = 0;
-#pragma unroll
-        for (int j = 0; j < W; j++) {
-            lo = (j == i - ws) ? a.w[j] : lo;
-            hi = (j == i - ws - 1) ? a.w[j] : hi;
+    if constexpr (W <= 4) {
+AC_UNROLL_W
+        for (int i = 0; i < W; i++) {
+            u64 lo = 0, hi = 0;
+AC_UNROLL_W
+            for (int j = 0; j < W; j++) {
+                lo = (j == i - ws) ? a.w[j] : lo;
+                hi = (j == i - ws - 1) ? a.w[j] : hi;
+            }
+            r.w[i] = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
         }
-        r.w[i] = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
+    } else {   // wide keys (k > 123, rare): W^2 selects per shift would blow the code up; a run-time index (scratch memory) is fine here
+        for (int i = 0; i < W; i++) {
+            int src = i - ws;
+            u64 lo = (src >= 0) ? a.w[src] : 0;
+            u64 hi = (src - 1 >= 0) ? a.w[src - 1] : 0;
+            r.w[i] = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
+        }
     }
     return r;
 }
@@ -93,7 +107,7 @@ template <int W> AC_HD Key<W> key_shr(const Key<W>& a, int s) {
 template <int W> AC_HD Key<W> key_kmask(int k) {
     Key<W> m;
     int bits = 2 * k;
-#pragma unroll
+AC_UNROLL_W
     for (int i = 0; i < W; i++) {
         int lo_bit = 64 * (W - 1 - i);  // bit index of this word's LSB
         int n = bits - lo_bit;
@@ -107,7 +121,7 @@ template <int W> AC_HD Key<W> key_inner_mask(int k, int nlead, int ntrail) {
     Key<W> hi = key_kmask<W>(k - nlead);     // ones for the low 2(k-nlead) bits
     Key<W> lo = key_kmask<W>(ntrail);        // ones for the low 2*ntrail bits
     Key<W> m;
-#pragma unroll
+AC_UNROLL_W
     for (int i = 0; i < W; i++) m.w[i] = hi.w[i] & ~lo.w[i];
     return m;
 }
@@ -115,29 +129,29 @@ template <int W> AC_HD Key<W> key_inner_mask(int k, int nlead, int ntrail) {
 // Reverse complement of a right-aligned 2k-bit value (no dots).
 template <int W> AC_HD Key<W> key_rc(const Key<W>& a, int k) {
     Key<W> t;
-#pragma unroll
+AC_UNROLL_W
     for (int i = 0; i < W; i++) t.w[i] = rev2_64(a.w[W - 1 - i]);
     Key<W> r = key_shr<W>(t, 64 * W - 2 * k);
     Key<W> m = key_kmask<W>(k);
-#pragma unroll
+AC_UNROLL_W
     for (int i = 0; i < W; i++) r.w[i] = (~r.w[i]) & m.w[i];
     return r;
 }
 
 // Rolling updates.  fwd <- (fwd << 2 | c) & mask ;  rc <- (rc >> 2) | ((3-c) << 2(k-1)).
 template <int W> AC_HD void key_roll_fwd(Key<W>& a, u32 c, const Key<W>& kmask) {
-#pragma unroll
+AC_UNROLL_W
     for (int i = 0; i < W - 1; i++) a.w[i] = ((a.w[i] << 2) | (a.w[i + 1] >> 62)) & kmask.w[i];
     a.w[W - 1] = ((a.w[W - 1] << 2) | (u64)c) & kmask.w[W - 1];
 }
 template <int W> AC_HD void key_roll_rc(Key<W>& a, u32 c, int k) {
-#pragma unroll
+AC_UNROLL_W
     for (int i = W - 1; i > 0; i--) a.w[i] = (a.w[i] >> 2) | (a.w[i - 1] << 62);
     a.w[0] >>= 2;
     int bit = 2 * (k - 1);
     int wi = W - 1 - (bit >> 6);
     u64 v = (u64)(3 - c) << (bit & 63);
-#pragma unroll
+AC_UNROLL_W
     for (int i = 0; i < W; i++) a.w[i] |= (i == wi) ? v : 0;   // constant indices only (see key_shr)
 }
 
@@ -153,7 +167,7 @@ template <int W> AC_HD Key<W> text_extract(const u64* bits, u64 p, int k) {
     u64 j0 = p >> 5;
     int o = 2 * (int)(p & 31);
     Key<W> l;
-#pragma unroll
+AC_UNROLL_W
     for (int i = 0; i < W; i++) {
         u64 a = bits[j0 + i], b = bits[j0 + i + 1];
         l.w[i] = o ? ((a << o) | (b >> (64 - o))) : a;
@@ -293,7 +307,7 @@ template <int W> AC_HD Key<W> xk_canonical(const XKmer<W>& x, int k, bool* flipp
     } else if (x.td > 0) {
         key = key_rc<W>(x.fwd, k);
         Key<W> m = key_inner_mask<W>(k, x.td, 0);  // the td former-dot bases became 'T' under rc: clear them
-#pragma unroll
+AC_UNROLL_W
         for (int i = 0; i < W; i++) key.w[i] &= m.w[i];
         ld = x.td; *flipped = true;
     } else {
@@ -312,7 +326,7 @@ template <int W> AC_HD XKmer<W> xk_rc(const XKmer<W>& x, int k) {
     r.fwd = key_rc<W>(x.fwd, k);
     r.ld = x.td; r.td = x.ld;
     Key<W> m = key_inner_mask<W>(k, r.ld, r.td);
-#pragma unroll
+AC_UNROLL_W
     for (int i = 0; i < W; i++) r.fwd.w[i] &= m.w[i];
     return r;
 }
@@ -340,7 +354,7 @@ template <int W> AC_HD bool xk_next(const XKmer<W>& x, int k, int c, XKmer<W>* o
 // 64-bit mix of a key.
 template <int W> AC_HD u64 key_hash(const Key<W>& key) {
     u64 h = 0x9E3779B97F4A7C15ULL;
-#pragma unroll
+AC_UNROLL_W
     for (int i = 0; i < W; i++) {
         h ^= key.w[i];
         h *= 0xff51afd7ed558ccdULL;

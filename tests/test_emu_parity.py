@@ -91,8 +91,8 @@ def test_errors(emu):
         compress_build(10, 1, [(b"." * 5 + b"ACGTACGTACGT" + b"." * 4, 12, 1)], lib_path=emu)
     with pytest.raises(AutocyclerError, match="no sequences"):
         compress_build(9, 1, [], lib_path=emu)
-    with pytest.raises(AutocyclerError, match="not supported"):
-        compress_build(201, 1, [(b"." * 100 + b"A" * 300 + b"." * 100, 300, 1)], lib_path=emu)
+    with pytest.raises(AutocyclerError, match="not supported"):      # above the reference's own limit (compress.rs:56-60)
+        compress_build(503, 1, [(b"." * 251 + b"A" * 600 + b"." * 251, 600, 1)], lib_path=emu)
 
 
 def shared_prefix_case(n, k, seed=3):
@@ -113,3 +113,12 @@ def test_renumber_tie_groups(emu, n, k):
     seqs, fn, hd = shared_prefix_case(n, k)
     parity_util.check_case(k, seqs, fn, hd, lib_path=emu, repair=False)
     parity_util.check_case(k, seqs, fn, hd, lib_path=emu, repair=True)
+
+
+@pytest.mark.parametrize("k", [125, 151, 201, 251, 253, 301, 501])
+def test_wide_keys(emu, k):   # keys of 8 and 16 words: the reference allows --kmer up to 501 (compress.rs:56-60)
+    for seed in (1, 2, 6, 7, 13):
+        seqs, fn, hd = seqgen.make_case(seed, k)
+        parity_util.check_case(k, seqs, fn, hd, lib_path=emu)
+    seqs, fn, hd = shared_prefix_case(12, k)
+    parity_util.check_case(k, seqs, fn, hd, lib_path=emu, repair=False)

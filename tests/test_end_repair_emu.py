@@ -18,7 +18,7 @@ def test_fixed_seqs(emu, k):
     repair_util.check_repair(emu, k, [FIXED[c] for c in "abcde"], ["a.fasta", "b.fna", "c.fa", "d.fasta.gz", "e.fna.gz"], list("abcde"))
 
 
-@pytest.mark.parametrize("k", [3, 5, 7, 11, 21, 31, 51, 101, 123])
+@pytest.mark.parametrize("k", [3, 5, 7, 11, 21, 31, 51, 101, 123, 129, 131, 251, 501])
 def test_adversarial_cases(emu, k):
     total = 0
     for seed in range(24):

@@ -102,3 +102,10 @@ def test_end_repair_then_build_on_the_same_device_text():
     gfa_o, _, _ = s.compress(k)
     loaded = s.all()
     assert graph.gfa([q["filename"] for q in loaded], [q["header"] for q in loaded]) == gfa_o
+
+
+@pytest.mark.parametrize("k", [125, 201, 251, 253, 501])
+def test_wide_keys(k):   # keys of 8 and 16 words (--kmer up to 501, compress.rs:56-60)
+    for seed in (1, 2, 6, 7):
+        seqs, fn, hd = seqgen.make_case(seed, k)
+        parity_util.check_case(k, seqs, fn, hd)

@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--init-builds", type=int, default=2, help="untimed builds before the warmup (one-time process initialisation)")
     ap.add_argument("--repair", choices=["device", "host"], default="device",
                     help="where sequence_end_repair runs (upstream of the timed region): on the device text, or the host implementation")
+    ap.add_argument("--no-independent", action="store_true", help="N > 1: skip the secondary independent-jobs measurement")
     ap.add_argument("--gather-paths", action="store_true",
                     help="sharded mode: gather the paths of all sequences to rank 0 (default: every rank keeps its own P lines)")
     args = ap.parse_args()
@@ -112,11 +113,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # Dry runs of the N > 1 code path on a box with fewer GPUs than ranks: BENCH_FORCE_DEVICE=0 puts every rank on device 0 and
+    # BENCH_BACKEND=gloo moves the collectives through the host (RCCL refuses two ranks on one device).
+    if os.environ.get("BENCH_FORCE_DEVICE") is not None:
+        local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     lib = _capi.load_library()          # raises if the HIP extension is missing: no fallback
     lib.ac_seqs_views.restype = C.POINTER(_capi.SeqView)
@@ -236,6 +245,32 @@ def main():
     else:
         total_bases = float(bases)
 
+    graph_info = {**g.stats_post, "kmers": g.kmer_count}
+    # Secondary figure at N > 1 (not `value`): the same ranks running their slices as N independent compress jobs — no
+    # data-path collective — timed the same way, so that the cost of making it ONE job is visible in the same line.
+    independent = None
+    if world > 1 and mode == "sharded" and not args.no_independent:
+        def step_ind():
+            h = C.c_void_p()
+            rc = lib.ac_compress_build_device(C.c_uint32(k), C.c_uint32(args.assemblies), C.c_void_p(d_text.data_ptr()),
+                                              C.c_uint64(n_text), off, lens, ids, d1, d2, C.c_uint32(n), C.c_int(local_rank), C.byref(h))
+            if rc:
+                raise RuntimeError(lib.ac_last_error().decode())
+            return _capi.Graph(lib, h, n)
+        g.close(); g = None
+        for _ in range(max(args.warmup, 1)):
+            step_ind().close()
+        barrier()
+        t_i = time.perf_counter()
+        for _ in range(args.steps):
+            step_ind().close()
+        barrier()
+        e_i = torch.tensor([time.perf_counter() - t_i], dtype=torch.float64, device=dev)
+        dist.all_reduce(e_i, op=dist.ReduceOp.MAX)
+        independent = {"value": total_bases / 1e6 / (float(e_i.item()) / args.steps), "unit": "Mbp/s",
+                       "ms_per_step": float(e_i.item()) / args.steps * 1e3,
+                       "what": "the same ranks and texts as N independent compress jobs (one per GPU, no data-path collective)"}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_bases / 1e6 / (elapsed / args.steps)
@@ -284,11 +319,13 @@ def main():
             "step_ms_list": [round(x * 1e3, 2) for x in step_s],
             "step_ms": {"min": min(step_s) * 1e3, "median": sorted(step_s)[len(step_s) // 2] * 1e3, "max": max(step_s) * 1e3},
             "stages_s": stage, "stages_note": "from 2 extra untimed builds with per-stage stream syncs (total_device there includes them)",
-            "graph": {**g.stats_post, "kmers": g.kmer_count, "distinct_canonical": tms[-1]["n_distinct"],
+            "graph": {**graph_info, "distinct_canonical": tms[-1]["n_distinct"],
                       "path_entries": tms[-1]["n_path_entries"], "table_capacity": tms[-1]["table_capacity"],
                       "simplify_passes": tms[-1]["simplify_passes"]},
             "prep_s": {"generate": t_gen, "end_repair": t_repair, "end_repair_info": repair_info, "h2d": t_h2d, "h2d_GBps": n_text / t_h2d / 1e9},
         }
+        if independent is not None:
+            line["independent_jobs"] = independent
         if mode == "sharded":
             line["sharded"] = {**last_info, "fragments_rank0": tms[-1]["n_fragments"], "fragment_bytes_rank0": tms[-1]["fragment_bytes"],
                                "local_distinct_rank0": tms[-1]["n_local_distinct"]}

@@ -4,6 +4,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -494,9 +495,13 @@ int ac_compress_dir(const char* assemblies_dir, const char* autocycler_dir, uint
         if (ec) throw UserError(std::string("failed to create directory ") + autocycler_dir + "\n" + ec.message());
         // load (host) -> text layout -> H2D -> end repair on the device text -> graph build from the same buffer
         const bool host_repair = getenv("AC_HOST_REPAIR") != nullptr;      // the host implementation, kept for comparison
+        // the HIP context and the code objects come up on another thread while the host reads the FASTA files
+        std::thread warm([device] { try { device_warmup(device); } catch (...) {} });
+        struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{warm};
         ac_seqs s;
         s.lr = load_sequences(assemblies_dir, k, max_contigs, threads, host_repair);
         s.make_views();
+        warm.join();
         double t0 = now();
         ac_graph* g = nullptr;
         if (host_repair) {
@@ -535,9 +540,8 @@ int ac_compress_dir(const char* assemblies_dir, const char* autocycler_dir, uint
         std::vector<SeqMeta> meta(s.lr.seqs.size());
         for (size_t i = 0; i < meta.size(); i++) meta[i] = SeqMeta{s.lr.seqs[i].id, s.lr.seqs[i].length, s.lr.seqs[i].filename, s.lr.seqs[i].contig_header};
         {
-            std::string gfa = gfa_string(g->g, meta, 3);
             std::ofstream f(fs::path(autocycler_dir) / "input_assemblies.gfa", std::ios::binary);
-            f.write(gfa.data(), (std::streamsize)gfa.size());
+            for (const std::string& piece : gfa_chunks(g->g, meta, threads)) f.write(piece.data(), (std::streamsize)piece.size());
             if (!f) throw UserError("failed to write input_assemblies.gfa");
         }
         {

@@ -2,6 +2,8 @@
 
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <thread>
 
 namespace ac {
 
@@ -32,6 +34,7 @@ std::string gfa_string(const FinalGraph& g, const std::vector<SeqMeta>& seqs, in
     }
     if (parts & 2)
     for (size_t s = 0; s < seqs.size(); s++) {
+        out.reserve(out.size() + (size_t)(g.path_off[s + 1] - g.path_off[s]) * 8 + 512);
         out += "P\t"; put_u64(out, seqs[s].id); out.push_back('\t');
         for (uint64_t i = g.path_off[s]; i < g.path_off[s + 1]; i++) {
             if (i != g.path_off[s]) out.push_back(',');
@@ -42,6 +45,31 @@ std::string gfa_string(const FinalGraph& g, const std::vector<SeqMeta>& seqs, in
         out += "\tFN:Z:"; out += seqs[s].filename; out += "\tHD:Z:"; out += seqs[s].contig_header;
         out.push_back('\n');   // cluster is 0 in compress output: no CL:i tag (unitig_graph.rs:357)
     }
+    return out;
+}
+
+// The same text in pieces built by several threads (H/S/L in one piece, the P lines split by path entries): concatenated in
+// order they are exactly gfa_string().  Used by the whole-command driver, which writes the pieces one after the other.
+std::vector<std::string> gfa_chunks(const FinalGraph& g, const std::vector<SeqMeta>& seqs, int threads) {
+    size_t S = seqs.size();
+    int T = std::max(1, std::min<int>(threads, 64));
+    std::vector<size_t> cut{0};          // sequence ranges with about equal numbers of path entries
+    uint64_t total = g.path_off.empty() ? 0 : g.path_off[S], per = total / (uint64_t)T + 1;
+    for (size_t s = 0; s < S; s++)
+        if (g.path_off[s + 1] >= per * cut.size() && s + 1 < S) cut.push_back(s + 1);
+    cut.push_back(S);
+    std::vector<std::string> out(cut.size());          // out[0] = H, S, L; out[i] = P lines of sequences [cut[i-1], cut[i])
+    auto p_lines = [&](size_t a, size_t b, std::string* dst) {
+        FinalGraph view;       // a shallow view restricted to [a, b): same arrays, shifted offsets
+        std::vector<SeqMeta> sub(seqs.begin() + (long)a, seqs.begin() + (long)b);
+        view.k = g.k; view.path = g.path; view.path_off.assign(g.path_off.begin() + (long)a, g.path_off.begin() + (long)b + 1);
+        view.n_path = view.path_off.back() - view.path_off.front();
+        *dst = gfa_string(view, sub, 2);
+    };
+    std::vector<std::thread> pool;
+    for (size_t i = 1; i < cut.size(); i++) pool.emplace_back(p_lines, cut[i - 1], cut[i], &out[i]);
+    out[0] = gfa_string(g, seqs, 1);
+    for (auto& t : pool) t.join();
     return out;
 }
 

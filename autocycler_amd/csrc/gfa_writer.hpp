@@ -10,4 +10,5 @@ namespace ac {
 struct SeqMeta { uint16_t id; uint32_t length; std::string filename; std::string contig_header; };
 // parts: bit 0 = H, S and L lines, bit 1 = P lines (a sharded build can keep the P lines of each rank's sequences on that rank)
 std::string gfa_string(const FinalGraph& g, const std::vector<SeqMeta>& seqs, int parts = 3);
+std::vector<std::string> gfa_chunks(const FinalGraph& g, const std::vector<SeqMeta>& seqs, int threads);
 }  // namespace ac

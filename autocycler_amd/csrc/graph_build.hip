@@ -1943,6 +1943,19 @@ template struct Stages<AC_W_ONLY>;
 #endif
 
 #if AC_W_ONLY == 0
+void device_warmup(int device) {
+#ifndef AC_EMU
+    AC_HIP_CHECK(hipSetDevice(device));
+    void* p = nullptr;
+    AC_HIP_CHECK(hipMalloc(&p, 4096));
+    hipLaunchKernelGGL(functor_kernel<PackFunctor>, dim3(1), dim3(256), 0, 0, (u64)1, PackFunctor{(const u8*)p, 32, (u64*)((u8*)p + 1024), (u32*)((u8*)p + 2048)});
+    (void)hipDeviceSynchronize();
+    (void)hipFree(p);
+#else
+    (void)device;
+#endif
+}
+
 // ---- GraphBuilder ------------------------------------------------------------------------------------------------
 GraphBuilder::GraphBuilder(uint32_t k) : impl_(new Impl) {
     // A builder owns the arenas for its lifetime (the C ABI serialises builds): whatever the previous build

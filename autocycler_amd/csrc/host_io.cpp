@@ -4,6 +4,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <exception>
 #include <array>
 #include <atomic>
 #include <chrono>
@@ -237,36 +238,59 @@ LoadResult load_sequences(const std::string& assemblies_dir, uint32_t k, uint32_
     LoadResult lr;
     double t0 = now_s();
     std::vector<std::string> assemblies = find_all_assemblies(assemblies_dir);
-    size_t seq_id = 0;
-    for (const std::string& assembly : assemblies) {
-        AssemblyDetails det;
-        det.filename = assembly;                                   // full path (metrics.rs:85)
-        std::string base = fs::path(assembly).filename().string();
-        for (auto& rec : load_fasta(assembly)) {
-            if (rec[2].size() < k) continue;                        // skipped silently, consumes no id
-            if (++seq_id > 32767) throw UserError("no more than 32767 input sequences are allowed");
-            LoadedSeq s;
-            s.id = (uint16_t)seq_id;
-            s.filename = base;
-            {   // header whitespace runs -> single spaces (compress.rs:115)
-                const std::string& hd = rec[1];
-                size_t i = 0;
-                while (i < hd.size()) {
-                    while (i < hd.size() && isspace((unsigned char)hd[i])) i++;
-                    size_t j = i;
-                    while (j < hd.size() && !isspace((unsigned char)hd[j])) j++;
-                    if (j > i) { if (!s.contig_header.empty()) s.contig_header.push_back(' '); s.contig_header.append(hd, i, j - i); }
-                    i = j;
+    // Files are read, checked and padded in parallel; ids are handed out afterwards in file-then-record order, and the first
+    // failing file (in that order) is the one reported, exactly as a sequential reader would.
+    struct PerFile { AssemblyDetails det; std::vector<LoadedSeq> seqs; std::vector<char> ignored; std::exception_ptr err; };
+    std::vector<PerFile> files(assemblies.size());
+    auto load_one = [&](size_t fi) {
+        PerFile& pf = files[fi];
+        try {
+            const std::string& assembly = assemblies[fi];
+            pf.det.filename = assembly;                              // full path (metrics.rs:85)
+            std::string base = fs::path(assembly).filename().string();
+            for (auto& rec : load_fasta(assembly)) {
+                if (rec[2].size() < k) continue;                    // skipped silently, consumes no id
+                LoadedSeq s;
+                s.filename = base;
+                {   // header whitespace runs -> single spaces (compress.rs:115)
+                    const std::string& hd = rec[1];
+                    size_t i = 0;
+                    while (i < hd.size()) {
+                        while (i < hd.size() && isspace((unsigned char)hd[i])) i++;
+                        size_t j = i;
+                        while (j < hd.size() && !isspace((unsigned char)hd[j])) j++;
+                        if (j > i) { if (!s.contig_header.empty()) s.contig_header.push_back(' '); s.contig_header.append(hd, i, j - i); }
+                        i = j;
+                    }
                 }
+                pad_sequence(&s, rec[2], k);
+                size_t sp = s.contig_header.find(' ');
+                pf.det.contigs.push_back({s.contig_header.substr(0, sp), sp == std::string::npos ? "" : s.contig_header.substr(sp + 1), s.length});
+                std::string lower = s.contig_header;
+                for (char& c : lower) c = (char)tolower((unsigned char)c);
+                pf.ignored.push_back(lower.find("autocycler_ignore") != std::string::npos);
+                pf.seqs.push_back(std::move(s));
             }
-            pad_sequence(&s, rec[2], k);
-            size_t sp = s.contig_header.find(' ');
-            det.contigs.push_back({s.contig_header.substr(0, sp), sp == std::string::npos ? "" : s.contig_header.substr(sp + 1), s.length});
-            std::string lower = s.contig_header;
-            for (char& c : lower) c = (char)tolower((unsigned char)c);
-            if (lower.find("autocycler_ignore") == std::string::npos) lr.seqs.push_back(std::move(s));
+        } catch (...) { pf.err = std::current_exception(); }
+    };
+    {
+        int T = std::max(1, std::min<int>(threads, (int)assemblies.size()));
+        std::atomic<size_t> next{0};
+        auto worker = [&] { for (size_t fi; (fi = next.fetch_add(1)) < assemblies.size();) load_one(fi); };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < T; t++) pool.emplace_back(worker);
+        worker();
+        for (auto& t : pool) t.join();
+    }
+    size_t seq_id = 0;
+    for (PerFile& pf : files) {
+        if (pf.err) std::rethrow_exception(pf.err);
+        for (size_t i = 0; i < pf.seqs.size(); i++) {
+            if (++seq_id > 32767) throw UserError("no more than 32767 input sequences are allowed");
+            pf.seqs[i].id = (uint16_t)seq_id;
+            if (!pf.ignored[i]) lr.seqs.push_back(std::move(pf.seqs[i]));
         }
-        lr.details.push_back(std::move(det));
+        lr.details.push_back(std::move(pf.det));
     }
     lr.assembly_count = (uint32_t)assemblies.size();
     lr.total_contigs_seen = (uint32_t)seq_id;

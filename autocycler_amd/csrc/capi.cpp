@@ -347,6 +347,17 @@ int ac_end_repair_device(uint32_t k, void* d_text, uint64_t n_text, const uint64
     });
 }
 
+// pairwise_contig_distances (cluster.rs:132-157), the first step of `autocycler cluster`, on the graph just built.
+int ac_pairwise_distances(const ac_graph* g, int device, double* out) {
+    return guarded([&] {
+        if (!g->host_arrays || !g->host_paths) throw DeviceError("this rank kept no host arrays (sharded build, not the writing rank)");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
+        select_device(device);
+        pairwise_distances_device(g->g, (uint32_t)g->seq_ids.size(), out);
+    });
+}
+
 uint64_t ac_kmer_count(const ac_graph* g) { return g->g.n_kmers; }
 ac_stats ac_stats_pre(const ac_graph* g) { return ac_stats{g->g.pre.unitigs, g->g.pre.links_one_way, g->g.pre.total_length}; }
 ac_stats ac_stats_post(const ac_graph* g) { return ac_stats{g->g.post.unitigs, g->g.post.links_one_way, g->g.post.total_length}; }

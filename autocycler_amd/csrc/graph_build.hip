@@ -2346,6 +2346,63 @@ void end_repair_device(uint32_t k, uint8_t* d_text, uint64_t n_text, const std::
     else end_repair_impl<8>(k, d_text, n_text, off, len, d1, d2, tm);      // literals of up to 250 bases (k <= 501)
 }
 
+// =============================================================================================================
+// pairwise_contig_distances (cluster.rs:132-157; SURVEY.md §8 "next" row f-3): the first step of `autocycler cluster` on the
+// graph `compress` has just built.  distance(a, b) = 1 - len(U_a ∩ U_b) / len(U_a), U_s = set of unitigs on the path of s
+// (strand and multiplicity ignored).  One bitset of U bits per sequence; one wavefront per pair ANDs the two bitsets and sums
+// the lengths of the common unitigs (integers: exact, any summation order).
+struct PathBitsFunctor {      // one thread per path entry
+    const int32_t* path; const u64* path_off; u32 n_seqs; u64 n_ent; u64 words; u32* bits32;
+    AC_D void operator()(u64 i) const {
+        u32 lo = 0, hi = n_seqs;   // largest s with path_off[s] <= i
+        while (hi - lo > 1) { u32 mid = lo + ((hi - lo) >> 1); if (path_off[mid] <= i) lo = mid; else hi = mid; }
+        u32 u = idx_of(path[i]);
+        atomic_or32(&bits32[(u64)lo * words * 2 + (u >> 5)], 1u << (u & 31));
+    }
+};
+struct PairLenFunctor {       // thread t of pair p = t / 64 takes the words lane, lane + 64, ... of the two bitsets
+    const u64* bits; u64 words; const u32* ulen; u32 n_seqs; u64* ab;
+    AC_D void operator()(u64 tid, bool valid) const {
+        if (!valid) return;
+        u64 pair = tid >> 6;
+        u32 lane = (u32)(tid & 63);
+        u32 a = (u32)(pair / n_seqs), b = (u32)(pair % n_seqs);
+        const u64* A = bits + (u64)a * words; const u64* B = bits + (u64)b * words;
+        u64 sum = 0;
+        for (u64 w = lane; w < words; w += 64) {
+            u64 x = A[w] & B[w];
+            while (x) { u64 low = x & (~x + 1); sum += ulen[w * 64 + (u64)popc64(low - 1)]; x ^= low; }
+        }
+#ifndef AC_EMU
+#pragma unroll
+        for (int o = 32; o; o >>= 1) sum += (u64)__shfl_xor((unsigned long long)sum, o);
+        if (lane == 0) ab[pair] = sum;
+#else
+        atomic_add64(&ab[pair], sum);
+#endif
+    }
+};
+void pairwise_distances_device(const FinalGraph& g, uint32_t n_seqs, double* out) {
+    if (n_seqs == 0 || g.path_off.size() != (size_t)n_seqs + 1) throw DeviceError("pairwise distances: the graph holds no paths");
+    const u32 U = g.n_unitigs;
+    const u64 n_ent = g.n_path, words = ((u64)U + 63) / 64;
+    Arena::device().reset();
+    DBuf<int32_t> d_path(n_ent); DBuf<u64> d_off((size_t)n_seqs + 1); DBuf<u32> d_len(words * 64);
+    DBuf<u64> bits((u64)n_seqs * words), ab((u64)n_seqs * n_seqs);
+    copy_h2d(d_path.ptr(), g.path, n_ent * 4);
+    copy_h2d(d_off.ptr(), g.path_off.data(), ((size_t)n_seqs + 1) * 8);
+    d_len.fill_bytes(0);
+    copy_h2d(d_len.ptr(), g.seq_len, (size_t)U * 4);
+    bits.fill_bytes(0); ab.fill_bytes(0);
+    launch(n_ent, PathBitsFunctor{d_path.ptr(), d_off.ptr(), n_seqs, n_ent, words, (u32*)bits.ptr()});
+    launch_full((u64)n_seqs * n_seqs * 64, PairLenFunctor{bits.ptr(), words, d_len.ptr(), n_seqs, ab.ptr()});
+    std::vector<u64> h = to_host(ab, (size_t)n_seqs * n_seqs);
+    for (u32 a = 0; a < n_seqs; a++) {
+        double a_len = (double)(uint32_t)h[(size_t)a * n_seqs + a];        // |U_a ∩ U_a|; the reference sums a_len in u32
+        for (u32 b = 0; b < n_seqs; b++) out[(size_t)a * n_seqs + b] = 1.0 - ((double)h[(size_t)a * n_seqs + b] / a_len);
+    }
+}
+
 #endif   // AC_W_ONLY == 0
 
 }  // namespace ac

@@ -103,6 +103,9 @@ struct RepairTimings { double total = 0, scan_ms = 0; uint64_t hits = 0, matches
 void end_repair_device(uint32_t k, uint8_t* d_text, uint64_t n_text, const std::vector<uint64_t>& off, const std::vector<uint32_t>& len,
                        std::vector<uint16_t>* d1, std::vector<uint16_t>* d2, RepairTimings* tm);
 
+// pairwise_contig_distances (cluster.rs:132-157) on the final graph: out[a * n_seqs + b], sequences in path order.
+void pairwise_distances_device(const FinalGraph& g, uint32_t n_seqs, double* out);
+
 // Brings the HIP context and this library's code objects up on `device` (first use costs ~0.2 s): callable from a helper
 // thread while the caller is still busy on the host.
 void device_warmup(int device);

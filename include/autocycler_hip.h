@@ -133,6 +133,11 @@ int ac_path_counts(const ac_graph*, uint64_t* counts /* ac_graph_seq_count() */)
 int ac_end_repair_device(uint32_t k, void* d_text, uint64_t n_text, const uint64_t* seq_off, const uint32_t* seq_len,
                          uint16_t* seq_d1, uint16_t* seq_d2, uint32_t n_seqs, int device, double* seconds, uint64_t* n_matches);
 
+/* pairwise_contig_distances (cluster.rs:132-157), the first step of `autocycler cluster`, computed on the device from the
+ * graph this library has just built: out[a * S + b] = 1 - len(unitigs shared by the paths of a and b) / len(unitigs of a),
+ * S = ac_graph_seq_count(), sequences in input order. */
+int ac_pairwise_distances(const ac_graph*, int device, double* out);
+
 /* Host helper: lay sequences out as the text described above.  text must hold ac_text_size() bytes. */
 uint64_t ac_text_size(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs);
 int ac_layout_text(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs, uint8_t* text, uint64_t* seq_off,

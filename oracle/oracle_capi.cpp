@@ -2,6 +2,8 @@
 // (ctypes), smoke() and bench.py's cpu_baseline leg.  Returned strings are malloc'd; free with
 // orc_free().  Every call returns 0 on success; on failure orc_last_error() holds the message
 // (the reference would have printed "Error: ..." and exited, or panicked: misc.rs:131-142).
+#include <map>
+#include <set>
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -313,6 +315,36 @@ int orc_decompress(const char* gfa, char** out) {
         std::string o;
         for (auto& [f, h, s] : g.reconstruct_original_sequences(seqs)) o += f + "\t" + h + "\t" + s + "\n";
         *out = dup_str(o);
+    });
+}
+
+// cluster.rs:132-157 pairwise_contig_distances: distance(a, b) = 1 - (summed length of the unitigs shared by the paths of a
+// and b) / (summed length of the unitigs of a's path); unitig sets ignore strand and multiplicity.  out: S*S doubles,
+// out[a*S + b], sequences in GFA P-line order.
+int orc_pairwise_distances(const char* gfa, double* out, uint32_t* n_seqs) {
+    return guarded([&] {
+        auto [g, seqs] = UnitigGraph::from_gfa_lines(split_lines(gfa));
+        std::map<uint32_t, uint32_t> unitig_lengths;
+        for (auto& u : g.unitigs) unitig_lengths[u->number] = u->length();
+        std::vector<std::set<uint32_t>> sets;
+        for (auto& s : seqs) {
+            std::set<uint32_t> st;
+            for (auto& [number, strand] : g.get_unitig_path_for_sequence(s)) { (void)strand; st.insert(number); }
+            sets.push_back(std::move(st));
+        }
+        size_t S = seqs.size();
+        if (n_seqs) *n_seqs = (uint32_t)S;
+        if (!out) return;
+        for (size_t a = 0; a < S; a++) {
+            uint32_t a_sum = 0;
+            for (uint32_t u : sets[a]) a_sum += unitig_lengths[u];
+            double a_len = (double)a_sum;
+            for (size_t b = 0; b < S; b++) {
+                double ab_len = 0;
+                for (uint32_t u : sets[a]) if (sets[b].count(u)) ab_len += (double)unitig_lengths[u];
+                out[a * S + b] = 1.0 - (ab_len / a_len);
+            }
+        }
     });
 }
 

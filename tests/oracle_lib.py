@@ -107,6 +107,16 @@ def decompress(gfa):
     return [tuple(l.split("\t")) for l in _str_call(lib().orc_decompress, _b(gfa)).splitlines()]
 
 
+def pairwise_distances(gfa):
+    """cluster.rs:132-157 on a GFA text -> S x S list of lists (row a, column b)."""
+    n = C.c_uint32()
+    _check(lib().orc_pairwise_distances(_b(gfa), None, C.byref(n)))
+    S = n.value
+    out = (C.c_double * (S * S))()
+    _check(lib().orc_pairwise_distances(_b(gfa), out, C.byref(n)))
+    return [[out[a * S + b] for b in range(S)] for a in range(S)]
+
+
 class Seqs:
     """Loaded (padded, end-repaired) sequences as the reference has them at compress.rs:41."""
 

@@ -11,7 +11,7 @@ def first_diff(a, b):
     return f"line counts differ: oracle={len(la)} got={len(lb)}"
 
 
-def check_case(k, seqs, filenames, headers, lib_path=None, repair=True, device=0):
+def check_case(k, seqs, filenames, headers, lib_path=None, repair=True, device=0, distances=False):
     s = O.Seqs.from_raw(k, seqs, filenames=filenames, headers=headers, repair=repair)
     gfa_o, st, _ = s.compress(k)
     loaded = s.all()
@@ -22,4 +22,6 @@ def check_case(k, seqs, filenames, headers, lib_path=None, repair=True, device=0
     assert g.stats_pre == dict(unitigs=st["unitigs_pre"], links=st["links_pre"], total_length=st["length_pre"])
     assert g.stats_post == dict(unitigs=st["unitigs_post"], links=st["links_post"], total_length=st["length_post"])
     assert gfa_o == gfa_g, first_diff(gfa_o, gfa_g)
+    if distances:     # cluster.rs:132-157 on the same graph: exact f64 equality (integer sums, one division)
+        assert g.pairwise_distances(device) == O.pairwise_distances(gfa_o)
     return g, gfa_g, loaded

@@ -122,3 +122,10 @@ def test_wide_keys(emu, k):   # keys of 8 and 16 words: the reference allows --k
         parity_util.check_case(k, seqs, fn, hd, lib_path=emu)
     seqs, fn, hd = shared_prefix_case(12, k)
     parity_util.check_case(k, seqs, fn, hd, lib_path=emu, repair=False)
+
+
+@pytest.mark.parametrize("k", [5, 11, 51])
+def test_pairwise_distances(emu, k):   # cluster.rs:132-157 on the graph just built
+    for seed in range(24):
+        seqs, fn, hd = seqgen.make_case(seed, k)
+        parity_util.check_case(k, seqs, fn, hd, lib_path=emu, distances=True)

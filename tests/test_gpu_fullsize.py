@@ -111,7 +111,21 @@ def test_config_b_12_assemblies():
 
 
 def test_config_c_96_assemblies():
+    import time
     g, seqs, fn, hd = build(96)
     U = check_properties(g, seqs, 51)
     assert U > 10000
     assert g.stats_post["total_length"] < g.stats_pre["total_length"]
+    # pairwise_contig_distances (cluster.rs:132-157) on the device against a numpy restatement, every 7th row
+    t0 = time.time()
+    d = g.pairwise_distances()
+    dt = time.time() - t0
+    print(f"pairwise distances of {len(seqs)} sequences on the device: {dt * 1e3:.1f} ms")
+    ulen = np.array([len(g.unitig(i)[0]) for i in range(U)], dtype=np.int64)
+    sets = [np.unique(np.abs(np.asarray(g.path(s), dtype=np.int64)) - 1) for s in range(len(seqs))]
+    for a in range(0, len(seqs), 7):
+        a_len = float(ulen[sets[a]].sum())
+        for b in range(len(seqs)):
+            ab = float(ulen[np.intersect1d(sets[a], sets[b], assume_unique=True)].sum())
+            assert d[a][b] == 1.0 - ab / a_len, (a, b)
+        assert d[a][a] == 0.0

@@ -109,3 +109,12 @@ def test_wide_keys(k):   # keys of 8 and 16 words (--kmer up to 501, compress.rs
     for seed in (1, 2, 6, 7):
         seqs, fn, hd = seqgen.make_case(seed, k)
         parity_util.check_case(k, seqs, fn, hd)
+
+
+@pytest.mark.parametrize("k", [11, 51])
+def test_pairwise_distances(k):   # cluster.rs:132-157 on the graph just built
+    for seed in range(24):
+        seqs, fn, hd = seqgen.make_case(seed, k)
+        parity_util.check_case(k, seqs, fn, hd, distances=True)
+    seqs, fn, hd = _synth_case(8, 200_000, 8_000, 1e-3, 1e-4, 4242)
+    parity_util.check_case(k, seqs, fn, hd, distances=True)

@@ -515,8 +515,12 @@ inline void exclusive_scan_u64(const u64* in, u64* out, size_t n, stream_t s = 0
 
 // Segmented reduction of `vals` over runs of equal consecutive `seg` ids (ids are 0,1,2,... in order,
 // so run r reduces into out[r]).
+struct CountCheckFunctor {    // sets an error bit instead of making the host wait for the segment count
+    const u32* cnt; u32 expected; u32* err; u32 bit;
+    AC_D void operator()(u64) const { if (*cnt != expected) atomic_or32(err, bit); }
+};
 template <class V, class Op>
-inline void reduce_by_segment(const u32* seg, const V* vals, size_t n, V* out, size_t n_segments, Op op, stream_t s = 0) {
+inline void reduce_by_segment(const u32* seg, const V* vals, size_t n, V* out, size_t n_segments, Op op, u32* err = nullptr, stream_t s = 0) {
     if (!n) return;
 #ifdef AC_EMU
     size_t r = 0;
@@ -535,8 +539,8 @@ inline void reduce_by_segment(const u32* seg, const V* vals, size_t n, V* out, s
     AC_HIP_CHECK(rocprim::reduce_by_key(nullptr, tmp_bytes, seg, vals, n, uniq.ptr(), out, cnt.ptr(), op, rocprim::equal_to<u32>(), s));
     DBuf<u8> tmp(tmp_bytes);
     AC_HIP_CHECK(rocprim::reduce_by_key(tmp.ptr(), tmp_bytes, seg, vals, n, uniq.ptr(), out, cnt.ptr(), op, rocprim::equal_to<u32>(), s));
-    u32 c = read_scalar(cnt.ptr(), s);
-    if (c != n_segments) throw DeviceError("reduce_by_segment: segment count mismatch");
+    if (err) launch(1, CountCheckFunctor{cnt.ptr(), (u32)n_segments, err, 128u}, s);
+    else if (read_scalar(cnt.ptr(), s) != n_segments) throw DeviceError("reduce_by_segment: segment count mismatch");
 #endif
 }
 
@@ -544,7 +548,7 @@ inline void reduce_by_segment(const u32* seg, const V* vals, size_t n, V* out, s
 // position i is the index i itself, `op(a, b)` returns whichever of two indices wins.  No value array is materialised: the
 // indices come from a counting iterator and the operator looks at whatever the indices stand for.
 template <class Op>
-inline void segment_argmin(const u32* seg, size_t n, u32* out, size_t n_segments, Op op, stream_t s = 0) {
+inline void segment_argmin(const u32* seg, size_t n, u32* out, size_t n_segments, Op op, u32* err = nullptr, stream_t s = 0) {
     if (!n) return;
 #ifdef AC_EMU
     size_t r = 0;
@@ -564,8 +568,8 @@ inline void segment_argmin(const u32* seg, size_t n, u32* out, size_t n_segments
     AC_HIP_CHECK(rocprim::reduce_by_key(nullptr, tmp_bytes, seg, idx, n, uniq.ptr(), out, cnt.ptr(), op, rocprim::equal_to<u32>(), s));
     DBuf<u8> tmp(tmp_bytes);
     AC_HIP_CHECK(rocprim::reduce_by_key(tmp.ptr(), tmp_bytes, seg, idx, n, uniq.ptr(), out, cnt.ptr(), op, rocprim::equal_to<u32>(), s));
-    u32 c = read_scalar(cnt.ptr(), s);
-    if (c != n_segments) throw DeviceError("segment_argmin: segment count mismatch");
+    if (err) launch(1, CountCheckFunctor{cnt.ptr(), (u32)n_segments, err, 128u}, s);
+    else if (read_scalar(cnt.ptr(), s) != n_segments) throw DeviceError("segment_argmin: segment count mismatch");
 #endif
 }
 

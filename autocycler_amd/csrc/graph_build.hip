@@ -997,11 +997,12 @@ struct LevelKeyFunctor {
     const u32* level; u64* key;
     AC_HD void operator()(u64 ci) const { key[ci] = ((u64)level[ci] << 32) | ci; }
 };
-struct LevelBoundsFunctor {   // keys sorted by (level, visiting position): first index of every level
-    const u64* key; u64 n; u32* bstart;
+struct LevelBoundsFunctor {   // keys sorted by (level >= 1, visiting position): bstart[lv] = first index of level lv (lv <= cap),
+    const u64* key; u64 n; u32* bstart; u32 cap;      // bstart[0] = number of levels
     AC_HD void operator()(u64 i) const {
         u32 lv = (u32)(key[i] >> 32);
-        if (i == 0 || (u32)(key[i - 1] >> 32) != lv) bstart[lv] = (u32)i;
+        if ((i == 0 || (u32)(key[i - 1] >> 32) != lv) && lv <= cap) bstart[lv] = (u32)i;
+        if (i + 1 == n) bstart[0] = lv;
     }
 };
 // A unitig strand's current sequence as seen by one junction: the descriptor is read once, after that every character
@@ -1510,7 +1511,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
     u64 est = pt.n_bases / hint;
     u64 c = next_pow2(std::max<u64>(1024, est * 3 + 4096));
     if (c > next_pow2(pt.n_bases * 2 + 1024)) c = next_pow2(pt.n_bases * 2 + 1024);
-    DBuf<InsertStats> istats(256);
+    DBuf<InsertStats> istats(257);       // [256].real doubles as the kernel's error word: one D2H reads everything
     DBuf<u64> sl;
     u64 n_distinct = 0;
     for (;;) {
@@ -1518,6 +1519,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
         sl.fill_bytes(0xFF);
         counters.fill_bytes(0);
         istats.fill_bytes(0);
+        u32* ierr = (u32*)&istats.ptr()[256].real;
         Table tb{sl.ptr(), c - 1, nullptr};
         stream_sync();
 #ifndef AC_EMU
@@ -1539,18 +1541,17 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
                 u32 chunk = (u32)std::min<u64>(std::max<u64>(c, 256), wave_chunk_max());
                 u64 n_waves = (len + chunk - 1) / chunk;
 #ifdef AC_EMU
-                launch(n_waves, InsertWaveEmuFunctor<W>{t, tb, pb, pe, chunk, istats.ptr(), counters.ptr() + 1});
+                launch(n_waves, InsertWaveEmuFunctor<W>{t, tb, pb, pe, chunk, istats.ptr(), ierr});
 #else
                 u64 blocks = (n_waves + 3) / 4;
                 if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
-                hipLaunchKernelGGL(insert_wave_kernel<W>, dim3((unsigned)blocks), dim3(256), 0, 0, t, tb, pb, pe, chunk, istats.ptr(),
-                                   counters.ptr() + 1);
+                hipLaunchKernelGGL(insert_wave_kernel<W>, dim3((unsigned)blocks), dim3(256), 0, 0, t, tb, pb, pe, chunk, istats.ptr(), ierr);
                 AC_HIP_CHECK(hipGetLastError());
 #endif
             } else {                          // one thread per chunk (kept for comparison: AC_INSERT_VARIANT=1)
                 u32 chunk = 64;
                 while (chunk < 1024 && len / chunk > (1u << 19)) chunk *= 2;   // >= ~0.5 M threads when the phase is long
-                launch((len + chunk - 1) / chunk, InsertFunctor<W>{t, tb, pb, pe, chunk, istats.ptr(), counters.ptr() + 1});
+                launch((len + chunk - 1) / chunk, InsertFunctor<W>{t, tb, pb, pe, chunk, istats.ptr(), ierr});
             }
             launches++;
             pb = pe;
@@ -1563,12 +1564,13 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 #endif
         tm->insert_launches += launches;
-        std::vector<u32> cc = to_host(counters, 2);
-        std::vector<InsertStats> st = to_host(istats, 256);
+        std::vector<InsertStats> st = to_host(istats, 257);
+        const bool ins_err = st[256].real != 0;
+        st.pop_back();
         n_distinct = 0;
         u64 real = 0;
         for (auto& x : st) { n_distinct += x.claimed; real += x.real; }
-        bool overflow = (cc[1] != 0) || (n_distinct * 10 > c * 7);
+        bool overflow = ins_err || (n_distinct * 10 > c * 7);
         if (!overflow) { tm->insert_real += real; tm->insert_positions += pt.n_text; break; }
         if (c >= next_pow2(pt.n_bases * 4 + 1024)) throw DeviceError("k-mer table overflow");
         c *= 4;
@@ -1676,10 +1678,10 @@ template <int W> void GraphBuilder::Impl::unitigs() {
     if constexpr (W <= 4) {
         DBuf<MinVal<W>> vals(N); DBuf<u32> seg(N);
         launch(N, CKeyFunctor<W>{t, npos.ptr(), scan.ptr(), vals.ptr(), seg.ptr()});
-        reduce_by_segment(seg.ptr(), vals.ptr(), N, umin.ptr(), U, MinOp<W>());
+        reduce_by_segment(seg.ptr(), vals.ptr(), N, umin.ptr(), U, MinOp<W>(), counters.ptr() + 3);
     } else {      // wide keys: arg-min over indices, the keys recomputed from the text inside the operator
         DBuf<u32> umin_idx(U);
-        segment_argmin(scan.ptr(), N, umin_idx.ptr(), U, MinIdxOp<W>{t, npos.ptr()});      // scan[i] = unitig of novel k-mer i
+        segment_argmin(scan.ptr(), N, umin_idx.ptr(), U, MinIdxOp<W>{t, npos.ptr()}, counters.ptr() + 3);      // scan[i] = unitig of novel k-mer i
         launch(U, UnitigMinFunctor<W>{t, npos.ptr(), umin_idx.ptr(), umin.ptr()});
     }
     lap(&tm->minkey);
@@ -1777,10 +1779,11 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     u32 n_cand = 0, n_levels = 0;
     {
         u64 J = (u64)U * 2;
-        DBuf<u32> cflag(J), cpos(J), prio(J);
+        DBuf<u32> cflag(J + 1), cpos(J + 1), prio(J);
+        cflag.fill_bytes(0);       // [J] = 0: the exclusive scan then ends with the total
         launch(J, CandFlagFunctor{order1.ptr(), cand.ptr(), cflag.ptr()});
-        exclusive_scan_u32(cflag.ptr(), cpos.ptr(), J);
-        n_cand = read_scalar(cpos.ptr() + (J - 1)) + read_scalar(cflag.ptr() + (J - 1));
+        exclusive_scan_u32(cflag.ptr(), cpos.ptr(), J + 1);
+        n_cand = read_scalar(cpos.ptr() + J);
         if (n_cand == 0) {
             passes = 1;   // the reference's single pass that moves nothing
         } else {
@@ -1789,35 +1792,47 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             prio.fill_bytes(0xFF);
             launch(J, CandListFunctor{order1.ptr(), cflag.ptr(), cpos.ptr(), clist.ptr(), prio.ptr()});
             launch(C, FillU32Functor{level.ptr(), 1u});
-            DBuf<u32> changed(1);
-            for (;;) {   // longest-path levels of the conflict DAG by relaxation (monotone, so stale reads only delay)
-                changed.fill_bytes(0);
-                for (int it = 0; it < 4; it++)
-                    launch(C, LevelRelaxFunctor{L, cand.ptr(), clist.ptr(), prio.ptr(), level.ptr(), changed.ptr()});
-                if (read_scalar(changed.ptr()) == 0) break;
+            DBuf<u32> changed(8);
+            for (;;) {   // longest-path levels of the conflict DAG by relaxation (monotone, so stale reads only delay); eight
+                changed.fill_bytes(0);       // sweeps per host check, converged when the last of them changed nothing
+                for (int it = 0; it < 8; it++)
+                    launch(C, LevelRelaxFunctor{L, cand.ptr(), clist.ptr(), prio.ptr(), level.ptr(), changed.ptr() + it});
+                if (to_host(changed, 8)[7] == 0) break;
             }
             DBuf<u64> lkey(C);
             launch(C, LevelKeyFunctor{level.ptr(), lkey.ptr()});
             sort_pairs_u64_u32(lkey, clist, C, 64);
-            n_levels = (u32)(read_scalar(lkey.ptr() + (C - 1)) >> 32);
-            DBuf<u32> bstart((u64)n_levels + 2);
-            launch(C, LevelBoundsFunctor{lkey.ptr(), C, bstart.ptr()});
-            std::vector<u32> hb = to_host(bstart, (u64)n_levels + 2);
+            // first index of every level; [0] = number of levels (levels beyond the table: a second, exact read)
+            const u32 LV_TABLE = 1024;
+            DBuf<u32> bstart((u64)LV_TABLE + 2);
+            launch(C, LevelBoundsFunctor{lkey.ptr(), C, bstart.ptr(), LV_TABLE});
+            std::vector<u32> hb = to_host(bstart, (u64)LV_TABLE + 2);
+            n_levels = hb[0];
+            if (n_levels > LV_TABLE) {
+                DBuf<u32> big((u64)n_levels + 2);
+                launch(C, LevelBoundsFunctor{lkey.ptr(), C, big.ptr(), n_levels});
+                hb = to_host(big, (u64)n_levels + 2);
+            }
+            hb.resize((size_t)n_levels + 2);
             hb[n_levels + 1] = (u32)C;
             ExpState e{cur, coff.ptr(), clen.ptr(), pre_off.ptr(), pre_len.ptr(), post_off.ptr(), post_len.ptr(), pool.ptr(),
                        pool_used.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), dirty.ptr(), cand.ptr(), L, shifted.ptr()};
             pool_used.fill_bytes(0);
             u64 moved = 0;
-            for (;;) {
-                shifted.fill_bytes(0);
-                for (u32 lv = 1; lv <= n_levels; lv++)
-                    launch_full((u64)(hb[lv + 1] - hb[lv]), ExpandFunctor{e, clist.ptr(), (u64)hb[lv], (u32)pool.size(), counters.ptr() + 7});
-                passes++;
-                u64 sh = read_scalar(shifted.ptr());
-                if (sh == 0) break;
-                moved += sh;
+            DBuf<u64> shifted2(2);
+            for (;;) {   // two passes per host check: if the first moved nothing the second is an (uncounted) no-op
+                shifted2.fill_bytes(0);
+                for (int half = 0; half < 2; half++) {
+                    e.shifted = shifted2.ptr() + half;
+                    for (u32 lv = 1; lv <= n_levels; lv++)
+                        launch_full((u64)(hb[lv + 1] - hb[lv]), ExpandFunctor{e, clist.ptr(), (u64)hb[lv], (u32)pool.size(), counters.ptr() + 7});
+                }
+                std::vector<u64> sh = to_host(shifted2, 2);
+                moved += sh[0] + sh[1];
+                if (sh[0] == 0) { passes += 1; break; }
+                passes += 2;
+                if (sh[1] == 0) break;
             }
-            if (read_scalar(counters.ptr() + 7)) throw DeviceError("internal error: expand_repeats pool overflow");
             if (moved) {   // rewrite the sequences contiguously, once
                 launch((u64)U + 1, ExpLenFunctor{e, len64.ptr(), U});
                 exclusive_scan_u64(len64.ptr(), noff.ptr(), (u64)U + 1);
@@ -1893,6 +1908,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     out->path_off = to_host(path_off, (size_t)n_seqs + 1);
     std::vector<u32> errs = to_host(counters, 8);   // synchronises stream 0
     side.sync();                                    // ... and the copies: everything above has landed
+    if (errs[7]) throw DeviceError("internal error: expand_repeats pool overflow");
     if (errs[3] || errs[4])
         throw DeviceError("internal error: inconsistent unitig ends (codes " + std::to_string(errs[3]) + "/" + std::to_string(errs[4]) + ")");
     if (want_graph) {

@@ -1413,7 +1413,7 @@ static size_t arena_estimate(u64 n_text, bool owns_text) { return (size_t)n_text
 // Tuning knobs of the insert (environment, read once): AC_INSERT_VARIANT=1 selects the thread-per-chunk kernel,
 // AC_INSERT_CHUNK the largest wavefront chunk (positions).
 static int insert_variant() { static int v = [] { const char* e = getenv("AC_INSERT_VARIANT"); return e ? atoi(e) : 0; }(); return v; }
-static u64 wave_chunk_max() { static u64 v = [] { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 4096; return (std::max<u64>(x, 256) + 63) & ~63ULL; }(); return v; }
+static u64 wave_chunk_max() { static u64 v = [] { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }(); return v; }
 
 // A text resident in HBM with its sequence table and its 2-bit packing.
 struct PackedText {

@@ -2159,9 +2159,15 @@ template <int WL> struct EndScanFunctor {   // a thread owns the literal-length 
 #pragma unroll
         for (int i = 0; i < WL; i++) key.w[i] = 0;
         int run = 0;
+        u64 wbits = 0; u32 wmask = 0;       // the current 32-base word of the packed text and its mask bits, in registers
         for (u64 b = p0; b < bend; b++) {
-            if (text_mask(mask, b)) { run = 0; continue; }
-            key_roll_fwd<WL>(key, text_code(bits, b), km);
+            const u32 o = (u32)(b & 31);
+            if (o == 0 || b == p0) {
+                wbits = bits[b >> 5];
+                wmask = (u32)(mask[b >> 6] >> (32 * ((b >> 5) & 1)));
+            }
+            if ((wmask >> o) & 1) { run = 0; continue; }
+            key_roll_fwd<WL>(key, (u32)(wbits >> (62 - 2 * o)) & 3u, km);
             if (++run < lit) continue;
             u64 h = key_hash<WL>(key);
             u64 fb = h >> 44;                                       // 2^20-bit filter

@@ -13,11 +13,21 @@ def load(path):
     return {r["Name"]: float(r[[c for c in r if c.endswith("_per_build")][0]]) * 1024 for r in csv.DictReader(open(path))}
 
 
+def per_dispatch(path, pat):
+    """Bytes per dispatch of the kernels matching pat (PackFunctor also runs inside the end repair, so per-build is not per-call)."""
+    tot = n = 0.0
+    for r in csv.DictReader(open(path)):
+        if pat in r["Name"]:
+            tot += float(r[[c for c in r if c.endswith("_sum")][0]]) * 1024
+            n += float(r["Dispatches"])
+    return tot / n if n else 0.0
+
+
 def main(fetch_csv, write_csv, n_text, tag):
     f, w = load(fetch_csv), load(write_csv)
     pick = lambda d, pat: sum(v for k, v in d.items() if pat in k)
     n_text = int(n_text)
-    pf, pw = pick(f, "PackFunctor"), pick(w, "PackFunctor")
+    pf, pw = per_dispatch(fetch_csv, "PackFunctor"), per_dispatch(write_csv, "PackFunctor")
     fcal, wcal = pf / n_text, pw / (0.375 * n_text)
     fcorr = 2.0 if 0.4 < fcal < 0.6 else 1.0     # gfx950: 128-B requests tallied at 64 B (MI355X_MICROARCH.md, HBM section)
     kf, kw = pick(f, "insert_wave_kernel"), pick(w, "insert_wave_kernel")

@@ -54,7 +54,7 @@ EXPORTS = ["ac_compress_build", "ac_compress_build_device", "ac_text_size", "ac_
            "ac_path", "ac_timings_get", "ac_free", "ac_gfa_string", "ac_string_free", "ac_last_error",
            "ac_device_count", "ac_max_kmer", "ac_version", "ac_set_stage_timing", "ac_end_repair_device", "ac_pairwise_distances",
            "ac_shard_begin", "ac_shard_fragment_sizes", "ac_shard_fragments_export", "ac_shard_build_union",
-           "ac_shard_unitig_count", "ac_shard_distinct_count", "ac_shard_degrees_export", "ac_shard_build_graph", "ac_gfa_string_parts", "ac_shard_reduce_export", "ac_shard_reduce_import", "ac_shard_finish",
+           "ac_shard_unitig_count", "ac_shard_local_distinct", "ac_shard_set_distinct_upper_bound", "ac_shard_distinct_count", "ac_shard_degrees_export", "ac_shard_build_graph", "ac_gfa_string_parts", "ac_shard_reduce_export", "ac_shard_reduce_import", "ac_shard_finish",
            "ac_shard_path_entries", "ac_shard_paths_export", "ac_shard_free", "ac_graph_set_paths", "ac_graph_seq_count", "ac_path_counts",
            "ac_seqs_load", "ac_seqs_from_raw", "ac_seqs_count", "ac_seqs_assembly_count", "ac_seqs_views", "ac_seqs_get",
            "ac_seqs_repair_seconds", "ac_seqs_metrics_yaml", "ac_seqs_free", "ac_compress_seqs", "ac_compress_dir"]
@@ -98,6 +98,10 @@ def load_library(path=None):
     lib.ac_timings_get.argtypes = [C.c_void_p, C.POINTER(Timings)]
     lib.ac_shard_unitig_count.restype = C.c_uint32
     lib.ac_shard_unitig_count.argtypes = [C.c_void_p]
+    lib.ac_shard_local_distinct.restype = C.c_uint64
+    lib.ac_shard_local_distinct.argtypes = [C.c_void_p]
+    lib.ac_shard_set_distinct_upper_bound.argtypes = [C.c_void_p, C.c_uint64]
+    lib.ac_shard_set_distinct_upper_bound.restype = None
     lib.ac_shard_distinct_count.restype = C.c_uint64
     lib.ac_shard_distinct_count.argtypes = [C.c_void_p]
     lib.ac_shard_path_entries.restype = C.c_uint64

@@ -204,6 +204,8 @@ int ac_shard_fragment_sizes(const ac_shard* s, uint64_t* text_bytes, uint64_t* n
     *n_fragments = s->b->fragment_count();
     return 0;
 }
+uint64_t ac_shard_local_distinct(const ac_shard* s) { return s->b->local_distinct_count(); }
+void ac_shard_set_distinct_upper_bound(ac_shard* s, uint64_t n) { s->b->set_distinct_upper_bound(n); }
 int ac_shard_fragments_export(ac_shard* s, void* d_text_out, void* d_meta_out) {
     return guarded([&] {
         if (s->phase < 1) throw DeviceError("ac_shard_fragments_export: no fragments yet");

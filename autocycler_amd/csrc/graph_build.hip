@@ -1478,6 +1478,7 @@ struct GraphBuilder::Impl {
     DBuf<u8> fs0, fe0;
     // fragments of a sharded build
     DBuf<u8> frag_text; DBuf<u64> frag_meta; u64 frag_bytes = 0, n_frags = 0;
+    u64 distinct_upper = 0;    // sharded builds: sum of the ranks' local distinct counts (0 = unknown)
 
     void begin(BuildTimings* t) {
         tm = t; t_begin = t0 = now_s();
@@ -1510,6 +1511,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
     if (hint == 0) hint = 1;
     u64 est = pt.n_bases / hint;
     u64 c = next_pow2(std::max<u64>(1024, est * 3 + 4096));
+    if (&pt == &uni && distinct_upper) c = next_pow2(std::max<u64>(1024, distinct_upper * 10 / 7 + 4096));   // no retry: an upper bound is known
     if (c > next_pow2(pt.n_bases * 2 + 1024)) c = next_pow2(pt.n_bases * 2 + 1024);
     DBuf<InsertStats> istats(257);       // [256].real doubles as the kernel's error word: one D2H reads everything
     DBuf<u64> sl;
@@ -2051,6 +2053,8 @@ void GraphBuilder::shard_begin(uint32_t local_assembly_hint) {
     m.lap(&tm_.pack);
     AC_DISPATCH_W(fragments, (*impl_))
 }
+uint64_t GraphBuilder::local_distinct_count() const { return tm_.n_local_distinct; }
+void GraphBuilder::set_distinct_upper_bound(uint64_t n) { impl_->distinct_upper = n; }
 uint64_t GraphBuilder::fragment_text_bytes() const { return impl_->frag_bytes; }
 uint64_t GraphBuilder::fragment_count() const { return impl_->n_frags; }
 void GraphBuilder::fragments_export(void* d_text_out, void* d_meta_out) {

@@ -68,6 +68,8 @@ class GraphBuilder {
     //   4. reduce_import + shard_finish: the order-sensitive tail (identical on every rank); paths of this rank's
     //      sequences in final numbers (kept per rank, or gathered with paths_export to the rank that writes the GFA).
     void shard_begin(uint32_t local_assembly_hint);
+    uint64_t local_distinct_count() const;                          // distinct canonical k-mers of this rank's slice
+    void set_distinct_upper_bound(uint64_t n);                      // optional: sum of all ranks' local counts sizes the global table
     uint64_t fragment_text_bytes() const;
     uint64_t fragment_count() const;
     void fragments_export(void* d_text_out, void* d_meta_out);      // device buffers: text bytes, 8 bytes per fragment

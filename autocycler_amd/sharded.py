@@ -139,7 +139,9 @@ def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False):
         nb, nf = C.c_uint64(), C.c_uint64()
         lib.ac_shard_fragment_sizes(h, C.byref(nb), C.byref(nf))
         nb, nf = nb.value, nf.value
-        sizes = comm.all_gather_sizes([nf, nb])
+        gathered = comm.all_gather_sizes([nf, nb, lib.ac_shard_local_distinct(h)])
+        sizes = [(f, b) for f, b, _ in gathered]
+        lib.ac_shard_set_distinct_upper_bound(h, C.c_uint64(sum(d for _, _, d in gathered)))
         mine = torch.empty(8 * nf + nb, dtype=torch.uint8, device=dev)       # [records | text]
         _check(lib, lib.ac_shard_fragments_export(h, C.c_void_p(mine.data_ptr() + 8 * nf), C.c_void_p(mine.data_ptr())))
         parts = comm.all_gather_padded(mine, [8 * f + b for f, b in sizes])

@@ -108,6 +108,9 @@ int ac_shard_begin(uint32_t k, uint32_t local_assembly_count, const void* d_text
                    uint32_t n_seqs, int device, ac_shard** out);
 int ac_shard_fragment_sizes(const ac_shard*, uint64_t* text_bytes, uint64_t* n_fragments);
 int ac_shard_fragments_export(ac_shard*, void* d_text_out /* text_bytes */, void* d_meta_out /* 8 * n_fragments */);
+uint64_t ac_shard_local_distinct(const ac_shard*);                 /* distinct canonical k-mers of this rank's slice */
+void ac_shard_set_distinct_upper_bound(ac_shard*, uint64_t n);     /* optional, before ac_shard_build_union: the sum of all ranks'
+                                                                      local counts sizes the global k-mer table without a retry */
 int ac_shard_build_union(ac_shard*, uint32_t rank, uint32_t n_shards, const void* d_union_text, uint64_t n_union_text,
                          const void* d_meta, uint64_t n_fragments_total);
 uint64_t ac_shard_distinct_count(const ac_shard*);     /* N: distinct canonical k-mers of the whole job */

@@ -94,6 +94,17 @@ const char* ac_version(void) {
 #endif
 }
 void ac_set_stage_timing(int on) { set_stage_timing(on != 0); }
+// The device arena and the pool of pinned result blocks stay allocated between builds; this gives them back (e.g. before a
+// long-lived host process turns to other work).  Graph handles that are still alive keep their blocks.
+int ac_release_memory(void) {
+    return guarded([&] {
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
+        Arena::device().release_all();
+        Arena::pinned_host().release_all();
+        PinnedPool::get().trim();
+    });
+}
 uint32_t ac_max_kmer(void) { int m = max_supported_k(); return (uint32_t)(m % 2 ? m : m - 1); }
 int ac_device_count(void) {
 #ifndef AC_EMU

@@ -193,6 +193,7 @@ int ac_compress_dir(const char* assemblies_dir, const char* autocycler_dir, uint
                     int threads, int device, ac_graph** graph_out, double* times);
 
 void ac_set_stage_timing(int on);   /* off by default */
+int ac_release_memory(void);        /* frees the device arena and the pinned result pool kept between builds */
 const char* ac_last_error(void);
 int ac_device_count(void);       /* number of visible HIP devices (0 if none / no driver) */
 uint32_t ac_max_kmer(void);      /* largest --kmer this build supports */

@@ -68,3 +68,29 @@ def launch(world, lib_path, device, cases, timeout=600):
 def test_multi_rank_gloo(emu, world):
     cases = ",".join(f"{k}:{seed}" for k in (5, 11, 31, 51) for seed in range(24)) + ",synth:51,synth:21"
     launch(world, emu, "cpu", cases)
+
+
+def test_phase_order_is_enforced(emu):
+    """The ac_shard_* calls only work in protocol order, and no other build may start while a sharded one is in flight."""
+    import ctypes as C
+    from autocycler_amd import AutocyclerError, _capi, compress_build
+    lib = _capi.load_library(emu)
+    seqs, fn, hd = seqgen.make_case(1, 11)
+    import oracle_lib as O
+    loaded = O.Seqs.from_raw(11, seqs, filenames=fn, headers=hd).all()
+    shard = sharded_util.local_shard(lib, 11, loaded, 0, len(loaded), 1, torch.device("cpu"))
+    h = C.c_void_p()
+    assert lib.ac_shard_begin(C.c_uint32(11), C.c_uint32(1), C.c_void_p(shard.d_text.data_ptr()), C.c_uint64(shard.n_text), shard.off, shard.lens,
+                              shard.ids, shard.d1, shard.d2, C.c_uint32(shard.n_seqs), C.c_int(0), C.byref(h)) == 0
+    try:
+        g = C.c_void_p()
+        assert lib.ac_shard_build_graph(h, None) != 0 and b"wrong phase" in lib.ac_last_error()
+        assert lib.ac_shard_finish(h, C.c_int(3), C.byref(g)) != 0 and b"wrong phase" in lib.ac_last_error()
+        assert lib.ac_shard_reduce_import(h, None, None) != 0
+        with pytest.raises(AutocyclerError, match="sharded build is in flight"):
+            compress_build(11, 1, [(q["fwd"], q["length"], q["id"]) for q in loaded], lib_path=emu)
+        assert lib.ac_release_memory() != 0
+    finally:
+        lib.ac_shard_free(h)
+    assert lib.ac_release_memory() == 0
+    compress_build(11, 1, [(q["fwd"], q["length"], q["id"]) for q in loaded], lib_path=emu).close()      # and builds work again

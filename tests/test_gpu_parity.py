@@ -118,3 +118,26 @@ def test_pairwise_distances(k):   # cluster.rs:132-157 on the
         parity_util.check_case(k, seqs, fn, hd, distances=True)
     seqs, fn, hd = _synth_case(8, 200_000, 8_000, 1e-3, 1e-4, 4242)
     parity_util.check_case(k, seqs, fn, hd, distances=True)
+
+
+def test_random_synthetic_sets():
+    # randomised assembly sets (2-14 assemblies, 8-50 kbp, substitution rates up to 2 %, indels, several k) through the build,
+    # the sharded path at world size 1 and the pairwise distances
+    import random
+    import torch
+    import autocycler_amd
+    import sharded_util
+    from autocycler_amd import sharded, synth
+    dev = torch.device("cuda", 0)
+    for seed in range(24):
+        r = random.Random(seed)
+        k = r.choice([21, 31, 51, 51, 51, 77, 101, 151])
+        na = r.randint(2, 14); genome = r.choice([8000, 20000, 50000]); plasmid = r.choice([0, 1500, 4000])
+        sub = r.choice([0, 1e-4, 1e-3, 5e-3, 2e-2]); indel = r.choice([0, 1e-4, 2e-3])
+        seqs, fn, hd = [], [], []
+        for i, contigs in enumerate(synth.make_assemblies(na, genome=genome, plasmid=plasmid, sub=sub, indel=indel, seed=1000 + seed)):
+            for header, s in contigs:
+                seqs.append(s.tobytes().decode()); fn.append(f"assembly_{i:04d}.fasta"); hd.append(header)
+        parity_util.check_case(k, seqs, fn, hd, distances=(seed % 2 == 0))
+        if seed % 3 == 0:
+            sharded_util.run_case(autocycler_amd.LIB_PATH, k, seqs, fn, hd, sharded.Comm(dev), dev)

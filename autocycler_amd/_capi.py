@@ -52,7 +52,7 @@ class Timings(C.Structure):
 EXPORTS = ["ac_compress_build", "ac_compress_build_device", "ac_text_size", "ac_layout_text", "ac_kmer_count",
            "ac_stats_pre", "ac_stats_post", "ac_unitig_count", "ac_unitig", "ac_unitig_positions", "ac_links",
            "ac_path", "ac_timings_get", "ac_free", "ac_gfa_string", "ac_string_free", "ac_last_error",
-           "ac_device_count", "ac_max_kmer", "ac_version", "ac_set_stage_timing", "ac_release_memory", "ac_end_repair_device", "ac_pairwise_distances",
+           "ac_device_count", "ac_max_kmer", "ac_version", "ac_set_stage_timing", "ac_release_memory", "ac_end_repair_device", "ac_pairwise_distances", "ac_graph_from_gfa", "ac_graph_kmer_size", "ac_graph_seq_info", "ac_decompress_seq",
            "ac_shard_begin", "ac_shard_fragment_sizes", "ac_shard_fragments_export", "ac_shard_build_union",
            "ac_shard_unitig_count", "ac_shard_local_distinct", "ac_shard_set_distinct_upper_bound", "ac_shard_distinct_count", "ac_shard_degrees_export", "ac_shard_build_graph", "ac_gfa_string_parts", "ac_shard_reduce_export", "ac_shard_reduce_import", "ac_shard_finish",
            "ac_shard_path_entries", "ac_shard_paths_export", "ac_shard_free", "ac_graph_set_paths", "ac_graph_seq_count", "ac_path_counts",
@@ -181,6 +181,13 @@ class Graph:
         _check(self._lib, self._lib.ac_path_counts(self._h, out))
         return list(out)
 
+    def decompress(self, seq_index):
+        idv, ln = C.c_uint16(), C.c_uint32()
+        _check(self._lib, self._lib.ac_graph_seq_info(self._h, C.c_uint32(seq_index), C.byref(idv), C.byref(ln), None, None))
+        buf = C.create_string_buffer(ln.value)
+        _check(self._lib, self._lib.ac_decompress_seq(self._h, C.c_uint32(seq_index), buf))
+        return buf.raw
+
     def pairwise_distances(self, device=0):
         """cluster.rs:132-157 -> S x S list of lists (row a, column b)."""
         S = self._lib.ac_graph_seq_count(self._h)
@@ -203,6 +210,22 @@ class Graph:
         s = C.string_at(out.value, ln.value).decode()
         self._lib.ac_string_free(out)
         return s
+
+
+def graph_from_gfa(gfa_text, lib_path=None):
+    """UnitigGraph::from_gfa_lines for a compress-written GFA -> (Graph, filenames, headers)."""
+    lib = load_library(lib_path)
+    b = gfa_text.encode() if isinstance(gfa_text, str) else gfa_text
+    h = C.c_void_p()
+    _check(lib, lib.ac_graph_from_gfa(b, C.c_uint64(len(b)), C.byref(h)))
+    n = lib.ac_graph_seq_count(h)
+    g = Graph(lib, h, n)
+    fns, hds = [], []
+    for i in range(n):
+        fn, hd = C.c_char_p(), C.c_char_p()
+        _check(lib, lib.ac_graph_seq_info(h, C.c_uint32(i), None, None, C.byref(fn), C.byref(hd)))
+        fns.append(fn.value.decode()); hds.append(hd.value.decode())
+    return g, fns, hds
 
 
 def compress_build(k, assembly_count, seqs, device=0, lib_path=None):

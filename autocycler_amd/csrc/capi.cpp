@@ -32,6 +32,7 @@ struct ac_graph {
     bool positions_built = false;
     bool host_arrays = true;   // false: a rank of a sharded build that did not ask for the unitigs / links
     bool host_paths = true;    // false: ... that did not ask for its paths either
+    std::vector<std::string> filenames, headers;   // graphs loaded from a GFA carry them (FN:Z / HD:Z)
 };
 
 struct ac_seqs {
@@ -368,6 +369,35 @@ int ac_pairwise_distances(const ac_graph* g, int device, double* out) {
         if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
         select_device(device);
         pairwise_distances_device(g->g, (uint32_t)g->seq_ids.size(), out);
+    });
+}
+
+// UnitigGraph::from_gfa_lines (unitig_graph.rs:55-174) for the GFAs `compress` writes: what `cluster` and `decompress` start from.
+int ac_graph_from_gfa(const char* gfa_text, uint64_t len, ac_graph** out) {
+    return guarded([&] {
+        if (!gfa_text) throw DeviceError("no GFA text");
+        auto h = std::make_unique<ac_graph>();
+        std::vector<SeqMeta> meta;
+        load_gfa(gfa_text, (size_t)len, &h->g, &meta);
+        for (auto& m : meta) { h->seq_ids.push_back(m.id); h->seq_lens.push_back(m.length); h->filenames.push_back(m.filename); h->headers.push_back(m.contig_header); }
+        *out = h.release();
+    });
+}
+uint32_t ac_graph_kmer_size(const ac_graph* g) { return g->g.k; }
+int ac_graph_seq_info(const ac_graph* g, uint32_t i, uint16_t* id, uint32_t* length, const char** filename, const char** header) {
+    if (i >= g->seq_ids.size()) { g_err = "sequence index out of range"; return 1; }
+    if (id) *id = g->seq_ids[i];
+    if (length) *length = g->seq_lens[i];
+    if (filename) *filename = i < g->filenames.size() ? g->filenames[i].c_str() : nullptr;
+    if (header) *header = i < g->headers.size() ? g->headers[i].c_str() : nullptr;
+    return 0;
+}
+// reconstruct_original_sequences (unitig_graph.rs:362-388) for one sequence; out holds its LN bytes.
+int ac_decompress_seq(const ac_graph* g, uint32_t seq_index, uint8_t* out) {
+    return guarded([&] {
+        if (seq_index >= g->seq_ids.size()) throw DeviceError("sequence index out of range");
+        if (!g->host_arrays || !g->host_paths) throw DeviceError("this rank kept no host arrays (sharded build, not the writing rank)");
+        decompress_sequence(g->g, seq_index, (char*)out);
     });
 }
 

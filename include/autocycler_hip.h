@@ -141,6 +141,15 @@ int ac_end_repair_device(uint32_t k, void* d_text, uint64_t n_text, const uint64
  * S = ac_graph_seq_count(), sequences in input order. */
 int ac_pairwise_distances(const ac_graph*, int device, double* out);
 
+/* The loader side of save_gfa for the GFAs `compress` writes (UnitigGraph::from_gfa_lines, unitig_graph.rs:55-174): what
+ * `autocycler cluster` (cluster.rs:42-43) and `autocycler decompress` (decompress.rs:27-39) start from.  The handle then serves
+ * every accessor above (ac_gfa_string on it reproduces the file: tests.rs:108-112), ac_pairwise_distances and: */
+int ac_graph_from_gfa(const char* gfa_text, uint64_t len, ac_graph** out);
+uint32_t ac_graph_kmer_size(const ac_graph*);
+int ac_graph_seq_info(const ac_graph*, uint32_t seq_index, uint16_t* id, uint32_t* length, const char** filename, const char** header);
+/* reconstruct_original_sequences (unitig_graph.rs:362-388) for one sequence: out receives its `length` bytes. */
+int ac_decompress_seq(const ac_graph*, uint32_t seq_index, uint8_t* out);
+
 /* Host helper: lay sequences out as the text described above.  text must hold ac_text_size() bytes. */
 uint64_t ac_text_size(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs);
 int ac_layout_text(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs, uint8_t* text, uint64_t* seq_off,

@@ -126,3 +126,35 @@ def test_compress_dir_user_errors(emu, tmp_path):
     assert "contains non-ACGT characters" in run(src, tmp_path / "o", k=11)[1]
     (src / "b.fasta").write_text("")
     assert "is an empty file" in run(src, tmp_path / "o", k=11)[1]
+
+
+@pytest.mark.parametrize("k", [5, 11, 51])
+def test_gfa_load_save_identity_and_decompress(k):
+    """The reference's round-trip properties (tests.rs:108-127) through the library's own loader: save -> load -> save is the
+    identity, every path spells its input sequence, and the loaded graph gives the oracle's pairwise distances."""
+    from autocycler_amd import graph_from_gfa
+    path = emu_lib.emu_path()
+    for seed in range(24):
+        seqs, fn, hd = seqgen.make_case(seed, k)
+        s = O.Seqs.from_raw(k, seqs, filenames=fn, headers=hd)
+        gfa, _, _ = s.compress(k)
+        g, fns, hds = graph_from_gfa(gfa, lib_path=path)
+        assert g.gfa(fns, hds) == gfa
+        assert [g.decompress(i).decode() for i in range(len(seqs))] == seqs
+        assert g.pairwise_distances() == O.pairwise_distances(gfa)
+        g.close()
+
+
+def test_gfa_loader_errors():
+    from autocycler_amd import AutocyclerError, graph_from_gfa
+    path = emu_lib.emu_path()
+    with pytest.raises(AutocyclerError, match="depth tag"):
+        graph_from_gfa("H\tVN:Z:1.0\tKM:i:9\nS\t1\tACGT\n", lib_path=path)
+    with pytest.raises(AutocyclerError, match="non-zero overlap"):
+        graph_from_gfa("H\tVN:Z:1.0\tKM:i:9\nS\t1\tACGT\tDP:f:1.00\nL\t1\t+\t1\t+\t5M\n", lib_path=path)
+    with pytest.raises(AutocyclerError, match="nonexistent unitig"):
+        graph_from_gfa("H\tVN:Z:1.0\tKM:i:9\nS\t1\tACGT\tDP:f:1.00\nL\t1\t+\t2\t+\t0M\n", lib_path=path)
+    with pytest.raises(AutocyclerError, match="missing required tag"):
+        graph_from_gfa("H\tVN:Z:1.0\tKM:i:9\nS\t1\tACGT\tDP:f:1.00\nP\t1\t1+\t*\tLN:i:4\n", lib_path=path)
+    with pytest.raises(AutocyclerError, match="mismatch"):
+        graph_from_gfa("H\tVN:Z:1.0\tKM:i:9\nS\t1\tACGT\tDP:f:1.00\nP\t1\t1+\t*\tLN:i:5\tFN:Z:a.fasta\tHD:Z:c\n", lib_path=path)

@@ -401,6 +401,15 @@ int ac_decompress_seq(const ac_graph* g, uint32_t seq_index, uint8_t* out) {
     });
 }
 
+int ac_random_access_ceilings(int device, double* cas_gops, double* read_gops) {
+    return guarded([&] {
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
+        select_device(device);
+        random_access_ceilings(cas_gops, read_gops);
+    });
+}
+
 uint64_t ac_kmer_count(const ac_graph* g) { return g->g.n_kmers; }
 ac_stats ac_stats_pre(const ac_graph* g) { return ac_stats{g->g.pre.unitigs, g->g.pre.links_one_way, g->g.pre.total_length}; }
 ac_stats ac_stats_post(const ac_graph* g) { return ac_stats{g->g.post.unitigs, g->g.post.links_one_way, g->g.post.total_length}; }

@@ -108,6 +108,9 @@ void end_repair_device(uint32_t k, uint8_t* d_text, uint64_t n_text, const std::
 // pairwise_contig_distances (cluster.rs:132-157) on the final graph: out[a * n_seqs + b], sequences in path order.
 void pairwise_distances_device(const FinalGraph& g, uint32_t n_seqs, double* out);
 
+// Measured ceilings of the device for random atomicCAS / random 8-byte reads on a 134 MB table, in 10^9 operations per second.
+void random_access_ceilings(double* cas_gops, double* read_gops);
+
 // Brings the HIP context and this library's code objects up on `device` (first use costs ~0.2 s): callable from a helper
 // thread while the caller is still busy on the host.
 void device_warmup(int device);

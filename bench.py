@@ -324,6 +324,22 @@ def main():
                       "simplify_passes": tms[-1]["simplify_passes"]},
             "prep_s": {"generate": t_gen, "end_repair": t_repair, "end_repair_info": repair_info, "h2d": t_h2d, "h2d_GBps": n_text / t_h2d / 1e9},
         }
+        # The kernels of this path are bound by random accesses into the k-mer table, not by streamed bytes: price them against
+        # the device's measured random-access ceilings as well (a ~20 ms microbenchmark inside the library).
+        cas, rd = C.c_double(), C.c_double()
+        if lib.ac_random_access_ceilings(C.c_int(local_rank), C.byref(cas), C.byref(rd)) == 0 and cas.value > 0:
+            st = tms[-1]
+            deg_ms = stage["degree"] * 1e3
+            line["random_access"] = {
+                "cas_ceiling_Gops": cas.value, "read_ceiling_Gops": rd.value,
+                "insert": {"slot_claims": st["n_local_distinct"] or st["n_distinct"], "kernel_ms": ins_ms,
+                           "claims_only_bound_ms": (st["n_local_distinct"] or st["n_distinct"]) / cas.value / 1e6,
+                           "frac_of_cas_ceiling": (st["n_local_distinct"] or st["n_distinct"]) / cas.value / 1e6 / ins_ms},
+                "degree": {"lookups": 6 * st["n_distinct"], "stage_ms": deg_ms,
+                           "lookups_only_bound_ms": 6 * st["n_distinct"] / rd.value / 1e6,
+                           "frac_of_read_ceiling": 6 * st["n_distinct"] / rd.value / 1e6 / deg_ms},
+                "note": "bounds count only the unavoidable random accesses (one CAS per distinct k-mer; six lookups of absent neighbours "
+                        "per distinct k-mer); the kernels also read the packed text and dereference it on every tag match"}
         if independent is not None:
             line["independent_jobs"] = independent
         if mode == "sharded":

@@ -10,6 +10,44 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 
 
+def big_case(lib_path, n_asm, genome, dev, rank, world):
+    import ctypes as C
+    import numpy as np
+    import torch.distributed as dist
+    import sharded_util
+    from autocycler_amd import _capi, compress_build, sharded, synth
+    k = 51
+    lib = _capi.load_library(lib_path)
+    lib.ac_seqs_views.restype = C.POINTER(_capi.SeqView)
+    lib.ac_seqs_count.restype = C.c_uint32
+    lib.ac_seqs_free.argtypes = [C.c_void_p]
+    seqs, fn, hd = [], [], []
+    for i, contigs in enumerate(synth.make_assemblies(n_asm, genome=genome, plasmid=genome // 50, sub=2e-4, indel=2e-5, seed=31337)):
+        for header, s in contigs:
+            seqs.append(np.ascontiguousarray(s)); fn.append(f"assembly_{i:04d}.fasta"); hd.append(header)
+    n = len(seqs)
+    out = C.c_void_p()
+    rc = lib.ac_seqs_from_raw(C.c_uint32(k), C.c_uint32(n), (C.c_void_p * n)(*[s.ctypes.data for s in seqs]), (C.c_uint32 * n)(*[len(s) for s in seqs]),
+                              (C.c_char_p * n)(*[x.encode() for x in fn]), (C.c_char_p * n)(*[x.encode() for x in hd]), C.c_uint32(n_asm), C.c_int(1),
+                              C.c_int(8), C.byref(out))
+    assert rc == 0, lib.ac_last_error()
+    views = lib.ac_seqs_views(out)
+    loaded = [dict(fwd=C.string_at(views[i].fwd, views[i].length + k - 1), length=views[i].length, id=views[i].id) for i in range(n)]
+    lib.ac_seqs_free(out)
+    b = sharded_util.slice_bounds(n, world)
+    shard = sharded_util.local_shard(lib, k, loaded, b[rank], b[rank + 1], max(1, n_asm // world), dev)
+    g, info = sharded.sharded_build(lib, shard, sharded.Comm(dev), device_index=dev.index or 0, root=0, gather_paths=True)
+    if rank == 0:
+        gfa_sharded = g.gfa(fn, hd)
+        single = compress_build(k, n_asm, [(q["fwd"], q["length"], q["id"]) for q in loaded], device=dev.index or 0, lib_path=lib_path)
+        gfa_single = single.gfa(fn, hd)
+        assert g.stats_post == single.stats_post and g.kmer_count == single.kmer_count
+        assert gfa_sharded == gfa_single, "sharded and single-device GFA differ"
+        assert info["fragments"] > 2 * n and g.stats_post["unitigs"] > 10
+        print(f"big case: {n} sequences, {g.stats_post['unitigs']} unitigs, {info['fragments']} fragments, union text {info['union_text_bytes']} bytes")
+    dist.barrier()
+
+
 def main():
     rank, world, port, lib_path, device, cases = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
@@ -24,6 +62,13 @@ def main():
         torch.cuda.set_device(dev)
     done = 0
     for case in cases.split(","):
+        if case.startswith("big:"):
+            # a realistic-size job (too big for the oracle): the sharded result must equal the single-device build of the same
+            # sequences, which the full-size property tests pin (tests/test_gpu_fullsize.py)
+            _, n_asm, genome = case.split(":")
+            big_case(lib_path, int(n_asm), int(genome), dev, rank, world)
+            done += 1
+            continue
         a, b = case.split(":")
         if a == "synth":
             from autocycler_amd import synth

@@ -94,3 +94,9 @@ def test_phase_order_is_enforced(emu):
         lib.ac_shard_free(h)
     assert lib.ac_release_memory() == 0
     compress_build(11, 1, [(q["fwd"], q["length"], q["id"]) for q in loaded], lib_path=emu).close()      # and builds work again
+
+
+def test_three_ranks_medium_size_vs_single(emu):
+    # the same comparison on the CPU emulation at a size it can do: 9 assemblies of 40 kbp over three ranks
+    outs = launch(3, emu, "cpu", "big:9:40000")
+    assert "big case" in outs[0]

@@ -47,3 +47,9 @@ def test_single_rank_synthetic_medium(lib_path):
 def test_two_ranks_one_gpu(lib_path):
     cases = ",".join(f"{k}:{seed}" for k in (11, 51) for seed in range(12)) + ",synth:51"
     launch(2, lib_path, "cuda:0", cases, timeout=900)
+
+
+def test_two_ranks_realistic_size(lib_path):
+    # 12 assemblies of a 2 Mbp genome split over two ranks == the single-device build of the same 12
+    outs = launch(2, lib_path, "cuda:0", "big:12:2000000", timeout=900)
+    assert "big case" in outs[0]

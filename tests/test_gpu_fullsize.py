@@ -20,7 +20,8 @@ for a, b in zip(b"ACGT", b"TGCA"):
     COMP[a] = b
 
 
-def build(n_assemblies, k=51):
+def build(n_assemblies, k=51, genome=5_000_000, pieces=1, device_repair=False):
+    """pieces > 1: every replicon is cut into that many contigs (fragmented assemblies: thousands of sequences)."""
     import torch
     import bench
     from autocycler_amd import _capi, synth
@@ -29,10 +30,12 @@ def build(n_assemblies, k=51):
     lib.ac_seqs_count.restype = C.c_uint32
     lib.ac_seqs_free.argtypes = [C.c_void_p]
     seqs, fn, hd = [], [], []
-    for i, contigs in enumerate(synth.make_assemblies(n_assemblies, seed=51_000)):
+    for i, contigs in enumerate(synth.make_assemblies(n_assemblies, genome=genome, plasmid=genome // 50, seed=51_000)):
         for header, s in contigs:
-            seqs.append(np.ascontiguousarray(s)); fn.append(f"assembly_{i:04d}.fasta"); hd.append(header)
-    h = bench.prepare(lib, k, seqs, fn, hd, n_assemblies, threads=32)
+            cuts = np.linspace(0, len(s), pieces + 1).astype(int) if len(s) >= 200 * pieces else np.array([0, len(s)])
+            for j in range(len(cuts) - 1):
+                seqs.append(np.ascontiguousarray(s[cuts[j]:cuts[j + 1]])); fn.append(f"assembly_{i:04d}.fasta"); hd.append(f"{header} part={j}")
+    h = bench.prepare(lib, k, seqs, fn, hd, n_assemblies, threads=32, repair=0 if device_repair else 1)
     n = lib.ac_seqs_count(h)
     views = lib.ac_seqs_views(h)
     n_text = lib.ac_text_size(C.c_uint32(k), views, C.c_uint32(n))
@@ -42,6 +45,9 @@ def build(n_assemblies, k=51):
     lens = (C.c_uint32 * n)(*[views[i].length for i in range(n)])
     ids = (C.c_uint16 * n)(*[views[i].id for i in range(n)])
     d_text = torch.from_numpy(text).to("cuda:0")
+    if device_repair:
+        assert lib.ac_end_repair_device(C.c_uint32(k), C.c_void_p(d_text.data_ptr()), C.c_uint64(n_text), off, lens, d1, d2, C.c_uint32(n),
+                                        C.c_int(0), None, None) == 0, lib.ac_last_error()
     g = C.c_void_p()
     rc = lib.ac_compress_build_device(C.c_uint32(k), C.c_uint32(n_assemblies), C.c_void_p(d_text.data_ptr()), C.c_uint64(n_text),
                                       off, lens, ids, d1, d2, C.c_uint32(n), C.c_int(0), C.byref(g))
@@ -129,3 +135,12 @@ def test_config_c_96_assemblies():
             ab = float(ulen[np.intersect1d(sets[a], sets[b], assume_unique=True)].sum())
             assert d[a][b] == 1.0 - ab / a_len, (a, b)
         assert d[a][a] == 0.0
+
+
+def test_fragmented_assemblies_many_sequences():
+    # 30 assemblies of a 1 Mbp genome cut into 400 contigs each (+ plasmid pieces): > 12 000 sequences, every one with two end
+    # repair patterns on the device, through the build and the size-independent properties
+    g, seqs, fn, hd = build(30, genome=1_000_000, pieces=400, device_repair=True)
+    assert len(seqs) > 12_000
+    U = check_properties(g, seqs, 51)
+    assert U > 1000

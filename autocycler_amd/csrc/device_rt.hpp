@@ -250,8 +250,34 @@ inline void copy_d2h_async(void* h, const void* d, size_t bytes, stream_t s = 0)
     AC_HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s));
 #endif
 }
+// Small read-backs (counts, flags, level tables: the ~20 host decisions of a build) land in a pinned scratch page first: a
+// copy into pageable memory takes the runtime's slow staging path and costs tens of microseconds of idle GPU each time.
+inline void* pinned_scratch(size_t bytes) {
+#ifdef AC_EMU
+    (void)bytes; return nullptr;
+#else
+    static void* p = nullptr;
+    static size_t cap = 0;
+    if (bytes > cap) {
+        if (p) (void)hipHostFree(p);
+        cap = std::max<size_t>(bytes, 64 << 10);
+        AC_HIP_CHECK(hipHostMalloc(&p, cap, hipHostMallocDefault));
+    }
+    return p;
+#endif
+}
 inline void copy_d2h(void* h, const void* d, size_t bytes, stream_t s = 0) {
     if (!bytes) return;
+#ifndef AC_EMU
+    static const bool use_scratch = getenv("AC_NO_PINNED_SCRATCH") == nullptr;
+    if (use_scratch && bytes <= (64 << 10)) {
+        void* p = pinned_scratch(bytes);
+        AC_HIP_CHECK(hipMemcpyAsync(p, d, bytes, hipMemcpyDeviceToHost, s));
+        AC_HIP_CHECK(hipStreamSynchronize(s));
+        memcpy(h, p, bytes);
+        return;
+    }
+#endif
     copy_d2h_async(h, d, bytes, s);
 #ifndef AC_EMU
     AC_HIP_CHECK(hipStreamSynchronize(s));

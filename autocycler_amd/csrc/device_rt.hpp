@@ -283,6 +283,32 @@ inline void copy_d2h(void* h, const void* d, size_t bytes, stream_t s = 0) {
     AC_HIP_CHECK(hipStreamSynchronize(s));
 #endif
 }
+// Several small device arrays -> host with ONE synchronisation (through the pinned scratch page).
+class ReadBatch {
+  public:
+    void add(void* h, const void* d, size_t bytes) { if (bytes) items_.push_back(Item{h, d, bytes}); }
+    void run(stream_t s = 0) {
+#ifdef AC_EMU
+        for (auto& it : items_) memcpy(it.h, it.d, it.bytes);
+        (void)s;
+#else
+        size_t total = 0;
+        for (auto& it : items_) total += (it.bytes + 63) & ~(size_t)63;
+        if (total == 0) return;
+        char* p = (char*)pinned_scratch(total);
+        size_t o = 0;
+        for (auto& it : items_) { AC_HIP_CHECK(hipMemcpyAsync(p + o, it.d, it.bytes, hipMemcpyDeviceToHost, s)); o += (it.bytes + 63) & ~(size_t)63; }
+        AC_HIP_CHECK(hipStreamSynchronize(s));
+        o = 0;
+        for (auto& it : items_) { memcpy(it.h, p + o, it.bytes); o += (it.bytes + 63) & ~(size_t)63; }
+#endif
+        items_.clear();
+    }
+  private:
+    struct Item { void* h; const void* d; size_t bytes; };
+    std::vector<Item> items_;
+};
+
 // Device -> pinned host arena (valid until the next build resets the arena); no sync.
 template <class T> T* to_pinned_async(const T* d, size_t n, stream_t s = 0) {
     T* h = (T*)Arena::pinned_host().alloc((n ? n : 1) * sizeof(T));

@@ -753,9 +753,16 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     }
     lap(&tm->finalize);
 
-    std::vector<u64> h_sums = to_host(sums, n_seqs);
-    out->path_off = to_host(path_off, (size_t)n_seqs + 1);
-    std::vector<u32> errs = to_host(counters, 8);   // synchronises stream 0
+    std::vector<u64> h_sums(n_seqs);
+    out->path_off.resize((size_t)n_seqs + 1);
+    std::vector<u32> errs(8);
+    {
+        ReadBatch rb;
+        rb.add(h_sums.data(), sums.ptr(), (size_t)n_seqs * 8);
+        rb.add(out->path_off.data(), path_off.ptr(), ((size_t)n_seqs + 1) * 8);
+        rb.add(errs.data(), counters.ptr(), 8 * 4);
+        rb.run();                                   // synchronises stream 0 (once)
+    }
     side.sync();                                    // ... and the copies: everything above has landed
     if (errs[7]) throw DeviceError("internal error: expand_repeats pool overflow");
     if (errs[3] || errs[4])

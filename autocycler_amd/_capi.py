@@ -52,7 +52,7 @@ class Timings(C.Structure):
 EXPORTS = ["ac_compress_build", "ac_compress_build_device", "ac_text_size", "ac_layout_text", "ac_kmer_count",
            "ac_stats_pre", "ac_stats_post", "ac_unitig_count", "ac_unitig", "ac_unitig_positions", "ac_links",
            "ac_path", "ac_timings_get", "ac_free", "ac_gfa_string", "ac_string_free", "ac_last_error",
-           "ac_device_count", "ac_max_kmer", "ac_version", "ac_set_stage_timing", "ac_random_access_ceilings", "ac_release_memory", "ac_end_repair_device", "ac_pairwise_distances", "ac_graph_from_gfa", "ac_graph_kmer_size", "ac_graph_seq_info", "ac_decompress_seq",
+           "ac_device_count", "ac_max_kmer", "ac_version", "ac_set_stage_timing", "ac_random_access_ceilings", "ac_release_memory", "ac_end_repair_device", "ac_pairwise_distances", "ac_graph_from_gfa", "ac_graph_kmer_size", "ac_graph_seq_info", "ac_decompress_seq", "ac_decompress",
            "ac_shard_begin", "ac_shard_fragment_sizes", "ac_shard_fragments_export", "ac_shard_build_union",
            "ac_shard_unitig_count", "ac_shard_local_distinct", "ac_shard_set_distinct_upper_bound", "ac_shard_distinct_count", "ac_shard_degrees_export", "ac_shard_build_graph", "ac_gfa_string_parts", "ac_shard_reduce_export", "ac_shard_reduce_import", "ac_shard_finish",
            "ac_shard_path_entries", "ac_shard_paths_export", "ac_shard_free", "ac_graph_set_paths", "ac_graph_seq_count", "ac_path_counts",

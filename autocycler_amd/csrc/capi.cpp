@@ -4,6 +4,10 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <zlib.h>
+#include <algorithm>
+#include <atomic>
+#include <map>
 #include <thread>
 #include <string>
 #include <vector>
@@ -407,6 +411,69 @@ int ac_random_access_ceilings(int device, double* cas_gops, double* read_gops) {
         if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
         select_device(device);
         random_access_ceilings(cas_gops, read_gops);
+    });
+}
+
+// The whole `autocycler decompress` command (decompress.rs:27-39): GFA file -> the assemblies it was built from, one file per
+// original filename in out_dir (gzip when the name ends in .gz, decompress.rs:83-105) and / or all contigs in one FASTA file
+// (headers ">{filename}__{header}", :117-137).  Either of out_dir / out_file may be NULL, not both.
+int ac_decompress(const char* in_gfa, const char* out_dir, const char* out_file, int threads) {
+    return guarded([&] {
+        namespace fs = std::filesystem;
+        if (!in_gfa || !fs::is_regular_file(in_gfa)) throw UserError(std::string("file does not exist: ") + (in_gfa ? in_gfa : ""));
+        if (!out_dir && !out_file) throw UserError("either --out_dir or --out_file is required");
+        if (out_dir && fs::exists(out_dir) && !fs::is_directory(out_dir)) throw UserError(std::string(out_dir) + " exists but is not a directory");
+        std::string text;
+        {
+            std::ifstream f(in_gfa, std::ios::binary);
+            text.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+        }
+        ac_graph h;
+        std::vector<SeqMeta> meta;
+        load_gfa(text.data(), text.size(), &h.g, &meta);
+        const size_t S = meta.size();
+        std::vector<std::string> seqs(S);
+        {   // reconstruct_original_sequences (unitig_graph.rs:362-388), one sequence per task
+            std::atomic<size_t> next{0};
+            auto worker = [&] { for (size_t i; (i = next.fetch_add(1)) < S;) { seqs[i].resize(meta[i].length); decompress_sequence(h.g, i, seqs[i].data()); } };
+            int T = std::max(1, std::min<int>(threads, (int)S));
+            std::vector<std::thread> pool;
+            for (int t = 1; t < T; t++) pool.emplace_back(worker);
+            worker();
+            for (auto& t : pool) t.join();
+        }
+        std::map<std::string, std::vector<size_t>> by_file;      // filenames sorted; contigs in GFA order within a file
+        for (size_t i = 0; i < S; i++) by_file[meta[i].filename].push_back(i);
+        if (out_dir) {
+            std::error_code ec;
+            fs::create_directories(out_dir, ec);
+            if (ec) throw UserError(std::string("failed to create directory ") + out_dir + "\n" + ec.message());
+            for (auto& [fname, idx] : by_file) {
+                fs::path path = fs::path(out_dir) / fname;
+                std::string body;
+                for (size_t i : idx) { body += ">" + meta[i].contig_header + "\n"; body += seqs[i]; body += "\n"; }
+                if (path.extension() == ".gz") {
+                    gzFile gz = gzopen(path.c_str(), "wb");
+                    if (!gz) throw UserError("failed to create " + path.string());
+                    size_t o = 0;
+                    while (o < body.size()) { int n = gzwrite(gz, body.data() + o, (unsigned)std::min<size_t>(body.size() - o, 1u << 30)); if (n <= 0) { gzclose(gz); throw UserError("failed to write " + path.string()); } o += (size_t)n; }
+                    gzclose(gz);
+                } else {
+                    std::ofstream f(path, std::ios::binary);
+                    f.write(body.data(), (std::streamsize)body.size());
+                    if (!f) throw UserError("failed to write " + path.string());
+                }
+            }
+        }
+        if (out_file) {
+            std::ofstream f(out_file, std::ios::binary);
+            for (auto& [fname, idx] : by_file) {
+                std::string clean = fname;
+                std::replace(clean.begin(), clean.end(), ' ', '_');
+                for (size_t i : idx) { f << ">" << clean << "__" << meta[i].contig_header << "\n"; f.write(seqs[i].data(), (std::streamsize)seqs[i].size()); f << "\n"; }
+            }
+            if (!f) throw UserError(std::string("failed to write ") + out_file);
+        }
     });
 }
 

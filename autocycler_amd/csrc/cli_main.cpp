@@ -14,7 +14,32 @@ static void usage() {
     fprintf(stderr, "Usage: autocycler-compress --assemblies_dir <DIR> --autocycler_dir <DIR> [--kmer 51] [--max_contigs 25] [--threads 8] [--device 0]\n");
 }
 
+// `autocycler decompress` (main.rs:163-175): -i/--in_gfa FILE  [-o/--out_dir DIR]  [-f/--out_file FASTA]
+static int decompress_main(int argc, char** argv) {
+    std::string in, dir, file;
+    for (int i = 2; i < argc; i++) {
+        std::string a = argv[i];
+        auto val = [&]() -> const char* {
+            if (i + 1 >= argc) { fprintf(stderr, "error: a value is required for '%s'\n", a.c_str()); exit(2); }
+            return argv[++i];
+        };
+        if (a == "-i" || a == "--in_gfa") in = val();
+        else if (a == "-o" || a == "--out_dir") dir = val();
+        else if (a == "-f" || a == "--out_file") file = val();
+        else { fprintf(stderr, "error: unexpected argument '%s'\nUsage: autocycler-compress decompress --in_gfa <GFA> [--out_dir <DIR>] [--out_file <FASTA>]\n", a.c_str()); return 2; }
+    }
+    fprintf(stderr, "\nStarting autocycler decompress\nSettings:\n  --in_gfa %s\n", in.c_str());
+    if (!dir.empty()) fprintf(stderr, "  --out_dir %s\n", dir.c_str());
+    if (!file.empty()) fprintf(stderr, "  --out_file %s\n", file.c_str());
+    if (ac_decompress(in.c_str(), dir.empty() ? nullptr : dir.c_str(), file.empty() ? nullptr : file.c_str(), 8) != 0) {
+        fprintf(stderr, "\nError: %s\n", ac_last_error());
+        return 1;
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && strcmp(argv[1], "decompress") == 0) return decompress_main(argc, argv);
     std::string in, out;
     unsigned k = 51, max_contigs = 25;
     int threads = 8, device = 0;

@@ -150,6 +150,10 @@ int ac_graph_seq_info(const ac_graph*, uint32_t seq_index, uint16_t* id, uint32_
 /* reconstruct_original_sequences (unitig_graph.rs:362-388) for one sequence: out receives its `length` bytes. */
 int ac_decompress_seq(const ac_graph*, uint32_t seq_index, uint8_t* out);
 
+/* The whole `autocycler decompress` command (decompress.rs:27-39): in_gfa -> one FASTA per original file name in out_dir
+ * (gzip when the name ends in .gz) and / or every contig in out_file (">{filename}__{header}").  Host code. */
+int ac_decompress(const char* in_gfa, const char* out_dir, const char* out_file, int threads);
+
 /* Host helper: lay sequences out as the text described above.  text must hold ac_text_size() bytes. */
 uint64_t ac_text_size(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs);
 int ac_layout_text(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs, uint8_t* text, uint64_t* seq_off,

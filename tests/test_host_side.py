@@ -158,3 +158,29 @@ def test_gfa_loader_errors():
         graph_from_gfa("H\tVN:Z:1.0\tKM:i:9\nS\t1\tACGT\tDP:f:1.00\nP\t1\t1+\t*\tLN:i:4\n", lib_path=path)
     with pytest.raises(AutocyclerError, match="mismatch"):
         graph_from_gfa("H\tVN:Z:1.0\tKM:i:9\nS\t1\tACGT\tDP:f:1.00\nP\t1\t1+\t*\tLN:i:5\tFN:Z:a.fasta\tHD:Z:c\n", lib_path=path)
+
+
+def test_decompress_command_reproduces_the_input_files(tmp_path):
+    """tests.rs:114-127 through the library: compress a directory (oracle), decompress the GFA (library) -> the same files
+    (plain ones byte for byte, gzipped ones after gunzip); plus the single-file output format of decompress.rs:117-137."""
+    import gzip
+    lib = _capi.load_library(emu_lib.emu_path())
+    src = tmp_path / "in"; src.mkdir()
+    files = {"a.fasta": [("c1 some text", "ACGTTGCAAGGCTTACGATCGATCGGATCGATTAGC"), ("c2", "TTGACCGATGCATGCATGGGATCAAC")],
+             "b with space.fna": [("x", "GGATCGATTAGCACGTTGCAAGGCTTACGATCGATC")],
+             "c.fa.gz": [("z 1", "ACGTTGCAAGGCTTACGATCGATCGGATCGATTAGCAAA")]}
+    for name, recs in files.items():
+        body = "".join(f">{h}\n{s}\n" for h, s in recs).encode()
+        (src / name).write_bytes(gzip.compress(body) if name.endswith(".gz") else body)
+    out = tmp_path / "ac"
+    O.compress_dir(src, out, k=11)
+    dec = tmp_path / "dec"
+    one = tmp_path / "all.fasta"
+    assert lib.ac_decompress(str(out / "input_assemblies.gfa").encode(), str(dec).encode(), str(one).encode(), C.c_int(3)) == 0, lib.ac_last_error()
+    for name, recs in files.items():
+        body = "".join(f">{h}\n{s}\n" for h, s in recs).encode()
+        got = (dec / name).read_bytes()
+        assert (gzip.decompress(got) if name.endswith(".gz") else got) == body
+    want = "".join(f">{name.replace(' ', '_')}__{h}\n{s}\n" for name, recs in sorted(files.items()) for h, s in recs)
+    assert one.read_text() == want
+    assert lib.ac_decompress(str(out / "missing.gfa").encode(), str(dec).encode(), None, C.c_int(1)) != 0

@@ -144,3 +144,10 @@ def test_fragmented_assemblies_many_sequences():
     assert len(seqs) > 12_000
     U = check_properties(g, seqs, 51)
     assert U > 1000
+
+
+def test_config_d_prime_k101():
+    # scaled replica of BASELINE config D (24 x 100 Mbp, k = 101): 24 x 10 Mbp, four-word keys, device end repair
+    g, seqs, fn, hd = build(24, k=101, genome=10_000_000, device_repair=True)
+    U = check_properties(g, seqs, 101)
+    assert U > 10000

@@ -30,6 +30,10 @@ static double now_s() {
 
 
 static const int MAX_PROBES = 1 << 14;
+// An insert that walks this far has met a table that is (nearly) full — the capacity hint was too small for the input's
+// diversity.  It raises the error word; every wavefront polls that word and stops, and the host retries with a table four times
+// the size.  (Without the early stop a full table turns every insert into a scan of MAX_PROBES slots: minutes instead of ms.)
+static const int MAX_PROBES_INSERT = 1 << 10;
 // This file is compiled once per key width (-DAC_W_ONLY=1,2,3,4,8,16: the kernels and the stage code of that width only) and
 // once as the main unit (AC_W_ONLY=0: everything that does not depend on the width, and the dispatch), so that the widths
 // build in parallel.  The CPU emulation compiles it once with everything in.
@@ -174,7 +178,7 @@ template <int W> AC_D u64 table_insert(const TextCtx& t, const Table& tb, const 
     u64 h = key_hash<W>(ukey);
     u64 mine = slot_make(h, isdot, p);
     u64 s = h & tb.cap_mask;
-    for (int probes = 0; probes < MAX_PROBES; probes++) {
+    for (int probes = 0; probes < MAX_PROBES_INSERT; probes++) {
         u64 v = tb.slots[s];
         if (v == SLOT_EMPTY) {
             u64 old = atomic_cas64(&tb.slots[s], SLOT_EMPTY, mine);
@@ -359,6 +363,10 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
     u64 est = pt.n_bases / hint;
     u64 c = next_pow2(std::max<u64>(1024, est * 3 + 4096));
     if (&pt == &uni && distinct_upper) c = next_pow2(std::max<u64>(1024, distinct_upper * 10 / 7 + 4096));   // no retry: an upper bound is known
+    // the capacity the previous build of a text of this very size ended with (a process that builds the same job again, or a
+    // stream of similar jobs, does not pay for the overflow retries twice)
+    static u64 memo_n_text = 0, memo_cap = 0; static u32 memo_k = 0;
+    if (pt.n_text == memo_n_text && k == memo_k && memo_cap > c) c = memo_cap;
     if (c > next_pow2(pt.n_bases * 2 + 1024)) c = next_pow2(pt.n_bases * 2 + 1024);
     DBuf<InsertStats> istats(257);       // [256].real doubles as the kernel's error word: one D2H reads everything
     DBuf<u64> sl;
@@ -426,6 +434,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
         tm->insert_kernel_ms = 0; tm->insert_launches = 0;
     }
     if (n_distinct >= 0xFFFFFFF0ULL) throw DeviceError("too many distinct k-mers for 32-bit novel indices");
+    memo_n_text = pt.n_text; memo_k = k; memo_cap = c;
     *slots_out = std::move(sl);
     *cap_out = c;
     *n_distinct_out = n_distinct;

@@ -129,3 +129,19 @@ def test_pairwise_distances(emu, k):   # cluster.rs:132-157 o
     for seed in range(24):
         seqs, fn, hd = seqgen.make_case(seed, k)
         parity_util.check_case(k, seqs, fn, hd, lib_path=emu, distances=True)
+
+
+def test_high_diversity_table_growth(emu):
+    # 30 strains 1 % apart: far more distinct k-mers than the capacity hint (assembly count) suggests.  The insert must notice
+    # the full table early, retry with a larger one (this used to take minutes: every insert scanned 16 K slots) and still
+    # give the oracle's graph.
+    import time
+    from autocycler_amd import synth
+    seqs, fn, hd = [], [], []
+    for i, contigs in enumerate(synth.make_assemblies(30, genome=20_000, plasmid=0, sub=1e-2, indel=1e-4, seed=900_000)):
+        for header, s in contigs:
+            seqs.append(s.tobytes().decode()); fn.append(f"strain_{i:03d}.fasta"); hd.append(header)
+    t0 = time.time()
+    g, _, _ = parity_util.check_case(51, seqs, fn, hd, lib_path=emu)
+    assert g.timings()["table_capacity"] >= 4 * 65536 and g.timings()["n_distinct"] > 200_000
+    assert time.time() - t0 < 60

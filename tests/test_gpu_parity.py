@@ -141,3 +141,17 @@ def test_random_synthetic_sets():
         parity_util.check_case(k, seqs, fn, hd, distances=(seed % 2 == 0))
         if seed % 3 == 0:
             sharded_util.run_case(autocycler_amd.LIB_PATH, k, seqs, fn, hd, sharded.Comm(dev), dev)
+
+
+def test_high_diversity_table_growth():
+    # see tests/test_emu_parity.py: the k-mer table outgrows its capacity hint, twice
+    import time
+    seqs, fn, hd = [], [], []
+    from autocycler_amd import synth
+    for i, contigs in enumerate(synth.make_assemblies(30, genome=100_000, plasmid=0, sub=1e-2, indel=1e-4, seed=900_000)):
+        for header, s in contigs:
+            seqs.append(s.tobytes().decode()); fn.append(f"strain_{i:03d}.fasta"); hd.append(header)
+    t0 = time.time()
+    g, _, _ = parity_util.check_case(51, seqs, fn, hd)
+    assert g.timings()["n_distinct"] > 1_000_000
+    assert time.time() - t0 < 120

@@ -10,9 +10,11 @@ the timed region (they are upstream of the seam).
     python bench.py [--gpus N --steps K --warmup W] [--assemblies 96 --genome 5000000 --kmer 51]
 
 N > 1: launched by torch.distributed.run, one rank per GPU.  Default `--mode sharded`: ONE compress job of
-N x 96 assemblies of the same species, sharded by sequence (rank r holds assemblies 96r .. 96r+95); the ranks
-exchange their novel-run fragments (all-gather), the per-unitig depths / positions (all-reduce) and the paths
-(gather to rank 0) over RCCL — autocycler_amd/sharded.py.  Weak scaling: 96 assemblies per GPU.
+N x 96 assemblies, sharded by sequence (rank r holds assemblies 96r .. 96r+95); the ranks exchange their novel-run
+fragments and degree slices (all-gather) and the per-unitig depths / positions (all-reduce) over RCCL —
+autocycler_amd/sharded.py.  Weak scaling: 96 assemblies per GPU; by default the job is a mixed-species one (species r
+on rank r, like BASELINE.json configs[4]) so that the output per GPU is fixed too; `--species one` makes all N x 96
+assemblies one species (the P lines of such a job grow with N^2).
 `--mode independent`: every rank builds the graph of its own 96-assembly set (N unrelated jobs, no data-path collective).
 """
 import argparse
@@ -31,12 +33,20 @@ HBM_PEAK = 8.0e12
 
 
 def make_inputs(args, rank, sharded_job):
-    """sharded_job: this rank's slice (assemblies rank*A .. rank*A + A-1) of ONE job; else an unrelated job per rank."""
+    """sharded_job: this rank's slice (assemblies rank*A .. rank*A + A-1) of ONE job; else an unrelated job per rank.
+    A sharded job is by default a mixed-species one (BASELINE.json configs[4] is): rank r holds the A assemblies of
+    species r, so the work AND the output per GPU stay fixed as N grows (weak scaling).  `--species one`: all N x A
+    assemblies are of one species — every sequence then runs through N times as many unitigs, i.e. the P lines of the
+    job grow with N^2 (that is the reference's output for such a job, not overhead; it is not a fixed per-GPU work)."""
     import numpy as np
     from autocycler_amd import synth
     first = rank * args.assemblies if sharded_job else 0
-    asm = synth.make_assemblies(args.assemblies, genome=args.genome, plasmid=args.plasmid, sub=args.sub, indel=args.indel,
-                                seed=51_000 + (0 if sharded_job else 1000 * rank), first=first)
+    if sharded_job and args.species == "one":
+        asm = synth.make_assemblies(args.assemblies, genome=args.genome, plasmid=args.plasmid, sub=args.sub, indel=args.indel,
+                                    seed=51_000, first=first)
+    else:      # species `rank` (rank 0: exactly the N = 1 workload)
+        asm = synth.make_assemblies(args.assemblies, genome=args.genome, plasmid=args.plasmid, sub=args.sub, indel=args.indel,
+                                    seed=51_000 + 1000 * rank)
     seqs, fn, hd = [], [], []
     for i, contigs in enumerate(asm):
         for header, s in contigs:
@@ -100,6 +110,9 @@ def main():
     ap.add_argument("--repair", choices=["device", "host"], default="device",
                     help="where sequence_end_repair runs (upstream of the timed region): on the device text, or the host implementation")
     ap.add_argument("--no-independent", action="store_true", help="N > 1: skip the secondary independent-jobs measurement")
+    ap.add_argument("--species", choices=["per-gpu", "one"], default="per-gpu",
+                    help="sharded mode at N > 1: one species per GPU (mixed-species job, fixed work and output per GPU) or all "
+                         "N x A assemblies of one species (path output grows with N^2)")
     ap.add_argument("--gather-paths", action="store_true",
                     help="sharded mode: gather the paths of all sequences to rank 0 (default: every rank keeps its own P lines)")
     args = ap.parse_args()
@@ -301,7 +314,12 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{args.assemblies} x ~{args.genome / 1e6:g} Mbp synthetic assemblies per GPU (+plasmid {args.plasmid} bp, "
-                                   f"sub {args.sub:g}, indel {args.indel:g}), k={k}, 1 species; BASELINE.json configs[2]",
+                                   f"sub {args.sub:g}, indel {args.indel:g}), k={k}, " +
+                                   ("1 species; BASELINE.json configs[2]" if world == 1 else
+                                    (f"ONE job of {world} species, one per GPU (mixed-species job as in BASELINE.json configs[4]; rank 0 holds "
+                                     "exactly the N=1 workload, configs[2])" if (mode == "sharded" and args.species == "per-gpu") else
+                                     f"ONE job of {world * args.assemblies} assemblies of one species" if mode == "sharded" else
+                                     f"{world} unrelated jobs of one species each")),
                        "bases_per_gpu": bases, "sequences_per_gpu": n, "mode": mode, "sharding": sharding,
                        "timed_region": "padded+repaired sequences in HBM -> final unitig graph in host RAM (device build + host tail)"},
             "roofline": {"bound": "hbm", "kernel": "insert_wave_kernel<W> (wavefront-cooperative run-following k-mer insert; %d phase launches per build)" % tms[-1]["insert_launches"],

@@ -1,6 +1,6 @@
 """One rank of a multi-process sharded build (launched by the tests, one process per rank; gloo on CPU, or two ranks
 sharing the one GPU of the test box with gloo staging).  Usage:
-    python sharded_worker.py RANK WORLD PORT LIB_PATH DEVICE CASES     CASES = "k:seed,k:seed,..." or "synth:k"
+    python sharded_worker.py RANK WORLD PORT LIB_PATH DEVICE CASES     CASES = "k:seed,k:seed,...", "synth:k", "mixed:k" or "big:assemblies:genome"
 """
 import os
 import sys
@@ -77,6 +77,14 @@ def main():
             for i, contigs in enumerate(synth.make_assemblies(6, genome=40_000, plasmid=2_000, sub=1e-3, indel=1e-4, seed=77)):
                 for header, s in contigs:
                     seqs.append(s.tobytes().decode()); fn.append(f"assembly_{i:04d}.fasta"); hd.append(header)
+        elif a == "mixed":      # a mixed-species job (bench.py's N > 1 workload in miniature): 3 species x 3 assemblies
+            from autocycler_amd import synth
+            k = int(b)
+            seqs, fn, hd = [], [], []
+            for sp in range(3):
+                for i, contigs in enumerate(synth.make_assemblies(3, genome=30_000, plasmid=1_500, sub=1e-3, indel=1e-4, seed=100 + 1000 * sp)):
+                    for header, s in contigs:
+                        seqs.append(s.tobytes().decode()); fn.append(f"assembly_{3 * sp + i:04d}.fasta"); hd.append(header)
         else:
             k, seed = int(a), int(b)
             seqs, fn, hd = seqgen.make_case(seed, k)

@@ -66,7 +66,7 @@ def launch(world, lib_path, device, cases, timeout=600):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_multi_rank_gloo(emu, world):
-    cases = ",".join(f"{k}:{seed}" for k in (5, 11, 31, 51) for seed in range(24)) + ",synth:51,synth:21"
+    cases = ",".join(f"{k}:{seed}" for k in (5, 11, 31, 51) for seed in range(24)) + ",synth:51,synth:21,mixed:51"
     launch(world, emu, "cpu", cases)
 
 

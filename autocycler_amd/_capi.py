@@ -71,6 +71,8 @@ def load_library(path=None):
         raise HipLibraryMissing(f"{path} not found: build the HIP extension first (make -C autocycler_amd/csrc). "
                                 "There is no CPU fallback.")
     try:
+        if os.environ.get("AC_NO_TORCH"):      # torch-free processes (tools/ab_knobs.py): the system HIP runtime is the only one
+            raise ImportError
         # PyTorch bundles its own HIP runtime; when ours (/opt/rocm) is loaded first, torch later finds "no HIP GPUs".
         # Importing torch first makes the dynamic loader resolve our libamdhip64 dependency to the copy torch loaded.
         import torch  # noqa: F401

@@ -263,6 +263,12 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 static size_t arena_estimate(u64 n_text, bool owns_text) { return (size_t)n_text * (owns_text ? 8 : 7) + ((size_t)768 << 20); }
 // Tuning knobs of the insert (environment, read once): AC_INSERT_VARIANT=1 selects the thread-per-chunk kernel,
 // AC_INSERT_CHUNK the largest wavefront chunk (positions).
+// Tuning knobs read on every build (so that one process can compare settings): AC_DEGREE_VARIANT (0 = probe sequences one after
+// the other, 1 = memory-parallel form), AC_TABLE_SHIFT (k-mer table capacity x 2^n over the default sizing),
+// AC_MINKEY_VARIANT (0 = key records + library reduce-by-key, 1 = wavefront segmented min in registers).
+static int degree_variant() { const char* e = getenv("AC_DEGREE_VARIANT"); return e ? atoi(e) : 0; }
+static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : 0; }     // 1 = wavefront segmented min
+static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 3 ? 3 : v); }
 static int insert_variant() { static int v = [] { const char* e = getenv("AC_INSERT_VARIANT"); return e ? atoi(e) : 0; }(); return v; }
 static u64 wave_chunk_max() { static u64 v = [] { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }(); return v; }
 
@@ -368,6 +374,8 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
     static u64 memo_n_text = 0, memo_cap = 0; static u32 memo_k = 0;
     if (pt.n_text == memo_n_text && k == memo_k && memo_cap > c) c = memo_cap;
     if (c > next_pow2(pt.n_bases * 2 + 1024)) c = next_pow2(pt.n_bases * 2 + 1024);
+    const u64 c_default = c;
+    c <<= table_shift();
     DBuf<InsertStats> istats(257);       // [256].real doubles as the kernel's error word: one D2H reads everything
     DBuf<u64> sl;
     u64 n_distinct = 0;
@@ -434,7 +442,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
         tm->insert_kernel_ms = 0; tm->insert_launches = 0;
     }
     if (n_distinct >= 0xFFFFFFF0ULL) throw DeviceError("too many distinct k-mers for 32-bit novel indices");
-    memo_n_text = pt.n_text; memo_k = k; memo_cap = c;
+    memo_n_text = pt.n_text; memo_k = k; memo_cap = std::max(c >> table_shift(), c_default);
     *slots_out = std::move(sl);
     *cap_out = c;
     *n_distinct_out = n_distinct;
@@ -509,7 +517,10 @@ template <int W> void GraphBuilder::Impl::degrees(u64 lo, u64 hi) {
     PackedText& g = *G;
     Table tb = graph_table();
     deg_lo = lo; deg_hi = hi;
-    launch(hi - lo, DegreeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kinfo.ptr(), g.any_dots, lo});
+    bool mlp = false;
+    if constexpr (W <= 4) mlp = degree_variant() == 1 && tb.occ != nullptr;
+    if constexpr (W <= 4) { if (mlp) launch(hi - lo, DegreeMlpFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kinfo.ptr(), g.any_dots, lo}); }
+    if (!mlp) launch(hi - lo, DegreeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kinfo.ptr(), g.any_dots, lo});
     lap(&tm->degree);
 }
 
@@ -534,9 +545,24 @@ template <int W> void GraphBuilder::Impl::unitigs() {
     // K8 min canonical k-mer per unitig
     DBuf<MinVal<W>> umin(U);
     if constexpr (W <= 4) {
-        DBuf<MinVal<W>> vals(N); DBuf<u32> seg(N);
-        launch(N, CKeyFunctor<W>{t, npos.ptr(), scan.ptr(), vals.ptr(), seg.ptr()});
-        reduce_by_segment(seg.ptr(), vals.ptr(), N, umin.ptr(), U, MinOp<W>(), counters.ptr() + 3);
+        if (minkey_variant() == 1) {      // wavefront form: keys stay in registers
+            const u64 n_waves = (N + 63) / 64;
+            DBuf<MinVal<W>> wfirst(n_waves), wlast(n_waves);
+            MinWaveArgs<W> a{t, npos.ptr(), scan.ptr(), N, umin.ptr(), wfirst.ptr(), wlast.ptr()};
+#ifdef AC_EMU
+            launch(n_waves, MinWaveEmuFunctor<W>{a});
+#else
+            const u64 blocks = (N + 255) / 256;
+            if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+            hipLaunchKernelGGL(minkey_wave_kernel<W>, dim3((unsigned)blocks), dim3(256), 0, 0, a);
+            AC_HIP_CHECK(hipGetLastError());
+#endif
+            launch(U, MinJoinFunctor<W>{ustart.ptr(), U, N, wfirst.ptr(), wlast.ptr(), umin.ptr()});
+        } else {
+            DBuf<MinVal<W>> vals(N); DBuf<u32> seg(N);
+            launch(N, CKeyFunctor<W>{t, npos.ptr(), scan.ptr(), vals.ptr(), seg.ptr()});
+            reduce_by_segment(seg.ptr(), vals.ptr(), N, umin.ptr(), U, MinOp<W>(), counters.ptr() + 3);
+        }
     } else {      // wide keys: arg-min over indices, the keys recomputed from the text inside the operator
         DBuf<u32> umin_idx(U);
         segment_argmin(scan.ptr(), N, umin_idx.ptr(), U, MinIdxOp<W>{t, npos.ptr()}, counters.ptr() + 3);      // scan[i] = unitig of novel k-mer i

@@ -268,6 +268,7 @@ static size_t arena_estimate(u64 n_text, bool owns_text) { return (size_t)n_text
 // AC_MINKEY_VARIANT (0 = key records + library reduce-by-key, 1 = wavefront segmented min in registers).
 static int degree_variant() { const char* e = getenv("AC_DEGREE_VARIANT"); return e ? atoi(e) : 0; }
 static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : 0; }     // 1 = wavefront segmented min
+static u32 path_chunk() { const char* e = getenv("AC_PATH_CHUNK"); int v = e ? atoi(e) : 256; return (u32)(v < 64 ? 64 : (v > 4096 ? 4096 : v)); }   // text positions per path walker
 static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 3 ? 3 : v); }
 static int insert_variant() { static int v = [] { const char* e = getenv("AC_INSERT_VARIANT"); return e ? atoi(e) : 0; }(); return v; }
 static u64 wave_chunk_max() { static u64 v = [] { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }(); return v; }
@@ -601,7 +602,7 @@ template <int W> void GraphBuilder::Impl::walk() {
     Table tb = graph_table();
     Novel nv{bm.ptr(), wprefix.ptr()};
     UnitigCtx uc{head.ptr(), scan.ptr(), rank.ptr(), uorient.ptr(), ustart.ptr(), ulen.ptr(), U, N};
-    const u32 PC = 256;
+    const u32 PC = path_chunk();
     u64 n_walkers = (loc.n_text + PC - 1) / PC;
     depth.alloc(U, true); minpos_fwd.alloc(U); minpos_rev.alloc(U);
     minpos_fwd.fill_bytes(0xFF); minpos_rev.fill_bytes(0xFF);

@@ -263,13 +263,18 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 static size_t arena_estimate(u64 n_text, bool owns_text) { return (size_t)n_text * (owns_text ? 8 : 7) + ((size_t)768 << 20); }
 // Tuning knobs of the insert (environment, read once): AC_INSERT_VARIANT=1 selects the thread-per-chunk kernel,
 // AC_INSERT_CHUNK the largest wavefront chunk (positions).
-// Tuning knobs read on every build (so that one process can compare settings): AC_DEGREE_VARIANT (0 = probe sequences one after
-// the other, 1 = memory-parallel form), AC_TABLE_SHIFT (k-mer table capacity x 2^n over the default sizing),
-// AC_MINKEY_VARIANT (0 = key records + library reduce-by-key, 1 = wavefront segmented min in registers).
-static int degree_variant() { const char* e = getenv("AC_DEGREE_VARIANT"); return e ? atoi(e) : 0; }
-static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : 0; }     // 1 = wavefront segmented min
-static u32 path_chunk() { const char* e = getenv("AC_PATH_CHUNK"); int v = e ? atoi(e) : 256; return (u32)(v < 64 ? 64 : (v > 4096 ? 4096 : v)); }   // text positions per path walker
-static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 3 ? 3 : v); }
+// Tuning knobs, read on every build so that one process can compare settings (tools/ab_knobs.py; measurements in
+// profiles/r03*_ab_knobs_configC.jsonl):
+//   AC_TABLE_SHIFT    k-mer table capacity = 2^n x the reference-style sizing.  Default 1 (load factor ~0.23 instead of ~0.46 on
+//                     similar assemblies): the occupancy bitmap then answers 77 % instead of 54 % of the lookups of absent
+//                     neighbours, and the degree kernel is bound by exactly the table lines those lookups fetch.
+//   AC_MINKEY_VARIANT 1 (default) = wavefront segmented min with the keys in registers, 0 = key records + library reduce-by-key.
+//   AC_PATH_CHUNK     text positions per path walker (default 256; 128 and 512 measured slower).
+//   AC_REMAP_BLOCK    path entries per wavefront in the final renumbering.
+static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : 1; }
+static u32 path_chunk() { const char* e = getenv("AC_PATH_CHUNK"); int v = e ? atoi(e) : 256; return (u32)(v < 64 ? 64 : (v > 4096 ? 4096 : v)); }
+static u32 remap_block() { const char* e = getenv("AC_REMAP_BLOCK"); int v = e ? atoi(e) : 4096; v = v < 64 ? 64 : (v > 65536 ? 65536 : v); return (u32)(v & ~63); }
+static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 3 ? 3 : v); }
 static int insert_variant() { static int v = [] { const char* e = getenv("AC_INSERT_VARIANT"); return e ? atoi(e) : 0; }(); return v; }
 static u64 wave_chunk_max() { static u64 v = [] { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }(); return v; }
 
@@ -518,10 +523,7 @@ template <int W> void GraphBuilder::Impl::degrees(u64 lo, u64 hi) {
     PackedText& g = *G;
     Table tb = graph_table();
     deg_lo = lo; deg_hi = hi;
-    bool mlp = false;
-    if constexpr (W <= 4) mlp = degree_variant() == 1 && tb.occ != nullptr;
-    if constexpr (W <= 4) { if (mlp) launch(hi - lo, DegreeMlpFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kinfo.ptr(), g.any_dots, lo}); }
-    if (!mlp) launch(hi - lo, DegreeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kinfo.ptr(), g.any_dots, lo});
+    launch(hi - lo, DegreeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kinfo.ptr(), g.any_dots, lo});
     lap(&tm->degree);
 }
 
@@ -775,13 +777,14 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     sums.fill_bytes(0);
     if (want_paths) out->path_block = PinnedPool::get().alloc(n_ent * 4);
     {
-        const u64 n_waves = (n_ent + 4095) / 4096;
+        const u64 RB = remap_block();
+        const u64 n_waves = (n_ent + RB - 1) / RB;
         const u64 per_chunk = std::max<u64>((n_waves + 3) / 4, 64);
         for (u64 w = 0; w < n_waves; w += per_chunk) {
             u64 cnt = std::min<u64>(per_chunk, n_waves - w);
-            launch_full(cnt * 64, RemapFunctor{ent_val.ptr(), number_len.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr(), w});
+            launch_full(cnt * 64, RemapFunctor{ent_val.ptr(), number_len.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr(), w, (u32)RB});
             if (want_paths) {
-                u64 b = w * 4096, e2 = std::min<u64>((w + cnt) * 4096, n_ent);
+                u64 b = w * RB, e2 = std::min<u64>((w + cnt) * RB, n_ent);
                 side.after_main();
                 copy_d2h_async((int32_t*)out->path_block.p + b, ent_val.ptr() + b, (e2 - b) * 4, side.stream());
             }

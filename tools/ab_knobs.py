@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--kmer", type=int, default=51)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--emu", action="store_true", help="dry run of this script on the CPU emulation (tests/_emu), small sizes only")
-    ap.add_argument("--variants", type=str, default="base;AC_DEGREE_VARIANT=1;AC_TABLE_SHIFT=1;AC_DEGREE_VARIANT=1,AC_TABLE_SHIFT=1;base")
+    ap.add_argument("--variants", type=str, default="base;AC_TABLE_SHIFT=0,AC_MINKEY_VARIANT=0;AC_TABLE_SHIFT=2;base")
     args = ap.parse_args()
     import numpy as np
     from autocycler_amd import _capi, synth
@@ -83,7 +83,7 @@ def main():
 
     for _ in range(2):
         build().close()
-    knobs = ("AC_DEGREE_VARIANT", "AC_TABLE_SHIFT", "AC_INSERT_CHUNK")
+    knobs = [kn for kn in os.environ if kn.startswith("AC_") and kn != "AC_NO_TORCH"] + ["AC_TABLE_SHIFT", "AC_MINKEY_VARIANT", "AC_PATH_CHUNK", "AC_REMAP_BLOCK", "AC_INSERT_CHUNK"]
     for variant in args.variants.split(";"):
         for kn in knobs:
             os.environ.pop(kn, None)

@@ -271,12 +271,15 @@ static size_t arena_estimate(u64 n_text, bool owns_text) { return (size_t)n_text
 //   AC_MINKEY_VARIANT 1 (default) = wavefront segmented min with the keys in registers, 0 = key records + library reduce-by-key.
 //   AC_PATH_CHUNK     text positions per path walker (default 256; 128 and 512 measured slower).
 //   AC_REMAP_BLOCK    path entries per wavefront in the final renumbering.
+//   AC_INSERT_CHUNK / AC_INSERT_GROWTH / AC_INSERT_WAVES   insert phases: longest wavefront chunk, prefix growth factor, wavefronts per phase.
 static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : 1; }
 static u32 path_chunk() { const char* e = getenv("AC_PATH_CHUNK"); int v = e ? atoi(e) : 256; return (u32)(v < 64 ? 64 : (v > 4096 ? 4096 : v)); }
 static u32 remap_block() { const char* e = getenv("AC_REMAP_BLOCK"); int v = e ? atoi(e) : 4096; v = v < 64 ? 64 : (v > 65536 ? 65536 : v); return (u32)(v & ~63); }
 static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 3 ? 3 : v); }
 static int insert_variant() { static int v = [] { const char* e = getenv("AC_INSERT_VARIANT"); return e ? atoi(e) : 0; }(); return v; }
-static u64 wave_chunk_max() { static u64 v = [] { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }(); return v; }
+static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
+static u64 insert_growth() { const char* e = getenv("AC_INSERT_GROWTH"); long x = e ? atol(e) : 2; return (u64)(x < 2 ? 2 : x); }      // phase i+1 ends at growth x the end of phase i
+static u64 insert_waves_target() { const char* e = getenv("AC_INSERT_WAVES"); long x = e ? atol(e) : 16384; return (u64)(x < 1024 ? 1024 : x); }   // wavefronts a long phase is cut into
 
 // A text resident in HBM with its sequence table and its 2-bit packing.
 struct PackedText {
@@ -404,11 +407,11 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
         u64 first = std::max<u64>(p_end_all / hint, 1u << 16);
         u64 pb = 0;
         while (pb < p_end_all) {
-            u64 pe = (pb == 0) ? first : pb * 2;
+            u64 pe = (pb == 0) ? first : pb * insert_growth();
             if (pe > p_end_all || p_end_all - pe < (1u << 16)) pe = p_end_all;
             u64 len = pe - pb;
             if (insert_variant() == 0) {      // one wavefront per chunk: >= ~16 K wavefronts when the phase is long
-                u64 c = (len / 16384 + 63) & ~63ULL;
+                u64 c = (len / insert_waves_target() + 63) & ~63ULL;
                 u32 chunk = (u32)std::min<u64>(std::max<u64>(c, 256), wave_chunk_max());
                 u64 n_waves = (len + chunk - 1) / chunk;
 #ifdef AC_EMU

@@ -83,10 +83,9 @@ def main():
 
     for _ in range(2):
         build().close()
-    knobs = [kn for kn in os.environ if kn.startswith("AC_") and kn != "AC_NO_TORCH"] + ["AC_TABLE_SHIFT", "AC_MINKEY_VARIANT", "AC_PATH_CHUNK", "AC_REMAP_BLOCK", "AC_INSERT_CHUNK"]
     for variant in args.variants.split(";"):
-        for kn in knobs:
-            os.environ.pop(kn, None)
+        for kn in [kn for kn in os.environ if kn.startswith("AC_") and kn != "AC_NO_TORCH"]:
+            del os.environ[kn]
         if variant != "base":
             for kv in variant.split(","):
                 a, b = kv.split("=")

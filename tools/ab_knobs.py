@@ -114,7 +114,7 @@ def main():
             print(json.dumps({"variant": variant, "ms_median": ts_sorted[len(ts) // 2], "ms_min": ts_sorted[0], "ms_mean": sum(ts) / len(ts),
                               "Mbp_s_median": bases / 1e3 / ts_sorted[len(ts) // 2], "insert_kernel_ms": sum(ins) / len(ins),
                               "stages_ms": {a: round(b * 1e3, 3) for a, b in tm.items() if isinstance(b, float) and b > 2e-5 and a != "insert_kernel_ms"},
-                              "table_capacity": tm["table_capacity"], "unitigs": st["unitigs"], "gfa_md5": dg}), flush=True)
+                              "table_capacity": tm["table_capacity"], "insert_launches": tm["insert_launches"], "unitigs": st["unitigs"], "gfa_md5": dg}), flush=True)
         except Exception as e:      # a variant that fails must not take the others with it
             print(json.dumps({"variant": variant, "error": str(e)}), flush=True)
     lib.ac_seqs_free(h_seqs)

@@ -274,8 +274,7 @@ static size_t arena_estimate(u64 n_text, bool owns_text) { return (size_t)n_text
 //   AC_INSERT_CHUNK / AC_INSERT_GROWTH / AC_INSERT_WAVES   insert phases: longest wavefront chunk, prefix growth factor, wavefronts per phase;
 //   AC_INSERT_ADAPT (default 1) / AC_INSERT_CHUNK_REST      redundant text: everything after the second phase in one launch, and its longest chunk.
 static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : 1; }
-static int path_diag() { const char* e = getenv("AC_PATH_DIAG"); return e ? atoi(e) : 0; }      // measurement only: the result is wrong when set
-static int path_records() { const char* e = getenv("AC_PATH_RECORDS"); return e ? (atoi(e) & 3) : 0; }   // bit 0: read-only 128-byte records, bit 1: 16-byte update structs
+static int path_diag() { const char* e = getenv("AC_PATH_DIAG"); return e ? (atoi(e) & 3) : 0; }      // measurement only: the result is wrong when set
 static u32 path_chunk() { const char* e = getenv("AC_PATH_CHUNK"); int v = e ? atoi(e) : 256; return (u32)(v < 64 ? 64 : (v > 4096 ? 4096 : v)); }
 static u32 remap_block() { const char* e = getenv("AC_REMAP_BLOCK"); int v = e ? atoi(e) : 4096; v = v < 64 ? 64 : (v > 65536 ? 65536 : v); return (u32)(v & ~63); }
 static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 3 ? 3 : v); }
@@ -632,14 +631,8 @@ template <int W> void GraphBuilder::Impl::walk() {
     DBuf<u32> seq_tid(loc.n_seqs), seq_j(loc.n_seqs);
     path_off.alloc((u64)loc.n_seqs + 1);
     wcount.fill_bytes(0);
-    DBuf<UnitigRec> rec; DBuf<UnitigHot> hot;
-    const int layout = path_records();
-    if (layout & 1) { rec.alloc(U); launch((u64)U * 16, RecFillFunctor{wlinks.ptr(), ulen.ptr(), rec.ptr()}); }
-    if (layout & 2) { hot.alloc(U); launch(U, HotFillFunctor{hot.ptr()}); }
     launch(n_walkers, PathWalkFunctor<W>{t, g, tb, nv, uc, wlinks.ptr(), PC, stage.ptr(), wcount.ptr(), seq_tid.ptr(), seq_j.ptr(),
-                                        depth.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), counters.ptr() + 4,
-                                        (layout & 1) ? rec.ptr() : nullptr, (layout & 2) ? hot.ptr() : nullptr, path_diag()});
-    if (layout & 2) launch(U, HotReadFunctor{hot.ptr(), depth.ptr(), minpos_fwd.ptr(), minpos_rev.ptr()});
+                                        depth.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), counters.ptr() + 4, path_diag()});
     exclusive_scan_u64(wcount.ptr(), woff.ptr(), n_walkers + 1);
     n_ent = read_scalar(woff.ptr() + n_walkers);
     ent_val.alloc(n_ent);

@@ -145,3 +145,49 @@ def test_high_diversity_table_growth(emu):
     g, _, _ = parity_util.check_case(51, seqs, fn, hd, lib_path=emu)
     assert g.timings()["table_capacity"] >= 4 * 65536 and g.timings()["n_distinct"] > 200_000
     assert time.time() - t0 < 60
+
+
+KNOB_SETTINGS = [{"AC_TABLE_SHIFT": "0"}, {"AC_TABLE_SHIFT": "2"}, {"AC_MINKEY_VARIANT": "0"}, {"AC_PATH_CHUNK": "64"},
+                 {"AC_REMAP_BLOCK": "128"}, {"AC_INSERT_ADAPT": "0", "AC_INSERT_GROWTH": "4"}, {"AC_INSERT_CHUNK": "256", "AC_INSERT_WAVES": "1024"}]
+
+
+@pytest.mark.parametrize("knobs", KNOB_SETTINGS, ids=lambda d: ",".join(f"{a}={b}" for a, b in d.items()))
+def test_tuning_knobs_do_not_change_the_result(emu, monkeypatch, knobs):
+    # every tuning knob of graph_build.hip (table sizing, seed-kernel form, walker span, insert phases) only moves work around
+    for a, b in knobs.items():
+        monkeypatch.setenv(a, b)
+    for k, seed in ((5, 3), (11, 7), (31, 11), (51, 13), (51, 21)):
+        seqs, fn, hd = seqgen.make_case(seed, k)
+        parity_util.check_case(k, seqs, fn, hd, lib_path=emu)
+
+
+def _redundant_set(n_asm, genome, seed):
+    from autocycler_amd import synth
+    seqs, fn, hd = [], [], []
+    for i, contigs in enumerate(synth.make_assemblies(n_asm, genome=genome, plasmid=genome // 40, sub=2e-4, indel=2e-5, seed=seed)):
+        for header, s in contigs:
+            seqs.append(s.tobytes().decode()); fn.append(f"assembly_{i:04d}.fasta"); hd.append(header)
+    return seqs, fn, hd
+
+
+@pytest.mark.parametrize("adapt", ["1", "0"])
+def test_insert_phase_schedule_on_a_redundant_text(emu, monkeypatch, adapt):
+    # 10 similar assemblies of 80 kbp: long enough for the insert to reach its third phase, where the claim counters of
+    # the first two decide that the rest of the text goes in one launch (3 launches) instead of doubling on (5 launches)
+    monkeypatch.setenv("AC_INSERT_ADAPT", adapt)
+    seqs, fn, hd = _redundant_set(10, 80_000, 2024)
+    g, _, _ = parity_util.check_case(51, seqs, fn, hd, lib_path=emu)
+    assert g.timings()["insert_launches"] == (3 if adapt == "1" else 5)
+
+
+def test_seed_kernel_long_unitigs_across_wavefronts(emu, monkeypatch):
+    # two identical 30 kbp sequences + one with a single substitution: unitigs of thousands of k-mers, i.e. dozens of
+    # 64-entry wavefront pieces per unitig for the segmented-min seed kernel, in both forms
+    import numpy as np
+    rng = np.random.default_rng(5)
+    a = "".join("ACGT"[i] for i in rng.integers(0, 4, size=30_000))
+    b = a[:17_321] + ("A" if a[17_321] != "A" else "C") + a[17_322:]
+    for variant in ("1", "0"):
+        monkeypatch.setenv("AC_MINKEY_VARIANT", variant)
+        for k in (21, 51, 101):
+            parity_util.check_case(k, [a, a, b], ["x.fasta", "y.fasta", "z.fasta"], ["a", "a2", "b"], lib_path=emu)

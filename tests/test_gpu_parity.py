@@ -155,3 +155,27 @@ def test_high_diversity_table_growth():
     g, _, _ = parity_util.check_case(51, seqs, fn, hd)
     assert g.timings()["n_distinct"] > 1_000_000
     assert time.time() - t0 < 120
+
+
+@pytest.mark.parametrize("knobs", [{"AC_TABLE_SHIFT": "0"}, {"AC_TABLE_SHIFT": "2"}, {"AC_MINKEY_VARIANT": "0"}, {"AC_PATH_CHUNK": "64"},
+                                   {"AC_REMAP_BLOCK": "128"}, {"AC_INSERT_ADAPT": "0", "AC_INSERT_GROWTH": "4"},
+                                   {"AC_INSERT_CHUNK": "256", "AC_INSERT_WAVES": "1024"}],
+                         ids=lambda d: ",".join(f"{a}={b}" for a, b in d.items()))
+def test_tuning_knobs_do_not_change_the_result(monkeypatch, knobs):
+    # the knobs of graph_build.hip (read on every build) only move work around: same GFA as the oracle under each of them
+    for a, b in knobs.items():
+        monkeypatch.setenv(a, b)
+    for k, seed in ((11, 7), (51, 13)):
+        seqs, fn, hd = seqgen.make_case(seed, k)
+        parity_util.check_case(k, seqs, fn, hd)
+    seqs, fn, hd = _synth_case(6, 60_000, 3_000, 1e-3, 1e-4, 99)
+    parity_util.check_case(51, seqs, fn, hd)
+
+
+@pytest.mark.parametrize("adapt", ["1", "0"])
+def test_insert_phase_schedule_on_a_redundant_text(monkeypatch, adapt):
+    # third phase reached: the claim counters of the first two send the rest of a redundant text in one launch
+    monkeypatch.setenv("AC_INSERT_ADAPT", adapt)
+    seqs, fn, hd = _synth_case(10, 80_000, 2_000, 2e-4, 2e-5, 2024)
+    g, _, _ = parity_util.check_case(51, seqs, fn, hd)
+    assert g.timings()["insert_launches"] == (3 if adapt == "1" else 5)

@@ -342,6 +342,18 @@ def main():
                       "simplify_passes": tms[-1]["simplify_passes"]},
             "prep_s": {"generate": t_gen, "end_repair": t_repair, "end_repair_info": repair_info, "h2d": t_h2d, "h2d_GBps": n_text / t_h2d / 1e9},
         }
+        if traffic is not None:      # the other two big kernels against the same peak, from the same PMC passes (bytes per build) and the
+            others = []      # stage timers of this run (a stage = the kernel + its small helpers)
+            try:
+                pk = pj.get("per_kernel_per_build", {})
+                for pat, st_key, what in (("PathWalkFunctor", "paths", "path walk (K10) + compaction"), ("DegreeFunctor", "degree", "degree kernel (K5) + first flags")):
+                    b = sum(v["hbm_side_bytes"] for kk, v in pk.items() if pat in kk)
+                    if b and stage.get(st_key):
+                        others.append({"kernel": pat, "stage": what, "stage_ms": stage[st_key] * 1e3, "traffic": b,
+                                       "traffic_GBps": b / stage[st_key] / 1e9, "traffic_frac": b / stage[st_key] / HBM_PEAK})
+            except (KeyError, TypeError, ZeroDivisionError):
+                pass
+            line["roofline_other"] = others
         # The kernels of this path are bound by random accesses into the k-mer table, not by streamed bytes: price them against
         # the device's measured random-access ceilings as well (a ~20 ms microbenchmark inside the library).
         cas, rd = C.c_double(), C.c_double()

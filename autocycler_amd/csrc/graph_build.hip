@@ -270,11 +270,13 @@ static size_t arena_estimate(u64 n_text, bool owns_text) { return (size_t)n_text
 //                     neighbours, and the degree kernel is bound by exactly the table lines those lookups fetch.
 //   AC_MINKEY_VARIANT 1 (default) = wavefront segmented min with the keys in registers, 0 = key records + library reduce-by-key.
 //   AC_PATH_CHUNK     text positions per path walker (default 256; 128 and 512 measured slower).
+//   AC_PATH_FILTER    1 (default): the walk keeps smallest positions only for unitig sides that can become expand_repeats
+//                     destinations (paths stage 1.35 -> 1.25 ms).
 //   AC_REMAP_BLOCK    path entries per wavefront in the final renumbering.
 //   AC_INSERT_CHUNK / AC_INSERT_GROWTH / AC_INSERT_WAVES   insert phases: longest wavefront chunk, prefix growth factor, wavefronts per phase;
 //   AC_INSERT_ADAPT (default 1) / AC_INSERT_CHUNK_REST      redundant text: everything after the second phase in one launch, and its longest chunk.
 static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : 1; }
-static bool path_filter() { const char* e = getenv("AC_PATH_FILTER"); return e ? atoi(e) != 0 : false; }   // smallest positions only for possible expand_repeats destinations
+static bool path_filter() { const char* e = getenv("AC_PATH_FILTER"); return e ? atoi(e) != 0 : true; }   // smallest positions only for possible expand_repeats destinations
 static int path_diag() { const char* e = getenv("AC_PATH_DIAG"); return e ? (atoi(e) & 3) : 0; }      // measurement only: the result is wrong when set
 static u32 path_chunk() { const char* e = getenv("AC_PATH_CHUNK"); int v = e ? atoi(e) : 256; return (u32)(v < 64 ? 64 : (v > 4096 ? 4096 : v)); }
 static u32 remap_block() { const char* e = getenv("AC_REMAP_BLOCK"); int v = e ? atoi(e) : 4096; v = v < 64 ? 64 : (v > 65536 ? 65536 : v); return (u32)(v & ~63); }

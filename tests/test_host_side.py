@@ -184,3 +184,21 @@ def test_decompress_command_reproduces_the_input_files(tmp_path):
     want = "".join(f">{name.replace(' ', '_')}__{h}\n{s}\n" for name, recs in sorted(files.items()) for h, s in recs)
     assert one.read_text() == want
     assert lib.ac_decompress(str(out / "missing.gfa").encode(), str(dec).encode(), None, C.c_int(1)) != 0
+
+
+def test_ab_knobs_tool_on_the_emulation():
+    # tools/ab_knobs.py (the torch-free A/B driver of the tuning knobs) stays runnable: every variant reports the same graph digest
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root / "tools" / "ab_knobs.py"), "--emu", "--assemblies", "4", "--genome", "30000", "--steps", "1",
+                          "--variants", "base;AC_TABLE_SHIFT=0,AC_MINKEY_VARIANT=0;AC_PATH_FILTER=0;AC_INSERT_ADAPT=0"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    variants = [r for r in rows if "variant" in r]
+    assert len(variants) == 4 and all("error" not in r for r in variants), variants
+    assert len({r["gfa_md5"] for r in variants}) == 1
+    assert variants[0]["table_capacity"] == 2 * variants[1]["table_capacity"]

@@ -380,6 +380,18 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             a, b2 = args.cpu_sample.split("x")
             line["cpu_baseline"] = cpu_baseline(k, int(a), int(b2))
+            gold = ROOT / "tests" / "golden" / "configC_k51.json"      # the oracle on the WHOLE workload, run once where it was recorded
+            if default_workload and gold.exists():
+                try:
+                    gj = json.loads(gold.read_text())
+                    hot = gj["seconds"]["kmer_graph"] + gj["seconds"]["unitig_graph"] + gj["seconds"]["simplify"]
+                    line["cpu_baseline_full_size"] = {
+                        "value": bases / 1e6 / hot, "unit": "Mbp/s", "cores": 1, "kind": "port", "seconds": hot,
+                        "sample": "the whole workload (96 x ~5 Mbp), recorded once by tests/golden/make_configC_golden.sh on " + gj.get("host", "the build container") +
+                                  "; NOT timed in this run; its GFA md5 is what tests/test_gpu_fullsize.py compares the device result with",
+                        "gfa_md5": gj["gfa_md5"]}
+                except (KeyError, ValueError, TypeError):
+                    pass
         print(json.dumps(line))
     if g is not None:
         g.close()

@@ -151,3 +151,25 @@ def test_config_d_prime_k101():
     g, seqs, fn, hd = build(24, k=101, genome=10_000_000, device_repair=True)
     U = check_properties(g, seqs, 101)
     assert U > 10000
+
+
+def test_config_c_gfa_digest_equals_the_oracle():
+    """Bit-exact parity at BASELINE's full size: the GFA built on the device for config C (96 x ~5 Mbp, k = 51; end repair on the
+    device text, build, GFA text — the flow of tools/ab_knobs.py, run here as the same torch-free process) has the md5 the
+    ORACLE produced for the same 96 FASTA files on the CPU (tests/golden/configC_k51.json, made by
+    tests/golden/make_configC_golden.sh: 26 minutes of the restated reference path), and the same printed statistics."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    golden = json.loads((root / "tests" / "golden" / "configC_k51.json").read_text())
+    out = subprocess.run([sys.executable, str(root / "tools" / "ab_knobs.py"), "--variants", "base", "--steps", "1"],
+                         env={**os.environ, "AC_NO_TORCH": "1"}, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    base = [r for r in rows if r.get("variant") == "base"]
+    assert base and "error" not in base[0], rows
+    assert base[0]["unitigs"] == golden["post"]["unitigs"]
+    assert base[0]["gfa_md5"] == golden["gfa_md5"]

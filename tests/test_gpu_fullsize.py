@@ -153,19 +153,21 @@ def test_config_d_prime_k101():
     assert U > 10000
 
 
-def test_config_c_gfa_digest_equals_the_oracle():
-    """Bit-exact parity at BASELINE's full size: the GFA built on the device for config C (96 x ~5 Mbp, k = 51; end repair on the
-    device text, build, GFA text — the flow of tools/ab_knobs.py, run here as the same torch-free process) has the md5 the
-    ORACLE produced for the same 96 FASTA files on the CPU (tests/golden/configC_k51.json, made by
-    tests/golden/make_configC_golden.sh: 26 minutes of the restated reference path), and the same printed statistics."""
+@pytest.mark.parametrize("golden_name,extra", [("configC_k51", []), ("configDprime_k101", ["--assemblies", "24", "--genome", "10000000", "--kmer", "101"])])
+def test_gfa_digest_equals_the_oracle(golden_name, extra):
+    """Bit-exact parity at full size: the GFA built on the device (end repair on the device text, build, GFA text — the flow of
+    tools/ab_knobs.py, run here as the same torch-free process) has the md5 the ORACLE produced for the same FASTA files on the CPU
+    (tests/golden/*.json, made by tests/golden/make_configC_golden.sh: 26 and 12 minutes of the restated reference path), and the
+    same unitig count.  configC_k51 = BASELINE configs[2] (96 x ~5 Mbp, k = 51: the benchmark workload); configDprime_k101 = the
+    scaled replica of configs[3] (24 x ~10 Mbp, k = 101: four-word keys)."""
     import json
     import os
     import subprocess
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
-    golden = json.loads((root / "tests" / "golden" / "configC_k51.json").read_text())
-    out = subprocess.run([sys.executable, str(root / "tools" / "ab_knobs.py"), "--variants", "base", "--steps", "1"],
+    golden = json.loads((root / "tests" / "golden" / (golden_name + ".json")).read_text())
+    out = subprocess.run([sys.executable, str(root / "tools" / "ab_knobs.py"), "--variants", "base", "--steps", "1"] + extra,
                          env={**os.environ, "AC_NO_TORCH": "1"}, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]

@@ -245,14 +245,15 @@ def test_random_seqs_roundtrip(length, seed):
         assert [q for _, _, q in O.decompress(g1)] == seqs
 
 
-def test_full_size_golden_of_config_c_is_consistent():
-    # tests/golden/configC_k51.json (the oracle on BASELINE configs[2], made by tests/golden/make_configC_golden.sh): what the
-    # device test compares its GFA digest with.  Internal consistency of the recorded statistics (unitig.rs:158-166: trimmed
-    # length = number of k-mers; kmers.len() counts both strands).
+@pytest.mark.parametrize("name,k", [("configC_k51", 51), ("configDprime_k101", 101)])
+def test_full_size_goldens_are_consistent(name, k):
+    # tests/golden/*.json (the oracle on whole configurations, made by tests/golden/make_configC_golden.sh): what the device test
+    # compares its GFA digest with.  Internal consistency of the recorded statistics (unitig.rs:158-166: trimmed length = number
+    # of k-mers; kmers.len() counts both strands).
     import json
     from pathlib import Path
-    g = json.loads((Path(__file__).resolve().parent / "golden" / "configC_k51.json").read_text())
-    assert g["k"] == 51 and len(g["gfa_md5"]) == 32
+    g = json.loads((Path(__file__).resolve().parent / "golden" / (name + ".json")).read_text())
+    assert g["k"] == k and len(g["gfa_md5"]) == 32
     assert g["kmers"] == 2 * g["pre"]["total_length"]
     assert g["pre"]["unitigs"] == g["post"]["unitigs"] and g["pre"]["links"] == g["post"]["links"]
     assert g["post"]["total_length"] < g["pre"]["total_length"]

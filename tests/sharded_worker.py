@@ -81,10 +81,11 @@ def main():
             from autocycler_amd import synth
             k = int(b)
             seqs, fn, hd = [], [], []
-            for sp in range(3):
-                for i, contigs in enumerate(synth.make_assemblies(3, genome=30_000, plasmid=1_500, sub=1e-3, indel=1e-4, seed=100 + 1000 * sp)):
+            n_species, per = (world, 2) if world > 3 else (3, 3)      # bench.py's layout: one species per rank
+            for sp in range(n_species):
+                for i, contigs in enumerate(synth.make_assemblies(per, genome=30_000, plasmid=1_500, sub=1e-3, indel=1e-4, seed=100 + 1000 * sp)):
                     for header, s in contigs:
-                        seqs.append(s.tobytes().decode()); fn.append(f"assembly_{3 * sp + i:04d}.fasta"); hd.append(header)
+                        seqs.append(s.tobytes().decode()); fn.append(f"assembly_{per * sp + i:04d}.fasta"); hd.append(header)
         else:
             k, seed = int(a), int(b)
             seqs, fn, hd = seqgen.make_case(seed, k)

@@ -70,6 +70,16 @@ def test_multi_rank_gloo(emu, world):
     launch(world, emu, "cpu", cases)
 
 
+@pytest.mark.parametrize("world", [4, 8])
+def test_many_ranks_gloo(emu, world):
+    # the world sizes the scaling benchmark runs at (bench.py --gpus 4 / 8): a mixed-species job with one species per rank, the
+    # single-species synthetic job, and adversarial cases that have at least `world` sequences
+    cases = ",".join(f"{k}:{seed}" for k in (11, 51) for seed in range(24)) + ",synth:51,mixed:51"
+    outs = launch(world, emu, "cpu", cases, timeout=900)
+    done = int(outs[0].split("rank 0:")[1].split()[0])
+    assert done >= 3, outs[0][-500:]
+
+
 def test_phase_order_is_enforced(emu):
     """The ac_shard_* calls only work in protocol order, and no other build may start while a sharded one is in flight."""
     import ctypes as C

@@ -153,13 +153,15 @@ def test_config_d_prime_k101():
     assert U > 10000
 
 
-@pytest.mark.parametrize("golden_name,extra", [("configC_k51", []), ("configDprime_k101", ["--assemblies", "24", "--genome", "10000000", "--kmer", "101"])])
+@pytest.mark.parametrize("golden_name,extra", [("configC_k51", []), ("configDprime_k101", ["--assemblies", "24", "--genome", "10000000", "--kmer", "101"]),
+                                               ("configB_k51", ["--assemblies", "12"])])
 def test_gfa_digest_equals_the_oracle(golden_name, extra):
     """Bit-exact parity at full size: the GFA built on the device (end repair on the device text, build, GFA text — the flow of
     tools/ab_knobs.py, run here as the same torch-free process) has the md5 the ORACLE produced for the same FASTA files on the CPU
     (tests/golden/*.json, made by tests/golden/make_configC_golden.sh: 26 and 12 minutes of the restated reference path), and the
     same unitig count.  configC_k51 = BASELINE configs[2] (96 x ~5 Mbp, k = 51: the benchmark workload); configDprime_k101 = the
-    scaled replica of configs[3] (24 x ~10 Mbp, k = 101: four-word keys)."""
+    scaled replica of configs[3] (24 x ~10 Mbp, k = 101: four-word keys); configB_k51 = BASELINE configs[1] (12 x ~5 Mbp, k = 51;
+    golden recorded after the round's GPU allowance was used up: first compared by the round-end run)."""
     import json
     import os
     import subprocess

@@ -245,7 +245,7 @@ def test_random_seqs_roundtrip(length, seed):
         assert [q for _, _, q in O.decompress(g1)] == seqs
 
 
-@pytest.mark.parametrize("name,k", [("configC_k51", 51), ("configDprime_k101", 101)])
+@pytest.mark.parametrize("name,k", [("configB_k51", 51), ("configC_k51", 51), ("configDprime_k101", 101)])
 def test_full_size_goldens_are_consistent(name, k):
     # tests/golden/*.json (the oracle on whole configurations, made by tests/golden/make_configC_golden.sh): what the device test
     # compares its GFA digest with.  Internal consistency of the recorded statistics (unitig.rs:158-166: trimmed length = number

@@ -131,8 +131,18 @@ def main():
     if os.environ.get("BENCH_FORCE_DEVICE") is not None:
         local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
     backend = os.environ.get("BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BENCH_EMU_LIB=<path of tests/_emu/libautocycler_emu.so>: dry run of THIS SCRIPT's plumbing (rank layout, collectives over gloo,
+    # the JSON line) on the CPU emulation of the kernels — used by tests/test_host_side.py only; its numbers mean nothing and the
+    # line says so ("data": "emulation dry run").  Without it the product library is loaded and a GPU is required.
+    emu_lib = os.environ.get("BENCH_EMU_LIB")
+    if emu_lib:
+        backend = "gloo"
+        dev = torch.device("cpu")
+        device_sync = lambda: None
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        device_sync = torch.cuda.synchronize
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
@@ -140,7 +150,7 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    lib = _capi.load_library()          # raises if the HIP extension is missing: no fallback
+    lib = _capi.load_library(emu_lib) if emu_lib else _capi.load_library()          # raises if the HIP extension is missing: no fallback
     lib.ac_seqs_views.restype = C.POINTER(_capi.SeqView)
     lib.ac_seqs_count.restype = C.c_uint32
     lib.ac_seqs_free.argtypes = [C.c_void_p]
@@ -171,7 +181,7 @@ def main():
     t_repair = lib.ac_seqs_repair_seconds(h_seqs)
     t1 = time.time()
     d_text = torch.from_numpy(text).to(dev)      # inputs resident in HBM before the timed region
-    torch.cuda.synchronize()
+    device_sync()
     t_h2d = time.time() - t1
     repair_info = {"where": args.repair, "seconds": t_repair}
     if args.repair == "device":      # sequence_end_repair on the device text, in place (upstream of the timed region)
@@ -212,10 +222,10 @@ def main():
         return _capi.Graph(lib, h, n)
 
     def barrier():
-        torch.cuda.synchronize()
+        device_sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     # One-time initialisation outside both the warmup and the timed region: the first two builds of a process load
     # the code objects, create the pinned result pool and the copy stream (60-180 ms and ~20 ms instead of ~9 ms).
@@ -288,6 +298,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = total_bases / 1e6 / (elapsed / args.steps)
         ins_ms = sum(t["insert_kernel_ms"] for t in tms) / len(tms)
+        if emu_lib and ins_ms <= 0:
+            ins_ms = 1e-3      # the emulation has no HIP events
         alg_bytes = A_K(k) * bases
         achieved = alg_bytes / (ins_ms * 1e-3)
         # HBM bytes of that kernel per build from the PMC passes (collected separately with tools/pmc_round.sh and
@@ -296,6 +308,8 @@ def main():
         traffic, traffic_src = None, None
         pmc = ROOT / "profiles" / "pmc_traffic.json"
         default_workload = (args.assemblies, args.genome, args.plasmid, args.sub, args.indel, k) == (96, 5_000_000, 100_000, 1e-4, 1e-5, 51)
+        if emu_lib and os.environ.get("BENCH_EMU_ASSUME_DEFAULT"):
+            default_workload = True      # dry run only: exercise the fields that are quoted for the default workload
         if pmc.exists() and default_workload:
             pj = json.loads(pmc.read_text())
             traffic = pj["traffic_bytes_per_build"]
@@ -312,7 +326,7 @@ def main():
             "metric": "Mbp/sec through compress->unitig GFA (k=%d)" % k,
             "value": value, "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
+            "dtype": "u64", "data": "synthetic" if not emu_lib else "emulation dry run (not a measurement)",
             "config": {"workload": f"{args.assemblies} x ~{args.genome / 1e6:g} Mbp synthetic assemblies per GPU (+plasmid {args.plasmid} bp, "
                                    f"sub {args.sub:g}, indel {args.indel:g}), k={k}, " +
                                    ("1 species; BASELINE.json configs[2]" if world == 1 else

@@ -202,3 +202,60 @@ def test_ab_knobs_tool_on_the_emulation():
     assert len(variants) == 4 and all("error" not in r for r in variants), variants
     assert len({r["gfa_md5"] for r in variants}) == 1
     assert variants[0]["table_capacity"] == 2 * variants[1]["table_capacity"]
+
+
+def _bench_dry_run(extra_args, launcher=(), env_extra=None, timeout=900):
+    """bench.py's own plumbing (rank layout, gloo collectives, the JSON line) on the CPU emulation of the kernels
+    (BENCH_EMU_LIB): the numbers mean nothing, the line's shape is what the driver parses."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    import emu_lib
+    root = Path(__file__).resolve().parent.parent
+    env = {**os.environ, "BENCH_EMU_LIB": str(emu_lib.emu_path()), **(env_extra or {})}
+    cmd = [sys.executable, *launcher, str(root / "bench.py"), "--assemblies", "3", "--genome", "30000", "--plasmid", "1500",
+           "--steps", "2", "--warmup", "1", *extra_args]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=str(root))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+CONTRACT_KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "roofline"]
+
+
+def test_bench_line_contract_single_rank_dry_run():
+    j = _bench_dry_run(["--cpu-sample", "2x20000"], env_extra={"BENCH_EMU_ASSUME_DEFAULT": "1"})
+    for key in CONTRACT_KEYS + ["cpu_baseline"]:
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True and j["scaling"] == "weak"
+    assert j["unit"] == "Mbp/s" and j["value"] > 0 and j["vs_baseline"] is None and j["dtype"] == "u64"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in j["roofline"], key
+    assert j["roofline"]["bound"] == "hbm" and j["roofline"]["peak"] == 8000.0 and j["roofline"]["traffic"] > 0
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in j["cpu_baseline"], key
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 1
+    assert [o["kernel"] for o in j["roofline_other"]] == ["PathWalkFunctor", "DegreeFunctor"]
+    assert j["cpu_baseline_full_size"]["gfa_md5"] == "c28d41ea9e4784f5f1dd06da6b3eb587"
+    assert "dry run" in j["data"]
+
+
+def test_bench_line_two_ranks_dry_run():
+    # the N > 1 path of bench.py as the driver launches it (torch.distributed.run, one process per rank): ONE mixed-species job
+    # sharded over the ranks, then the same ranks as independent jobs; collectives over gloo here, RCCL on the GPU box
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    j = _bench_dry_run(["--gpus", "2"], launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                                   "--master-port", str(port)))
+    for key in CONTRACT_KEYS + ["sharded", "independent_jobs"]:
+        assert key in j, key
+    assert j["n_gpus"] == 2 and j["config"]["mode"] == "sharded" and "2 species" in j["config"]["workload"]
+    assert j["value"] > 0 and j["independent_jobs"]["value"] > 0
+    assert j["sharded"]["unitigs"] > 0 and j["sharded"]["fragments"] >= j["sharded"]["fragments_rank0"]
+    assert "cpu_baseline" not in j          # rank 0 at N = 1 only

@@ -234,10 +234,10 @@ std::vector<uint8_t> layout_text(const std::vector<SeqView>& seqs, uint32_t k, s
 
 int max_supported_k() { return 501; }   // the reference's own limit (compress.rs:56-60); keys of 1, 2, 3, 4, 8 or 16 words
 #endif
-static int key_words(int k) { int w = words_for_k(k); return w <= 4 ? w : (w <= 8 ? 8 : 16); }
+[[maybe_unused]] static int key_words(int k) { int w = words_for_k(k); return w <= 4 ? w : (w <= 8 ? 8 : 16); }
 
 // renumber_unitigs (unitig_graph.rs:295-315): stable sort of `order` by (length desc, sequence asc, depth desc).
-static void renumber_sort(DBuf<u32>& order, u32 U, const u32* len, const u64* off, const u8* seq, const u32* depth, u32* flag) {
+[[maybe_unused]] static void renumber_sort(DBuf<u32>& order, u32 U, const u32* len, const u64* off, const u8* seq, const u32* depth, u32* flag) {
     if (U <= 1) return;
     DBuf<u32> backup(U);
     copy_d2d(backup.ptr(), order.ptr(), (size_t)U * 4);
@@ -260,7 +260,7 @@ static void renumber_sort(DBuf<u32>& order, u32 U, const u32* len, const u64* of
 static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 // Device memory one build of an n_text-byte text needs, roughly: packed text + bitmaps (~0.6 B/position), staging slots
 // of the path walk (4 B/position), k-mer table and per-k-mer arrays (sized by distinct content), unitig-sized buffers.
-static size_t arena_estimate(u64 n_text, bool owns_text) { return (size_t)n_text * (owns_text ? 8 : 7) + ((size_t)768 << 20); }
+[[maybe_unused]] static size_t arena_estimate(u64 n_text, bool owns_text) { return (size_t)n_text * (owns_text ? 8 : 7) + ((size_t)768 << 20); }
 // Tuning knobs of the insert (environment, read once): AC_INSERT_VARIANT=1 selects the thread-per-chunk kernel,
 // AC_INSERT_CHUNK the largest wavefront chunk (positions).
 // Tuning knobs, read on every build so that one process can compare settings (tools/ab_knobs.py; measurements in
@@ -275,18 +275,18 @@ static size_t arena_estimate(u64 n_text, bool owns_text) { return (size_t)n_text
 //   AC_REMAP_BLOCK    path entries per wavefront in the final renumbering.
 //   AC_INSERT_CHUNK / AC_INSERT_GROWTH / AC_INSERT_WAVES   insert phases: longest wavefront chunk, prefix growth factor, wavefronts per phase;
 //   AC_INSERT_ADAPT (default 1) / AC_INSERT_CHUNK_REST      redundant text: everything after the second phase in one launch, and its longest chunk.
-static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : 1; }
-static bool path_filter() { const char* e = getenv("AC_PATH_FILTER"); return e ? atoi(e) != 0 : true; }   // smallest positions only for possible expand_repeats destinations
-static int path_diag() { const char* e = getenv("AC_PATH_DIAG"); return e ? (atoi(e) & 3) : 0; }      // measurement only: the result is wrong when set
-static u32 path_chunk() { const char* e = getenv("AC_PATH_CHUNK"); int v = e ? atoi(e) : 256; return (u32)(v < 64 ? 64 : (v > 4096 ? 4096 : v)); }
-static u32 remap_block() { const char* e = getenv("AC_REMAP_BLOCK"); int v = e ? atoi(e) : 4096; v = v < 64 ? 64 : (v > 65536 ? 65536 : v); return (u32)(v & ~63); }
-static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 3 ? 3 : v); }
-static int insert_variant() { static int v = [] { const char* e = getenv("AC_INSERT_VARIANT"); return e ? atoi(e) : 0; }(); return v; }
-static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
-static u64 wave_chunk_rest() { const char* e = getenv("AC_INSERT_CHUNK_REST"); u64 x = e ? (u64)atoll(e) : 4096; return (std::max<u64>(x, 256) + 63) & ~63ULL; }   // longest chunk of the one-launch rest
-static bool insert_adaptive() { const char* e = getenv("AC_INSERT_ADAPT"); return e ? atoi(e) != 0 : true; }
-static u64 insert_growth() { const char* e = getenv("AC_INSERT_GROWTH"); long x = e ? atol(e) : 2; return (u64)(x < 2 ? 2 : x); }      // phase i+1 ends at growth x the end of phase i
-static u64 insert_waves_target() { const char* e = getenv("AC_INSERT_WAVES"); long x = e ? atol(e) : 16384; return (u64)(x < 1024 ? 1024 : x); }   // wavefronts a long phase is cut into
+[[maybe_unused]] static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : 1; }
+[[maybe_unused]] static bool path_filter() { const char* e = getenv("AC_PATH_FILTER"); return e ? atoi(e) != 0 : true; }   // smallest positions only for possible expand_repeats destinations
+[[maybe_unused]] static int path_diag() { const char* e = getenv("AC_PATH_DIAG"); return e ? (atoi(e) & 3) : 0; }      // measurement only: the result is wrong when set
+[[maybe_unused]] static u32 path_chunk() { const char* e = getenv("AC_PATH_CHUNK"); int v = e ? atoi(e) : 256; return (u32)(v < 64 ? 64 : (v > 4096 ? 4096 : v)); }
+[[maybe_unused]] static u32 remap_block() { const char* e = getenv("AC_REMAP_BLOCK"); int v = e ? atoi(e) : 4096; v = v < 64 ? 64 : (v > 65536 ? 65536 : v); return (u32)(v & ~63); }
+[[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 3 ? 3 : v); }
+[[maybe_unused]] static int insert_variant() { static int v = [] { const char* e = getenv("AC_INSERT_VARIANT"); return e ? atoi(e) : 0; }(); return v; }
+[[maybe_unused]] static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
+[[maybe_unused]] static u64 wave_chunk_rest() { const char* e = getenv("AC_INSERT_CHUNK_REST"); u64 x = e ? (u64)atoll(e) : 4096; return (std::max<u64>(x, 256) + 63) & ~63ULL; }   // longest chunk of the one-launch rest
+[[maybe_unused]] static bool insert_adaptive() { const char* e = getenv("AC_INSERT_ADAPT"); return e ? atoi(e) != 0 : true; }
+[[maybe_unused]] static u64 insert_growth() { const char* e = getenv("AC_INSERT_GROWTH"); long x = e ? atol(e) : 2; return (u64)(x < 2 ? 2 : x); }      // phase i+1 ends at growth x the end of phase i
+[[maybe_unused]] static u64 insert_waves_target() { const char* e = getenv("AC_INSERT_WAVES"); long x = e ? atol(e) : 16384; return (u64)(x < 1024 ? 1024 : x); }   // wavefronts a long phase is cut into
 
 // A text resident in HBM with its sequence table and its 2-bit packing.
 struct PackedText {

@@ -273,10 +273,13 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 //   AC_PATH_FILTER    1 (default): the walk keeps smallest positions only for unitig sides that can become expand_repeats
 //                     destinations (paths stage 1.35 -> 1.25 ms).
 //   AC_REMAP_BLOCK    path entries per wavefront in the final renumbering.
+//   AC_SEQ_LAYOUT     1 = the two sequence writers (K12, materialise) interleave the bytes of a wavefront; default 0 until measured.
 //   AC_INSERT_CHUNK / AC_INSERT_GROWTH / AC_INSERT_WAVES   insert phases: longest wavefront chunk, prefix growth factor, wavefronts per phase;
 //   AC_INSERT_ADAPT (default 1) / AC_INSERT_CHUNK_REST      redundant text: everything after the second phase in one launch, and its longest chunk.
 [[maybe_unused]] static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : 1; }
 [[maybe_unused]] static bool path_filter() { const char* e = getenv("AC_PATH_FILTER"); return e ? atoi(e) != 0 : true; }   // smallest positions only for possible expand_repeats destinations
+[[maybe_unused]] static int seq_layout() { const char* e = getenv("AC_SEQ_LAYOUT"); return e ? (atoi(e) != 0 ? 1 : 0) : 0; }      // 1 = interleaved byte ownership in the two sequence writers (not measured yet)
+[[maybe_unused]] static u64 seq_threads(u64 total) { return seq_layout() ? ((total + 4095) / 4096) * 64 : (total + 63) / 64; }
 [[maybe_unused]] static int path_diag() { const char* e = getenv("AC_PATH_DIAG"); return e ? (atoi(e) & 3) : 0; }      // measurement only: the result is wrong when set
 [[maybe_unused]] static u32 path_chunk() { const char* e = getenv("AC_PATH_CHUNK"); int v = e ? atoi(e) : 256; return (u32)(v < 64 ? 64 : (v > 4096 ? 4096 : v)); }
 [[maybe_unused]] static u32 remap_block() { const char* e = getenv("AC_REMAP_BLOCK"); int v = e ? atoi(e) : 4096; v = v < 64 ? 64 : (v > 65536 ? 65536 : v); return (u32)(v & ~63); }
@@ -661,8 +664,8 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     // K12 sequences
     u64 total = N;   // sum of unitig lengths == number of distinct canonical k-mers
     DBuf<u8> useq(total);
-    launch((total + 63) / 64, SeqFunctor{g.bits.ptr(), useq_off.ptr(), ustartpos.ptr(), ulen.ptr(), uorient.ptr(), U, total,
-                                         (int)(k / 2), useq.ptr()});
+    launch(seq_threads(total), SeqFunctor{g.bits.ptr(), useq_off.ptr(), ustartpos.ptr(), ulen.ptr(), uorient.ptr(), U, total,
+                                         (int)(k / 2), useq.ptr(), seq_layout()});
     lap(&tm->seqs);
 
     // K13 link push order, K14 static analysis for expand_repeats, K15 first renumber_unitigs
@@ -752,7 +755,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                 launch((u64)U + 1, ExpLenFunctor{e, len64.ptr(), U});
                 exclusive_scan_u64(len64.ptr(), noff.ptr(), (u64)U + 1);
                 final_total = read_scalar(noff.ptr() + U);
-                launch((final_total + 63) / 64, MaterializeFunctor{e, noff.ptr(), U, final_total, alt});
+                launch(seq_threads(final_total), MaterializeFunctor{e, noff.ptr(), U, final_total, alt, seq_layout()});
                 launch(U, ExpResetFunctor{e, noff.ptr()});
                 std::swap(cur, alt);
                 e.cur = cur;

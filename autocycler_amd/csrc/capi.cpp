@@ -67,9 +67,19 @@ static void select_device(int device) {
     AC_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         throw DeviceError(std::string("device is ") + prop.gcnArchName + "; this library is built for gfx950 only");
-#else
-    (void)device;
 #endif
+    // The device arena is one process-wide bump allocator: its blocks live on the device they were allocated on.  A call that
+    // names another ordinal gives them back first (a build never runs on HBM of another device), together with everything else
+    // that is tied to the previous device's memory.  One build at a time per process (g_build_mutex), so nothing is in flight.
+    static int arena_device = -1;
+    if (arena_device != device) {
+        if (arena_device >= 0) {
+            if (g_live_shards) throw DeviceError("a sharded build is in flight on device " + std::to_string(arena_device) + ": this process cannot use device " + std::to_string(device) + " until it is freed");
+            Arena::device().release_all();
+            Arena::pinned_host().release_all();
+        }
+        arena_device = device;
+    }
 }
 
 static void validate(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs) {
@@ -108,6 +118,7 @@ int ac_release_memory(void) {
         Arena::device().release_all();
         Arena::pinned_host().release_all();
         PinnedPool::get().trim();
+        release_host_stager();
     });
 }
 uint32_t ac_max_kmer(void) { int m = max_supported_k(); return (uint32_t)(m % 2 ? m : m - 1); }
@@ -639,31 +650,26 @@ int ac_compress_dir(const char* assemblies_dir, const char* autocycler_dir, uint
                 throw DeviceError(g_err);
         } else {
             const uint32_t n = (uint32_t)s.views.size();
-            if (n == 0) throw DeviceError("no sequences found in input assemblies");
-            std::vector<SeqView> v(n);
-            std::vector<uint16_t> ids(n);
-            for (uint32_t i = 0; i < n; i++) { v[i] = SeqView{s.views[i].fwd, s.views[i].length}; ids[i] = s.views[i].id; }
-            std::vector<uint64_t> off; std::vector<uint32_t> len; std::vector<uint16_t> d1, d2;
-            std::vector<uint8_t> text = layout_text(v, k, &off, &len, &d1, &d2);
+            validate(k, s.views.data(), n);
+            std::lock_guard<std::mutex> lock(g_build_mutex);
+            if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
             select_device(device);
-#ifdef AC_EMU
-            struct DevText { void* p = nullptr; ~DevText() { free(p); } } dt;
-            dt.p = malloc(text.size());
-            if (!dt.p) throw DeviceError("out of memory");
-            memcpy(dt.p, text.data(), text.size());
-#else
-            struct DevText { void* p = nullptr; ~DevText() { if (p) (void)hipFree(p); } } dt;
-            AC_HIP_CHECK(hipMalloc(&dt.p, text.size()));
-            AC_HIP_CHECK(hipMemcpy(dt.p, text.data(), text.size(), hipMemcpyHostToDevice));
-#endif
-            double secs = 0;
-            if (ac_end_repair_device(k, dt.p, text.size(), off.data(), len.data(), d1.data(), d2.data(), n, device, &secs, nullptr) != 0)
-                throw DeviceError(g_err);
-            s.lr.repair_seconds = now() - t0;        // H2D of the text + the repair itself
+            auto h = std::make_unique<ac_graph>();
+            std::vector<SeqView> v(n);
+            for (uint32_t i = 0; i < n; i++) {
+                v[i] = SeqView{s.views[i].fwd, s.views[i].length};
+                h->seq_ids.push_back(s.views[i].id);
+                h->seq_lens.push_back(s.views[i].length);
+            }
+            // pinned-ring upload of the padded sequences -> end repair in place on the device text -> pack + build from the same buffer
+            GraphBuilder b(k);
+            b.set_sequences_host(v, /*pack_now=*/false);
+            RepairTimings rt;
+            b.repair_ends(&rt);
+            s.lr.repair_seconds = now() - t0;        // upload of the text + the repair itself
             t0 = now();
-            if (ac_compress_build_device(k, s.lr.assembly_count, dt.p, text.size(), off.data(), len.data(), ids.data(), d1.data(), d2.data(),
-                                         n, device, &g) != 0)
-                throw DeviceError(g_err);
+            build_graph(b, s.lr.assembly_count, h.get());
+            g = h.release();
         }
         std::unique_ptr<ac_graph> guard(g);
         double t1 = now();

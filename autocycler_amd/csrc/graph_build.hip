@@ -18,6 +18,8 @@
 #include <map>
 #include <string>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 
 #include "device_rt.hpp"
 
@@ -287,6 +289,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static int insert_variant() { static int v = [] { const char* e = getenv("AC_INSERT_VARIANT"); return e ? atoi(e) : 0; }(); return v; }
 [[maybe_unused]] static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
 [[maybe_unused]] static u64 wave_chunk_rest() { const char* e = getenv("AC_INSERT_CHUNK_REST"); u64 x = e ? (u64)atoll(e) : 4096; return (std::max<u64>(x, 256) + 63) & ~63ULL; }   // longest chunk of the one-launch rest
+[[maybe_unused]] static u64 upload_threads() { const char* e = getenv("AC_UPLOAD_THREADS"); long x = e ? atol(e) : 8; return (u64)(x < 1 ? 1 : (x > 64 ? 64 : x)); }   // host threads filling the pinned staging ring
 [[maybe_unused]] static bool insert_adaptive() { const char* e = getenv("AC_INSERT_ADAPT"); return e ? atoi(e) != 0 : true; }
 [[maybe_unused]] static u64 insert_growth() { const char* e = getenv("AC_INSERT_GROWTH"); long x = e ? atol(e) : 2; return (u64)(x < 2 ? 2 : x); }      // phase i+1 ends at growth x the end of phase i
 [[maybe_unused]] static u64 insert_waves_target() { const char* e = getenv("AC_INSERT_WAVES"); long x = e ? atol(e) : 16384; return (u64)(x < 1024 ? 1024 : x); }   // wavefronts a long phase is cut into
@@ -317,12 +320,18 @@ struct PackedText {
         stream_sync();
     }
     TextCtx ctx(int k) const { return TextCtx{bits.ptr(), mask.ptr(), n_text, k, seq_off.ptr(), seq_len.ptr(), seq_d1.ptr(), seq_d2.ptr(), n_seqs}; }
-    void pack() {   // K1
+    bool packed = false;      // the host entry packs chunk by chunk behind the upload (set_sequences_host)
+    void pack_alloc(stream_t s = 0) {
         u64 n_bits_words = n_text / 32 + 24, n_mask_words = n_text / 64 + 12;   // slack for W <= 16 key words
         bits.alloc(n_bits_words); mask.alloc(n_mask_words);
-        bits.fill_bytes(0);
-        mask.fill_bytes(0xFF);
-        launch((n_text + 31) / 32, PackFunctor{d_text, n_text, bits.ptr(), (u32*)mask.ptr()});
+        bits.fill_bytes(0, s);
+        mask.fill_bytes(0xFF, s);
+    }
+    void pack() {   // K1
+        if (packed) return;
+        pack_alloc();
+        launch((n_text + 31) / 32, PackFunctor{d_text, n_text, bits.ptr(), (u32*)mask.ptr(), 0});
+        packed = true;
     }
 };
 
@@ -391,7 +400,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
     if (&pt == &uni && distinct_upper) c = next_pow2(std::max<u64>(1024, distinct_upper * 10 / 7 + 4096));   // no retry: an upper bound is known
     // the capacity the previous build of a text of this very size ended with (a process that builds the same job again, or a
     // stream of similar jobs, does not pay for the overflow retries twice)
-    static u64 memo_n_text = 0, memo_cap = 0; static u32 memo_k = 0;
+    static u64 memo_n_text = 0, memo_cap = 0; static u32 memo_k = 0;      // (a capacity is a number, not memory: valid on any device)
     if (pt.n_text == memo_n_text && k == memo_k && memo_cap > c) c = memo_cap;
     if (c > next_pow2(pt.n_bases * 2 + 1024)) c = next_pow2(pt.n_bases * 2 + 1024);
     const u64 c_default = c;
@@ -890,7 +899,7 @@ void device_warmup(int device) {
     AC_HIP_CHECK(hipSetDevice(device));
     void* p = nullptr;
     AC_HIP_CHECK(hipMalloc(&p, 4096));
-    hipLaunchKernelGGL(functor_kernel<PackFunctor>, dim3(1), dim3(256), 0, 0, (u64)1, PackFunctor{(const u8*)p, 32, (u64*)((u8*)p + 1024), (u32*)((u8*)p + 2048)});
+    hipLaunchKernelGGL(functor_kernel<PackFunctor>, dim3(1), dim3(256), 0, 0, (u64)1, PackFunctor{(const u8*)p, 32, (u64*)((u8*)p + 1024), (u32*)((u8*)p + 2048), 0});
     (void)hipDeviceSynchronize();
     (void)hipFree(p);
 #else
@@ -913,17 +922,177 @@ GraphBuilder::~GraphBuilder() { delete impl_; }
 uint64_t GraphBuilder::n_text() const { return impl_->loc.n_text; }
 uint64_t GraphBuilder::n_bases() const { return impl_->loc.n_bases; }
 
-void GraphBuilder::set_sequences_host(const std::vector<SeqView>& seqs) {
-    double t0 = now_s();
-    std::vector<uint64_t> off; std::vector<uint32_t> len; std::vector<uint16_t> d1, d2;
-    std::vector<uint8_t> text = layout_text(seqs, impl_->k, &off, &len, &d1, &d2);
-    impl_->loc.n_text = text.size();
-    Arena::device().reserve(arena_estimate(text.size(), true));
-    impl_->text_owned.alloc(text.size());
-    copy_h2d(impl_->text_owned.ptr(), text.data(), text.size());
-    impl_->loc.d_text = impl_->text_owned.ptr();
-    impl_->loc.set_table(off, len, d1, d2);
-    tm_.h2d = now_s() - t0;
+// ---- host entry: sequences in the caller's (pageable) memory -> text + packed text in HBM ----------------------------------
+// What `ac_compress_build` gets is what compress.rs:41 holds: one heap buffer per Sequence.  A plain hipMemcpy from such memory
+// runs at 3 GB/s the first time the runtime sees the pages (it pins them on the fly; measured 158-196 ms for the 487 MB of config
+// C, tools/microbench/h2d_probe.hip), against 55-57 GB/s from pinned memory.  So the text layout ('$' + padded sequence + '$' ...)
+// is written chunk by chunk into a persistent ring of pinned staging slots by a few host threads (memcpy: 25 GB/s per thread,
+// 126 GB/s with eight), every filled slot goes out with one asynchronous copy on an upload stream, and K1 packs that chunk on the
+// same stream right behind its copy — the PCIe link never waits, and the build that follows finds bits / mask ready.
+class HostStager {
+  public:
+    static const size_t SLOT = (size_t)16 << 20;     // 16 MB per copy: the SDMA path reaches 55 GB/s from 16 MB up (1-4 MB: 25-37 GB/s)
+    static const int NS = 12;
+    static HostStager& get() { static HostStager s; return s; }
+    void ensure() {
+#ifndef AC_EMU
+        int dev = 0;
+        AC_HIP_CHECK(hipGetDevice(&dev));
+        if (ring_ && dev == dev_) return;
+        if (created_) { (void)hipStreamDestroy(s_); for (auto& e : ev_) (void)hipEventDestroy(e); (void)hipEventDestroy(done_); created_ = false; }
+        if (!ring_) AC_HIP_CHECK(hipHostMalloc((void**)&ring_, SLOT * NS, hipHostMallocDefault));
+        AC_HIP_CHECK(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
+        for (auto& e : ev_) AC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        AC_HIP_CHECK(hipEventCreateWithFlags(&done_, hipEventDisableTiming));
+        created_ = true; dev_ = dev;
+#else
+        if (!ring_) ring_ = (u8*)malloc(SLOT * NS);
+#endif
+    }
+    void release() {
+#ifndef AC_EMU
+        if (ring_) (void)hipHostFree(ring_);
+#else
+        free(ring_);
+#endif
+        ring_ = nullptr;
+    }
+    u8* slot(int i) { return ring_ + (size_t)i * SLOT; }
+#ifndef AC_EMU
+    hipStream_t stream() { return s_; }
+    hipEvent_t& event(int i) { return ev_[i]; }
+    hipEvent_t& done() { return done_; }
+#else
+    stream_t stream() { return 0; }
+#endif
+  private:
+    HostStager() {}
+    u8* ring_ = nullptr;
+    bool created_ = false;
+    int dev_ = -1;
+#ifndef AC_EMU
+    hipStream_t s_ = nullptr;
+    hipEvent_t ev_[NS];
+    hipEvent_t done_;
+#endif
+};
+void release_host_stager() { HostStager::get().release(); }
+
+// Bytes [b, e) of the text layout of `seqs` (off[i] = first padded byte of sequence i; every padded sequence is followed by '$').
+static void fill_text_range(const std::vector<SeqView>& seqs, const std::vector<uint64_t>& off, uint32_t k, u64 b, u64 e, u8* dst) {
+    // first sequence whose span [off, off + plen] (the '$' after it included) ends after b
+    size_t lo = 0, hi = seqs.size();
+    while (lo < hi) { size_t mid = (lo + hi) / 2; if (off[mid] + (u64)seqs[mid].length + k - 1 + 1 <= b) lo = mid + 1; else hi = mid; }
+    u64 p = b;
+    if (p == 0 && p < e) { dst[0] = '$'; p = 1; }
+    for (size_t i = lo; i < seqs.size() && p < e; i++) {
+        const u64 s0 = off[i], plen = (u64)seqs[i].length + k - 1;
+        if (p < s0 + plen) {
+            const u64 from = p - s0, n = std::min(e, s0 + plen) - p;
+            memcpy(dst + (p - b), seqs[i].fwd + from, n);
+            p += n;
+        }
+        if (p == s0 + plen && p < e) { dst[p - b] = '$'; p++; }
+    }
+}
+
+void GraphBuilder::set_sequences_host(const std::vector<SeqView>& seqs, bool pack_now) {
+    const double t0 = now_s();
+    const uint32_t k = impl_->k;
+    const size_t S = seqs.size();
+    std::vector<uint64_t> off(S); std::vector<uint32_t> len(S); std::vector<uint16_t> d1(S), d2(S);
+    u64 n = 1;
+    for (size_t i = 0; i < S; i++) {
+        const u64 plen = (u64)seqs[i].length + k - 1;
+        off[i] = n; len[i] = seqs[i].length;
+        u16 a = 0, b = 0;
+        while (a < plen && seqs[i].fwd[a] == '.') a++;
+        while (b < plen && seqs[i].fwd[plen - 1 - b] == '.') b++;
+        d1[i] = a; d2[i] = b;
+        n += plen + 1;
+    }
+    PackedText& loc = impl_->loc;
+    loc.n_text = n;
+    Arena::device().reserve(arena_estimate(n, true));
+    impl_->text_owned.alloc(n + 64);
+    loc.d_text = impl_->text_owned.ptr();
+    loc.set_table(off, len, d1, d2);
+    HostStager& st = HostStager::get();
+    st.ensure();
+    const u64 C = HostStager::SLOT;
+    const u64 n_chunks = (n + C - 1) / C;
+    u8* const d_text = impl_->text_owned.ptr();
+#ifdef AC_EMU
+    if (pack_now) loc.pack_alloc();
+    for (u64 c = 0; c < n_chunks; c++) {
+        const u64 b = c * C, e = std::min(n, b + C);
+        fill_text_range(seqs, off, k, b, e, st.slot(0));
+        memcpy(d_text + b, st.slot(0), e - b);
+        if (pack_now) launch((e - b + 31) / 32, PackFunctor{d_text, n, loc.bits.ptr(), (u32*)loc.mask.ptr(), b / 32});
+    }
+#else
+    int dev = 0;
+    AC_HIP_CHECK(hipGetDevice(&dev));
+    hipStream_t up = st.stream();
+    {   // the upload stream starts after whatever stream 0 still has in flight on these buffers (the table copies above), and the
+        hipEvent_t& e0 = st.done();      // fills of bits / mask go first on it
+        AC_HIP_CHECK(hipEventRecord(e0, 0));
+        AC_HIP_CHECK(hipStreamWaitEvent(up, e0, 0));
+    }
+    if (pack_now) loc.pack_alloc(up);
+    std::atomic<u64> next{0};
+    std::vector<std::atomic<u64>> issued(HostStager::NS);
+    for (auto& x : issued) x.store(0);
+    std::mutex hip_mu;
+    std::string fail;
+    std::atomic<bool> stop{false};
+    auto worker = [&] {
+        try {
+            AC_HIP_CHECK(hipSetDevice(dev));
+            for (u64 c; (c = next.fetch_add(1)) < n_chunks;) {
+                const int sl = (int)(c % HostStager::NS);
+                if (c >= (u64)HostStager::NS) {      // the slot's previous chunk must have left it
+                    while (issued[sl].load(std::memory_order_acquire) != c - HostStager::NS + 1 && !stop.load()) std::this_thread::yield();
+                    if (stop.load()) break;
+                    AC_HIP_CHECK(hipEventSynchronize(st.event(sl)));
+                }
+                const u64 b = c * C, e = std::min(n, b + C);
+                fill_text_range(seqs, off, k, b, e, st.slot(sl));
+                {
+                    std::lock_guard<std::mutex> lock(hip_mu);
+                    AC_HIP_CHECK(hipMemcpyAsync(d_text + b, st.slot(sl), e - b, hipMemcpyHostToDevice, up));
+                    if (pack_now) launch((e - b + 31) / 32, PackFunctor{d_text, n, loc.bits.ptr(), (u32*)loc.mask.ptr(), b / 32}, up);
+                    AC_HIP_CHECK(hipEventRecord(st.event(sl), up));
+                }
+                issued[sl].store(c + 1, std::memory_order_release);
+            }
+        } catch (const std::exception& ex) {
+            std::lock_guard<std::mutex> lock(hip_mu);
+            if (fail.empty()) fail = ex.what();
+            next.store(n_chunks);      // no more chunks, and nobody keeps waiting for a slot
+            stop.store(true);
+        }
+    };
+    const int T = (int)std::min<u64>(n_chunks, upload_threads());
+    std::vector<std::thread> pool;
+    for (int i = 1; i < T; i++) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+    if (!fail.empty()) { (void)hipStreamSynchronize(up); throw DeviceError(fail); }
+    // the build (stream 0) starts when the last chunk is packed; the caller's buffers are no longer referenced from here on
+    AC_HIP_CHECK(hipEventRecord(st.done(), up));
+    AC_HIP_CHECK(hipStreamWaitEvent(0, st.done(), 0));
+#endif
+    loc.packed = pack_now;
+    tm_.h2d = now_s() - t0;      // host side of the pipeline (the last copies may still be in flight: the build's first sync absorbs them)
+}
+void GraphBuilder::repair_ends(RepairTimings* tm) {
+    PackedText& loc = impl_->loc;
+    if (!impl_->text_owned.ptr() || loc.packed) throw DeviceError("repair_ends: needs the unpacked text of set_sequences_host(seqs, false)");
+    std::vector<uint64_t> off = loc.h_off; std::vector<uint32_t> len = loc.h_len;
+    std::vector<uint16_t> d1(off.size()), d2(off.size());
+    end_repair_device(impl_->k, impl_->text_owned.ptr(), loc.n_text, off, len, &d1, &d2, tm, /*reset_arena=*/false);
+    loc.set_table(off, len, d1, d2);
 }
 void GraphBuilder::set_text_device(const uint8_t* d_text, uint64_t n_text, const std::vector<uint64_t>& off,
                                    const std::vector<uint32_t>& len, const std::vector<uint16_t>& d1,

@@ -40,12 +40,20 @@ struct BuildTimings {                   // seconds; device stages are bracketed 
     uint64_t n_local_distinct = 0, n_fragments = 0, fragment_bytes = 0;
 };
 
+// sequence_end_repair (compress.rs:202-270) on the device.  d_text: the PADDED, unrepaired sequences in the text layout below;
+// it is patched in place and d1 / d2 (surviving dots) are updated.
+struct RepairTimings { double total = 0, scan_ms = 0; uint64_t hits = 0, matches = 0; uint32_t patterns = 0; };
+
 class GraphBuilder {
   public:
     explicit GraphBuilder(uint32_t k);
     ~GraphBuilder();
-    // Host entry: lays the sequences out as one text ('$' separators), copies it to the device.
-    void set_sequences_host(const std::vector<SeqView>& seqs);
+    // Host entry: lays the sequences out as one text ('$' separators) chunk by chunk in a pinned staging ring and streams it to
+    // the device; pack_now: K1 packs every chunk right behind its copy (the sequences are final, i.e. end-repaired already).
+    void set_sequences_host(const std::vector<SeqView>& seqs, bool pack_now = true);
+    // sequence_end_repair (compress.rs:202-270) on the text set_sequences_host(seqs, false) uploaded: patches it in place and
+    // updates the surviving-dot counts; the build then packs the repaired text.
+    void repair_ends(RepairTimings* tm);
     // Device entry: `d_text` is an ASCII text already resident in HBM with the same layout:
     // text[0] = '$', then for each sequence its padded bytes followed by one '$'.
     // off[s] = index of the first padded byte of sequence s.  d1/d2 = leading/trailing dot counts.
@@ -99,11 +107,8 @@ class GraphBuilder {
 std::vector<uint8_t> layout_text(const std::vector<SeqView>& seqs, uint32_t k, std::vector<uint64_t>* off,
                                  std::vector<uint32_t>* len, std::vector<uint16_t>* d1, std::vector<uint16_t>* d2);
 
-// sequence_end_repair (compress.rs:202-270) on the device.  d_text: the PADDED, unrepaired sequences in the text layout above;
-// it is patched in place and d1 / d2 (surviving dots) are updated.
-struct RepairTimings { double total = 0, scan_ms = 0; uint64_t hits = 0, matches = 0; uint32_t patterns = 0; };
 void end_repair_device(uint32_t k, uint8_t* d_text, uint64_t n_text, const std::vector<uint64_t>& off, const std::vector<uint32_t>& len,
-                       std::vector<uint16_t>* d1, std::vector<uint16_t>* d2, RepairTimings* tm);
+                       std::vector<uint16_t>* d1, std::vector<uint16_t>* d2, RepairTimings* tm, bool reset_arena = true);
 
 // pairwise_contig_distances (cluster.rs:132-157) on the final graph: out[a * n_seqs + b], sequences in path order.
 void pairwise_distances_device(const FinalGraph& g, uint32_t n_seqs, double* out);
@@ -114,6 +119,9 @@ void random_access_ceilings(double* cas_gops, double* read_gops);
 // Brings the HIP context and this library's code objects up on `device` (first use costs ~0.2 s): callable from a helper
 // thread while the caller is still busy on the host.
 void device_warmup(int device);
+
+// Frees the pinned staging ring of the host entry (192 MB; it otherwise stays for the next build of the process).
+void release_host_stager();
 
 int max_supported_k();
 void set_stage_timing(bool on);   // per-stage timers (a stream sync per stage); off by default

@@ -74,6 +74,50 @@ def make_assemblies(n_assemblies, genome=5_000_000, plasmid=100_000, sub=1e-4, i
     return out
 
 
+def make_mixed_species(n_species, n_strains, genome=5_000_000, plasmid=100_000, strain_div=1e-2, sub=1e-4, indel=1e-5, seed=77_000):
+    """BASELINE.json configs[4] model ("E"): n_species unrelated roots; every assembly is one strain of its
+    species = the root with substitutions at rate strain_div, then the per-assembly noise (sub, indel), rotation, strand flip and
+    plasmid loss of make_assemblies.  Assembly i = species i // n_strains, strain i % n_strains (file names sort in that order)."""
+    out = []
+    for sp in range(n_species):
+        chrom, plas = _root(np.random.default_rng(seed + 1_000_003 * (sp + 1)), genome, plasmid)
+        for st in range(n_strains):
+            rng = np.random.default_rng(seed + sp * n_strains + st)
+            contigs = []
+            c = _place(rng, _mutate(rng, _mutate(rng, chrom, strain_div, 0.0), sub, indel))
+            contigs.append((f"contig_1 length={len(c)} circular=true", c))
+            if plas is not None and rng.random() < 0.75:
+                p = _place(rng, _mutate(rng, _mutate(rng, plas, strain_div, 0.0), sub, indel))
+                contigs.append((f"contig_2 length={len(p)} circular=true", p))
+            out.append(contigs)
+    return out
+
+
+# Named workloads: the BASELINE.json configurations (or their scaled replicas) that tests/golden/*.json hold oracle results for.
+# name -> (k, number of assemblies, generator)
+WORKLOADS = {
+    "configB_k51": (51, 12, lambda: make_assemblies(12, genome=5_000_000, plasmid=100_000, sub=1e-4, indel=1e-5, seed=51_000)),
+    "configC_k51": (51, 96, lambda: make_assemblies(96, genome=5_000_000, plasmid=100_000, sub=1e-4, indel=1e-5, seed=51_000)),
+    "configDprime_k101": (101, 24, lambda: make_assemblies(24, genome=10_000_000, plasmid=100_000, sub=1e-4, indel=1e-5, seed=51_000)),
+    "configD_k101": (101, 24, lambda: make_assemblies(24, genome=100_000_000, plasmid=0, sub=1e-4, indel=1e-5, seed=101_000)),
+    # E' = scaled replica of configs[4] (1000 x 5 Mbp, 25 species x 40 strains): 5 species x 20 strains = 100 assemblies of ~1 Mbp,
+    # strains 1 % apart.  The genome is 1 Mbp instead of 5 because the oracle keeps the reference's per-k-mer heap records
+    # (kmer_graph.rs:36-41) and nearly every k-mer of such an input is distinct: 100 x 5 Mbp would need several hundred GB.
+    "configEprime_k51": (51, 100, lambda: make_mixed_species(5, 20, genome=1_000_000, plasmid=20_000, strain_div=1e-2, sub=1e-4, indel=1e-5, seed=77_000)),
+    # mini-E: 2 species x 40 strains x 5 Mbp — configs[4]'s per-GPU shape at N = 8 is 125 assemblies; no oracle golden (memory)
+    "configEmini_k51": (51, 80, lambda: make_mixed_species(2, 40, genome=5_000_000, plasmid=100_000, strain_div=1e-2, sub=1e-4, indel=1e-5, seed=77_000)),
+}
+
+
+def flatten(assemblies):
+    """-> (sequences as uint8 arrays, file names, headers) in the order `compress` numbers them."""
+    seqs, fn, hd = [], [], []
+    for i, contigs in enumerate(assemblies):
+        for header, s in contigs:
+            seqs.append(np.ascontiguousarray(s)); fn.append(f"assembly_{i:04d}.fasta"); hd.append(header)
+    return seqs, fn, hd
+
+
 def write_fasta_dir(assemblies, out_dir):
     """Single-line records (so decompress reproduces the files byte-for-byte, tests.rs:122-127)."""
     from pathlib import Path

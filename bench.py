@@ -2,10 +2,20 @@
 """Benchmark of the `autocycler compress` hot path on MI355X.
 
 Metric (BASELINE.json): Mbp/s through compress -> unitig graph (k=51), workload config C = 96 x ~5 Mbp synthetic
-assemblies on one GPU.  A "step" is one full pass of the replaced region (compress.rs:42-44): padded,
-end-repaired sequences resident in HBM -> final unitig graph (segments, links in L-line order, paths) resident in
-host RAM, including the order-dependent host tail.  Input generation, padding and end repair happen before
-the timed region (they are upstream of the seam).
+assemblies on one GPU.  A "step" is one full pass of the replaced region (compress.rs:42-44).  Three brackets are timed in
+the same run and printed in the same JSON line:
+
+  value / ms_per_step   padded, end-repaired sequences RESIDENT IN HBM -> final unitig graph (segments, links in L-line
+                        order, paths) in host RAM: `ac_compress_build_device` (the bench contract: inputs in HBM when the
+                        timed region starts; PCIe-inclusive rates are never `value`)
+  t_hot                 the same region as the Rust shim sees it: sequences in (pageable) HOST RAM -> final graph in host
+                        RAM through `ac_compress_build`, i.e. including the pinned-ring upload of the text (H2D) and the D2H
+                        of the results — T_hot of SURVEY.md 8(d); same number of steps, same barriers
+  t_e2e                 the whole command (compress.rs:34 -> :49): FASTA directory -> input_assemblies.gfa / .yaml through
+                        `ac_compress_dir` in this (warm) process, and through the `autocycler-compress` CLI in a fresh process
+                        (HIP context creation and code-object load included)
+plus cold_first_build_ms, the first build of this process (arena, pinned pools, code objects).  Input generation happens
+before all of them.
 
     python bench.py [--gpus N --steps K --warmup W] [--assemblies 96 --genome 5000000 --kmer 51]
 
@@ -30,6 +40,21 @@ sys.path.insert(0, str(ROOT))
 
 A_K = lambda k: 1 + 2 * (8 * ((2 * k + 63) // 64) + 8)   # algorithmic bytes per input bp
 HBM_PEAK = 8.0e12
+
+
+def workload_label(args, k):
+    """Which BASELINE.json configuration (if any) the arguments describe."""
+    key = (args.assemblies, args.genome, k)
+    std_noise = (args.sub, args.indel) == (1e-4, 1e-5)
+    if std_noise and args.plasmid == 100_000 and key == (96, 5_000_000, 51):
+        return "BASELINE.json configs[2]"
+    if std_noise and args.plasmid == 100_000 and key == (12, 5_000_000, 51):
+        return "BASELINE.json configs[1]"
+    if std_noise and key == (24, 100_000_000, 101):
+        return "BASELINE.json configs[3] on ONE GPU"
+    if std_noise and key == (24, 10_000_000, 101):
+        return "D' (scaled replica of BASELINE.json configs[3])"
+    return "custom workload (no BASELINE.json configuration)"
 
 
 def make_inputs(args, rank, sharded_job):
@@ -103,6 +128,8 @@ def main():
     ap.add_argument("--indel", type=float, default=1e-5)
     ap.add_argument("--kmer", type=int, default=51)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-bracket", action="store_true", help="skip the T_hot bracket (host RAM -> host RAM through ac_compress_build)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the whole-command bracket (FASTA directory -> GFA/YAML)")
     ap.add_argument("--cpu-sample", type=str, default="4x1000000")
     ap.add_argument("--mode", choices=["auto", "single", "sharded", "independent"], default="auto",
                     help="auto: single-device build at N=1, one sharded job at N>1")
@@ -229,8 +256,12 @@ def main():
 
     # One-time initialisation outside both the warmup and the timed region: the first two builds of a process load
     # the code objects, create the pinned result pool and the copy stream (60-180 ms and ~20 ms instead of ~9 ms).
-    for _ in range(args.init_builds):
+    cold_first_build_ms = None
+    for i in range(args.init_builds):
+        tc = time.perf_counter()
         step().close()
+        if i == 0:
+            cold_first_build_ms = (time.perf_counter() - tc) * 1e3
     if os.environ.get("BENCH_STAGE_TIMING"):      # experiment: keep the per-stage syncs inside the timed loop
         lib.ac_set_stage_timing(C.c_int(1))
     for _ in range(args.warmup):
@@ -258,6 +289,104 @@ def main():
         stage_tms.append(g.timings())
     lib.ac_set_stage_timing(C.c_int(0))
     barrier()
+
+    # ---- T_hot: the same sequences in host RAM -> final graph in host RAM through ac_compress_build ------------
+    t_hot = None
+    if world == 1 and mode == "single" and not args.no_host_bracket:
+        import hashlib
+        # what the Rust caller holds at compress.rs:41: the padded, end-repaired forward sequences in ordinary (pageable) host
+        # memory — here the repaired device text read back, one view per sequence
+        text_host = d_text.cpu().numpy() if not emu_lib else text
+        hviews = (_capi.SeqView * n)()
+        base_addr = text_host.ctypes.data
+        for i in range(n):
+            hviews[i].fwd = C.cast(C.c_void_p(base_addr + off[i]), C.c_char_p)
+            hviews[i].length = lens[i]
+            hviews[i].id = ids[i]
+
+        def step_host():
+            h = C.c_void_p()
+            if lib.ac_compress_build(C.c_uint32(k), C.c_uint32(args.assemblies), hviews, C.c_uint32(n), C.c_int(local_rank), C.byref(h)):
+                raise RuntimeError(lib.ac_last_error().decode())
+            return _capi.Graph(lib, h, n)
+
+        md5_dev = hashlib.md5(g.gfa(fn, hd).encode()).hexdigest()
+        tc = time.perf_counter()
+        gh = step_host()
+        first_host_ms = (time.perf_counter() - tc) * 1e3      # allocates the pinned staging ring
+        md5_host = hashlib.md5(gh.gfa(fn, hd).encode()).hexdigest()
+        if md5_host != md5_dev:
+            raise SystemExit(f"host entry and device entry built different graphs: {md5_host} != {md5_dev}")
+        gh.close()
+        for _ in range(max(args.warmup, 1)):
+            step_host().close()
+        barrier()
+        th0 = time.perf_counter()
+        hs, hup = [], []
+        gh = None
+        for _ in range(args.steps):
+            ts = time.perf_counter()
+            if gh is not None:
+                gh.close()
+            gh = step_host()
+            hs.append(time.perf_counter() - ts)
+            hup.append(gh.timings()["h2d"])
+        barrier()
+        e_hot = time.perf_counter() - th0
+        gh.close()
+        t_hot = {"value": bases / 1e6 / (e_hot / args.steps), "unit": "Mbp/s", "ms_per_step": e_hot / args.steps * 1e3, "steps": args.steps,
+                 "timed_region": "padded+repaired sequences in pageable host RAM (one buffer per sequence view) -> final unitig graph in host "
+                                 "RAM through ac_compress_build: pinned-ring upload (8 host threads, 16 MB copies) with K1 packing each chunk "
+                                 "behind its copy, device build, D2H of the results",
+                 "step_ms": {"min": min(hs) * 1e3, "median": sorted(hs)[len(hs) // 2] * 1e3, "max": max(hs) * 1e3},
+                 "upload_ms": sum(hup) / len(hup) * 1e3, "upload_GBps": n_text / (sum(hup) / len(hup)) / 1e9,
+                 "first_call_ms": first_host_ms, "gfa_md5": md5_host, "same_graph_as_device_entry": True}
+        del text_host
+
+    # ---- T_e2e: the whole command on a FASTA directory (compress.rs:34 -> :49) -----------------------------------------------------
+    t_e2e = None
+    if world == 1 and mode == "single" and not args.no_e2e and not emu_lib:
+        import hashlib
+        import shutil
+        import subprocess
+        import tempfile
+        from autocycler_amd import synth
+        tmp = Path(tempfile.mkdtemp(prefix="ac_bench_e2e_", dir="/dev/shm" if Path("/dev/shm").is_dir() else None))
+        try:
+            synth.write_fasta_dir(synth.make_assemblies(args.assemblies, genome=args.genome, plasmid=args.plasmid, sub=args.sub, indel=args.indel,
+                                                        seed=51_000), tmp / "in")
+            fasta_bytes = sum(f.stat().st_size for f in (tmp / "in").iterdir())
+            threads = min(os.cpu_count() or 8, 32)
+            runs = []
+            for r in range(3):
+                shutil.rmtree(tmp / "out", ignore_errors=True)
+                times = (C.c_double * 4)()
+                tc = time.perf_counter()
+                if lib.ac_compress_dir(str(tmp / "in").encode(), str(tmp / "out").encode(), C.c_uint32(k), C.c_uint32(25), C.c_int(threads),
+                                       C.c_int(local_rank), None, times):
+                    raise RuntimeError(lib.ac_last_error().decode())
+                runs.append({"wall_s": time.perf_counter() - tc, "load_s": times[0], "upload_and_end_repair_s": times[1], "graph_s": times[2], "write_s": times[3]})
+            md5_e2e = hashlib.md5((tmp / "out" / "input_assemblies.gfa").read_bytes()).hexdigest()
+            best = min(runs, key=lambda x: x["wall_s"])
+            t_e2e = {"value": bases / 1e6 / best["wall_s"], "unit": "Mbp/s", **best, "runs_wall_s": [round(x["wall_s"], 4) for x in runs],
+                     "what": f"ac_compress_dir in this (warm) process: {args.assemblies} FASTA files ({fasta_bytes / 1e6:.0f} MB, tmpfs) -> "
+                             f"input_assemblies.gfa + .yaml, {threads} host threads for load and GFA formatting; best of 3",
+                     "gfa_md5": md5_e2e}
+            cli = ROOT / "autocycler_amd" / "autocycler-compress"
+            if cli.exists():      # the same command as a fresh process: HIP context creation and code-object load included
+                shutil.rmtree(tmp / "out", ignore_errors=True)
+                tc = time.perf_counter()
+                pr = subprocess.run([str(cli), "compress", "-i", str(tmp / "in"), "-a", str(tmp / "out"), "--kmer", str(k), "-t", str(threads),
+                                     "--device", str(local_rank)], capture_output=True, text=True)
+                wall = time.perf_counter() - tc
+                if pr.returncode == 0:
+                    t_e2e["cli_fresh_process"] = {"wall_s": wall, "value": bases / 1e6 / wall,
+                                                  "gfa_md5": hashlib.md5((tmp / "out" / "input_assemblies.gfa").read_bytes()).hexdigest(),
+                                                  "stage_line": next((l for l in pr.stderr.splitlines() if l.startswith("Stage times")), "")}
+                else:
+                    t_e2e["cli_fresh_process"] = {"error": pr.stderr[-300:]}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -329,13 +458,15 @@ def main():
             "dtype": "u64", "data": "synthetic" if not emu_lib else "emulation dry run (not a measurement)",
             "config": {"workload": f"{args.assemblies} x ~{args.genome / 1e6:g} Mbp synthetic assemblies per GPU (+plasmid {args.plasmid} bp, "
                                    f"sub {args.sub:g}, indel {args.indel:g}), k={k}, " +
-                                   ("1 species; BASELINE.json configs[2]" if world == 1 else
+                                   (f"1 species; {workload_label(args, k)}" if world == 1 else
                                     (f"ONE job of {world} species, one per GPU (mixed-species job as in BASELINE.json configs[4]; rank 0 holds "
                                      "exactly the N=1 workload, configs[2])" if (mode == "sharded" and args.species == "per-gpu") else
                                      f"ONE job of {world * args.assemblies} assemblies of one species" if mode == "sharded" else
                                      f"{world} unrelated jobs of one species each")),
                        "bases_per_gpu": bases, "sequences_per_gpu": n, "mode": mode, "sharding": sharding,
-                       "timed_region": "padded+repaired sequences in HBM -> final unitig graph in host RAM (device build + host tail)"},
+                       "timed_region": "padded+repaired sequences in HBM -> final unitig graph in host RAM (ac_compress_build_device: device build "
+                                       "+ D2H); the host-RAM -> host-RAM bracket of the same region (H2D included, SURVEY.md 8d T_hot) is `t_hot`, the "
+                                       "whole command `t_e2e`"},
             "roofline": {"bound": "hbm", "kernel": "insert_wave_kernel<W> (wavefront-cooperative run-following k-mer insert; %d phase launches per build)" % tms[-1]["insert_launches"],
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                          "traffic": traffic, "traffic_source": traffic_src,
@@ -347,6 +478,7 @@ def main():
                                  "the kernel is bound by hash-table atomics and random slot reads, not by streaming bandwidth",
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": ins_ms,
                          "whole_path_frac": alg_bytes / (elapsed / args.steps) / HBM_PEAK},
+            "t_hot": t_hot, "t_e2e": t_e2e, "cold_first_build_ms": cold_first_build_ms,
             "total_device_timed_ms": sum(t["total_device"] for t in tms) / len(tms) * 1e3,
             "step_ms_list": [round(x * 1e3, 2) for x in step_s],
             "step_ms": {"min": min(step_s) * 1e3, "median": sorted(step_s)[len(step_s) // 2] * 1e3, "max": max(step_s) * 1e3},

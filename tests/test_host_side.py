@@ -244,6 +244,11 @@ def test_bench_line_contract_single_rank_dry_run():
     assert [o["kernel"] for o in j["roofline_other"]] == ["PathWalkFunctor", "DegreeFunctor"]
     assert j["cpu_baseline_full_size"]["gfa_md5"] == "c28d41ea9e4784f5f1dd06da6b3eb587"
     assert "dry run" in j["data"]
+    # the host-RAM -> host-RAM bracket of the same region (SURVEY.md 8d T_hot), timed in the same run through ac_compress_build
+    for key in ("value", "ms_per_step", "timed_region", "upload_ms", "gfa_md5"):
+        assert key in j["t_hot"], key
+    assert j["t_hot"]["same_graph_as_device_entry"] is True and j["t_hot"]["steps"] == 2
+    assert j["cold_first_build_ms"] > 0 and "configs[2]" not in j["config"]["workload"]      # 3 x 30 kbp is not a BASELINE configuration
 
 
 def test_bench_line_two_ranks_dry_run():

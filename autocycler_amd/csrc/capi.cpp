@@ -539,6 +539,7 @@ int ac_timings_get(const ac_graph* g, ac_timings* o) {
     o->analysis = t.analysis; o->finalize = t.finalize;
     o->fragments = t.fragments; o->union_pack = t.union_pack; o->union_insert = t.union_insert;
     o->n_local_distinct = t.n_local_distinct; o->n_fragments = t.n_fragments; o->fragment_bytes = t.fragment_bytes;
+    o->upload_device_ms = t.upload_device_ms;
     return 0;
 }
 void ac_free(ac_graph* g) { delete g; }

@@ -939,11 +939,19 @@ class HostStager {
         int dev = 0;
         AC_HIP_CHECK(hipGetDevice(&dev));
         if (ring_ && dev == dev_) return;
-        if (created_) { (void)hipStreamDestroy(s_); for (auto& e : ev_) (void)hipEventDestroy(e); (void)hipEventDestroy(done_); created_ = false; }
+        if (created_) {
+            (void)hipStreamDestroy(s_); (void)hipStreamDestroy(pk_);
+            for (auto& e : ev_) (void)hipEventDestroy(e);
+            (void)hipEventDestroy(done_); (void)hipEventDestroy(begin_); (void)hipEventDestroy(copied_);
+            created_ = false;
+        }
         if (!ring_) AC_HIP_CHECK(hipHostMalloc((void**)&ring_, SLOT * NS, hipHostMallocDefault));
         AC_HIP_CHECK(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
+        AC_HIP_CHECK(hipStreamCreateWithFlags(&pk_, hipStreamNonBlocking));
         for (auto& e : ev_) AC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        AC_HIP_CHECK(hipEventCreateWithFlags(&done_, hipEventDisableTiming));
+        AC_HIP_CHECK(hipEventCreate(&done_));
+        AC_HIP_CHECK(hipEventCreate(&begin_));
+        AC_HIP_CHECK(hipEventCreateWithFlags(&copied_, hipEventDisableTiming));
         created_ = true; dev_ = dev;
 #else
         if (!ring_) ring_ = (u8*)malloc(SLOT * NS);
@@ -959,9 +967,13 @@ class HostStager {
     }
     u8* slot(int i) { return ring_ + (size_t)i * SLOT; }
 #ifndef AC_EMU
-    hipStream_t stream() { return s_; }
+    hipStream_t stream() { return s_; }            // the copies, back to back
+    hipStream_t pack_stream() { return pk_; }      // K1 on each chunk, behind its copy (a kernel between two copies of ONE stream idles the link)
     hipEvent_t& event(int i) { return ev_[i]; }
     hipEvent_t& done() { return done_; }
+    hipEvent_t& begin() { return begin_; }
+    hipEvent_t& copied() { return copied_; }
+    bool timed = false;                            // begin / done bracket an upload whose duration has not been read yet
 #else
     stream_t stream() { return 0; }
 #endif
@@ -971,9 +983,9 @@ class HostStager {
     bool created_ = false;
     int dev_ = -1;
 #ifndef AC_EMU
-    hipStream_t s_ = nullptr;
+    hipStream_t s_ = nullptr, pk_ = nullptr;
     hipEvent_t ev_[NS];
-    hipEvent_t done_;
+    hipEvent_t done_, begin_, copied_;
 #endif
 };
 void release_host_stager() { HostStager::get().release(); }
@@ -1033,13 +1045,13 @@ void GraphBuilder::set_sequences_host(const std::vector<SeqView>& seqs, bool pac
 #else
     int dev = 0;
     AC_HIP_CHECK(hipGetDevice(&dev));
-    hipStream_t up = st.stream();
-    {   // the upload stream starts after whatever stream 0 still has in flight on these buffers (the table copies above), and the
-        hipEvent_t& e0 = st.done();      // fills of bits / mask go first on it
-        AC_HIP_CHECK(hipEventRecord(e0, 0));
-        AC_HIP_CHECK(hipStreamWaitEvent(up, e0, 0));
+    hipStream_t up = st.stream(), pk = st.pack_stream();
+    {   // both streams start after whatever stream 0 still has in flight (the table copies above); the fills of bits / mask go
+        AC_HIP_CHECK(hipEventRecord(st.begin(), 0));      // first on the pack stream
+        AC_HIP_CHECK(hipStreamWaitEvent(up, st.begin(), 0));
+        AC_HIP_CHECK(hipStreamWaitEvent(pk, st.begin(), 0));
     }
-    if (pack_now) loc.pack_alloc(up);
+    if (pack_now) loc.pack_alloc(pk);
     std::atomic<u64> next{0};
     std::vector<std::atomic<u64>> issued(HostStager::NS);
     for (auto& x : issued) x.store(0);
@@ -1061,8 +1073,11 @@ void GraphBuilder::set_sequences_host(const std::vector<SeqView>& seqs, bool pac
                 {
                     std::lock_guard<std::mutex> lock(hip_mu);
                     AC_HIP_CHECK(hipMemcpyAsync(d_text + b, st.slot(sl), e - b, hipMemcpyHostToDevice, up));
-                    if (pack_now) launch((e - b + 31) / 32, PackFunctor{d_text, n, loc.bits.ptr(), (u32*)loc.mask.ptr(), b / 32}, up);
                     AC_HIP_CHECK(hipEventRecord(st.event(sl), up));
+                    if (pack_now) {
+                        AC_HIP_CHECK(hipStreamWaitEvent(pk, st.event(sl), 0));
+                        launch((e - b + 31) / 32, PackFunctor{d_text, n, loc.bits.ptr(), (u32*)loc.mask.ptr(), b / 32}, pk);
+                    }
                 }
                 issued[sl].store(c + 1, std::memory_order_release);
             }
@@ -1078,10 +1093,14 @@ void GraphBuilder::set_sequences_host(const std::vector<SeqView>& seqs, bool pac
     for (int i = 1; i < T; i++) pool.emplace_back(worker);
     worker();
     for (auto& t : pool) t.join();
-    if (!fail.empty()) { (void)hipStreamSynchronize(up); throw DeviceError(fail); }
-    // the build (stream 0) starts when the last chunk is packed; the caller's buffers are no longer referenced from here on
-    AC_HIP_CHECK(hipEventRecord(st.done(), up));
+    if (!fail.empty()) { (void)hipStreamSynchronize(up); (void)hipStreamSynchronize(pk); throw DeviceError(fail); }
+    // the build (stream 0) starts when the last chunk has landed and is packed; the caller's buffers are no longer referenced
+    // from here on (every fill has been copied into the ring)
+    AC_HIP_CHECK(hipEventRecord(st.copied(), up));
+    AC_HIP_CHECK(hipStreamWaitEvent(pk, st.copied(), 0));
+    AC_HIP_CHECK(hipEventRecord(st.done(), pk));
     AC_HIP_CHECK(hipStreamWaitEvent(0, st.done(), 0));
+    st.timed = true;
 #endif
     loc.packed = pack_now;
     tm_.h2d = now_s() - t0;      // host side of the pipeline (the last copies may still be in flight: the build's first sync absorbs them)
@@ -1130,6 +1149,13 @@ void GraphBuilder::build(uint32_t assembly_count_hint, FinalGraph* out) {
     AC_DISPATCH_W(unitigs, (*impl_))
     AC_DISPATCH_W(walk, (*impl_))
     AC_DISPATCH_W(tail, (*impl_, out, true, true))
+#ifndef AC_EMU
+    if (HostStager::get().timed) {      // host entry: first copy issued -> last chunk packed, on the device's clock
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, HostStager::get().begin(), HostStager::get().done()) == hipSuccess) tm_.upload_device_ms = ms;
+        HostStager::get().timed = false;
+    }
+#endif
 }
 
 // ---- sharded build (one compress job over several devices; the collectives between the phases belong to the

@@ -38,6 +38,7 @@ struct BuildTimings {                   // seconds; device stages are bracketed 
     double fragments = 0;               // novel runs of this rank -> fragment text
     double union_pack = 0, union_insert = 0;   // packing / inserting the union of all ranks' fragments
     uint64_t n_local_distinct = 0, n_fragments = 0, fragment_bytes = 0;
+    double upload_device_ms = 0;        // host entry: first copy issued -> last chunk landed and packed (HIP events)
 };
 
 // sequence_end_repair (compress.rs:202-270) on the device.  d_text: the PADDED, unrepaired sequences in the text layout below;

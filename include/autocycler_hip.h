@@ -62,6 +62,7 @@ typedef struct {
     double fragments;           /* cutting this rank's novel runs out of its text */
     double union_pack, union_insert;   /* packing / inserting the union of all ranks' fragments */
     uint64_t n_local_distinct, n_fragments, fragment_bytes;
+    double upload_device_ms;    /* ac_compress_build only: first H2D copy issued -> last chunk landed and packed (HIP events) */
 } ac_timings;
 
 /* Replaces compress.rs:42-44.  k: --kmer (odd).  assembly_count: the reference's capacity hint

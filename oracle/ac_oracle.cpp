@@ -155,6 +155,12 @@ void KmerGraph::add_sequences(const std::vector<Sequence>& seqs, size_t assembly
     for (auto& s : seqs) add_sequence(s, assembly_count);
 }
 void KmerGraph::add_sequence(const Sequence& seq, size_t assembly_count) {
+    // The reference pre-sizes every k-mer's occurrence vector (Vec::with_capacity(assembly_count), kmer_graph.rs:40): a pure
+    // capacity hint, 8 x assembly_count bytes per distinct k-mer.  On diverse inputs (config E': nearly every k-mer distinct,
+    // 100 assemblies) that alone is ~70 GB, so ORACLE_NO_POSITION_RESERVE=1 lets the vectors grow on demand instead — same
+    // contents, same output (tests/test_oracle_kats.py::test_position_reserve_is_only_a_hint compares both).
+    static const bool no_reserve = getenv("ORACLE_NO_POSITION_RESERVE") != nullptr;
+    if (no_reserve) assembly_count = 0;
     size_t k = k_size, half_k = k_size / 2, two_half_k = half_k + half_k;
     const char* fraw = seq.forward_seq.data();
     const char* rraw = seq.reverse_seq.data();

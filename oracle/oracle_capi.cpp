@@ -348,4 +348,24 @@ int orc_pairwise_distances(const char* gfa, double* out, uint32_t* n_seqs) {
     });
 }
 
+// position.rs:18-46 + unitig_graph.rs:151-174: the forward / reverse positions of every unitig as from_gfa_lines rebuilds them
+// from the P lines.  One line per unitig: "number\tF id,strand,pos;...\tR id,strand,pos;..." in vector order.
+int orc_gfa_positions(const char* gfa, char** out) {
+    return guarded([&] {
+        auto [g, seqs] = UnitigGraph::from_gfa_lines(split_lines(gfa));
+        (void)seqs;
+        std::ostringstream os;
+        for (auto& u : g.unitigs) {
+            os << u->number;
+            for (int fwd = 1; fwd >= 0; fwd--) {
+                os << (fwd ? "\tF" : "\tR");
+                const auto& v = fwd ? u->forward_positions : u->reverse_positions;
+                for (size_t i = 0; i < v.size(); i++) os << (i ? ";" : " ") << v[i].seq_id() << "," << (v[i].strand() ? 1 : 0) << "," << v[i].pos;
+            }
+            os << "\n";
+        }
+        *out = dup_str(os.str());
+    });
+}
+
 }  // extern "C"

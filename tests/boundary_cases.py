@@ -1,0 +1,107 @@
+"""Boundary pieces of the C ABI that are not the graph build itself, as test bodies shared by the CPU suite (the serial emulation of
+the kernels, tests/test_emu_boundary.py) and the device suite (libautocycler_hip.so on the MI355X, tests/test_gpu_boundary.py):
+`Position` accessors (position.rs:18-46), the whole command `ac_compress_dir` / `autocycler-compress` on the reference's five-file
+fixture set (tests.rs:131-148; flags main.rs:140-160), and `ac_decompress` on a GFA the library has just built (decompress.rs:83-105)."""
+import ctypes as C
+import gzip
+import subprocess
+from pathlib import Path
+
+import oracle_lib as O
+import parity_util
+import seqgen
+from autocycler_amd import _capi
+from test_oracle_kats import FIXED
+
+ROOT = Path(__file__).resolve().parent.parent
+FIVE = [("a.fasta", "a"), ("b.fna", "b"), ("c.fa", "c"), ("d.fasta.gz", "d"), ("e.fna.gz", "e")]      # tests.rs:133-142
+
+
+def positions_match_the_oracle(lib_path, cases):
+    """ac_unitig_positions == the forward / reverse positions from_gfa_lines rebuilds (unitig_graph.rs:151-174), vector order included."""
+    checked = 0
+    for k, seqs, fn, hd in cases:
+        g, gfa, loaded = parity_util.check_case(k, seqs, fn, hd, lib_path=lib_path)
+        want = O.gfa_positions(gfa)
+        assert len(want) == g.unitig_count
+        for i in range(g.unitig_count):
+            for fwd in (True, False):
+                got = g.positions(i, fwd)
+                assert got == want[i + 1][0 if fwd else 1], (k, i, fwd)
+                checked += len(got)
+        # Position invariants (position.rs:24-46): every occurrence on one strand implies the mirrored one on the other strand
+        lens = {q["id"]: q["length"] for q in loaded}
+        for i in range(g.unitig_count):
+            n = len(g.unitig(i)[0])
+            mirrored = sorted((sid, not strand, lens[sid] - n - pos) for sid, strand, pos in g.positions(i, True))
+            assert mirrored == sorted(g.positions(i, False)), i
+    assert checked > 0
+
+
+def write_five_file_fixture(d):
+    """The reference's five fixed sequences (tests.rs:133-142) as the five kinds of assembly file find_all_assemblies accepts."""
+    d.mkdir(parents=True, exist_ok=True)
+    for name, key in FIVE:
+        body = f">{key}\n{FIXED[key]}\n".encode()
+        (d / name).write_bytes(gzip.compress(body) if name.endswith(".gz") else body)
+
+
+def compress_dir_matches_the_oracle(lib, tmp_path, k, device=0):
+    """compress.rs:32-50 on the five-file fixture: same GFA bytes and the same YAML as the oracle's whole-command restatement;
+    then `ac_decompress` of that very GFA gives the input files back (tests.rs:114-127)."""
+    src = tmp_path / "asm"
+    write_five_file_fixture(src)
+    out_o, out_p = tmp_path / "o", tmp_path / "p"
+    O.compress_dir(src, out_o, k=k)
+    times = (C.c_double * 4)()
+    rc = lib.ac_compress_dir(str(src).encode(), str(out_p).encode(), C.c_uint32(k), C.c_uint32(25), C.c_int(4), C.c_int(device), None, times)
+    assert rc == 0, lib.ac_last_error()
+    assert (out_p / "input_assemblies.gfa").read_bytes() == (out_o / "input_assemblies.gfa").read_bytes()
+    assert (out_p / "input_assemblies.yaml").read_text() == (out_o / "input_assemblies.yaml").read_text()
+    dec = tmp_path / "dec"
+    assert lib.ac_decompress(str(out_p / "input_assemblies.gfa").encode(), str(dec).encode(), None, C.c_int(3)) == 0, lib.ac_last_error()
+    for name, key in FIVE:
+        got = (dec / name).read_bytes()
+        assert (gzip.decompress(got) if name.endswith(".gz") else got) == f">{key}\n{FIXED[key]}\n".encode()
+    return out_o
+
+
+def cli_matches_the_oracle(tmp_path, k):
+    """The `autocycler-compress` binary (flag surface of main.rs:140-160) on the same fixture, as a fresh process."""
+    cli = ROOT / "autocycler_amd" / "autocycler-compress"
+    assert cli.exists(), "build the product first (make -C autocycler_amd/csrc)"
+    src = tmp_path / "asm_cli"
+    write_five_file_fixture(src)
+    out_o, out_c = tmp_path / "o_cli", tmp_path / "c_cli"
+    O.compress_dir(src, out_o, k=k)
+    pr = subprocess.run([str(cli), "compress", "--assemblies_dir", str(src), "--autocycler_dir", str(out_c), "--kmer", str(k), "--threads", "2"],
+                        capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    assert (out_c / "input_assemblies.gfa").read_bytes() == (out_o / "input_assemblies.gfa").read_bytes()
+    assert (out_c / "input_assemblies.yaml").read_text() == (out_o / "input_assemblies.yaml").read_text()
+    assert "unitigs" in pr.stderr and "Graph contains" in pr.stderr          # the statistics compress.rs:152,165,177 prints
+    dec = tmp_path / "dec_cli"
+    pr = subprocess.run([str(cli), "decompress", "-i", str(out_c / "input_assemblies.gfa"), "-o", str(dec)], capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    for name, key in FIVE:
+        got = (dec / name).read_bytes()
+        assert (gzip.decompress(got) if name.endswith(".gz") else got) == f">{key}\n{FIXED[key]}\n".encode()
+    # user errors leave through exit code 1 with the reference's message shape (misc.rs:131-137)
+    pr = subprocess.run([str(cli), "compress", "-i", str(tmp_path / "nowhere"), "-a", str(out_c)], capture_output=True, text=True, timeout=60)
+    assert pr.returncode == 1 and "Error: directory does not exist" in pr.stderr
+
+
+def two_device_ordinals(lib_path):
+    """the process-wide device arena belongs to the device of the previous call; a call that names another ordinal
+    must not run on its blocks.  (The emulation ignores the ordinal itself but runs the same release path.)"""
+    k = 21
+    seqs, fn, hd = seqgen.make_case(4, k)
+    g0, gfa0, _ = parity_util.check_case(k, seqs, fn, hd, lib_path=lib_path, device=0)
+    lib = _capi.load_library(lib_path)
+    n_dev = lib.ac_device_count()
+    other = 1 if (n_dev == 0 or n_dev > 1) else None      # emulation (0 devices): any ordinal; one GPU: nothing else to name
+    if other is not None:
+        g1, gfa1, _ = parity_util.check_case(k, seqs, fn, hd, lib_path=lib_path, device=other)
+        assert gfa1 == gfa0
+    g2, gfa2, _ = parity_util.check_case(k, seqs, fn, hd, lib_path=lib_path, device=0)
+    assert gfa2 == gfa0 and g0.stats_post == g2.stats_post

@@ -107,6 +107,16 @@ def decompress(gfa):
     return [tuple(l.split("\t")) for l in _str_call(lib().orc_decompress, _b(gfa)).splitlines()]
 
 
+def gfa_positions(gfa):
+    """unitig_graph.rs:151-174: {number: (forward positions, reverse positions)}, each a list of (seq_id, strand, pos) in vector order."""
+    out = {}
+    for line in _str_call(lib().orc_gfa_positions, _b(gfa)).splitlines():
+        num, f, r = line.split("\t")
+        parse = lambda x: [tuple(int(v) for v in p.split(",")) for p in x[2:].split(";")] if len(x) > 2 else []
+        out[int(num)] = ([(a, bool(b), c) for a, b, c in parse(f)], [(a, bool(b), c) for a, b, c in parse(r)])
+    return out
+
+
 def pairwise_distances(gfa):
     """cluster.rs:132-157 on a GFA text -> S x S list of lists (row a, column b)."""
     n = C.c_uint32()

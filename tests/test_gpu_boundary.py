@@ -1,0 +1,62 @@
+"""tests/boundary_cases.py on the MI355X: the boundary pieces the round-1 device suite did not reach."""
+import pytest
+
+import boundary_cases as B
+import seqgen
+from test_oracle_kats import FIXED
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import autocycler_amd
+    lib = autocycler_amd.load_library()       # raises HipLibraryMissing: the product has no fallback
+    assert lib.ac_device_count() >= 1, "no HIP device visible"
+    return lib
+
+
+def test_positions(lib):
+    from test_gpu_parity import _synth_case
+    cases = [(k, *seqgen.make_case(seed, k)) for k, seed in ((5, 1), (9, 2), (21, 5), (51, 7), (51, 13), (101, 3))]
+    cases.append((13, [FIXED[c] for c in "abcde"], [f for f, _ in B.FIVE], list("abcde")))
+    cases.append((51, *_synth_case(6, 60_000, 3_000, 1e-3, 1e-4, 99)))
+    B.positions_match_the_oracle(None, cases)
+
+
+def test_fixed_seqs_k1(lib):      # tests.rs:131-148 runs k = 1 as well
+    import parity_util
+    parity_util.check_case(1, [FIXED[c] for c in "abcde"], [f for f, _ in B.FIVE], list("abcde"))
+
+
+@pytest.mark.parametrize("k", [13, 51])
+def test_compress_dir_five_file_fixture(lib, tmp_path, k):
+    B.compress_dir_matches_the_oracle(lib, tmp_path, k)
+
+
+@pytest.mark.parametrize("k", [13, 51])
+def test_cli_five_file_fixture(lib, tmp_path, k):
+    B.cli_matches_the_oracle(tmp_path, k)
+
+
+def test_two_device_ordinals(lib):
+    B.two_device_ordinals(None)
+
+
+def test_decompress_a_device_built_graph(lib, tmp_path):
+    """ac_decompress_seq on the handle ac_compress_build returned (no GFA in between) and ac_decompress on the GFA file written
+    from it: both reproduce every input sequence (unitig_graph.rs:362-388, decompress.rs:83-105)."""
+    import ctypes as C
+    import parity_util
+    from test_gpu_parity import _synth_case
+    seqs, fn, hd = _synth_case(6, 60_000, 3_000, 1e-3, 1e-4, 99)
+    g, gfa, loaded = parity_util.check_case(51, seqs, fn, hd)
+    from autocycler_amd import graph_from_gfa
+    g2, fns, hds = graph_from_gfa(gfa)
+    assert [g2.decompress(i).decode() for i in range(len(seqs))] == seqs
+    p = tmp_path / "input_assemblies.gfa"
+    p.write_text(gfa)
+    one = tmp_path / "all.fasta"
+    assert lib.ac_decompress(str(p).encode(), None, str(one).encode(), C.c_int(4)) == 0, lib.ac_last_error()
+    want = "".join(f">{f}__{h}\n{s}\n" for f, h, s in sorted(zip(fn, hd, seqs), key=lambda x: x[0]))
+    assert one.read_text() == want

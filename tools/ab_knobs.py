@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--genome", type=int, default=5_000_000)
     ap.add_argument("--kmer", type=int, default=51)
     ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--host-entry", action="store_true", help="build through ac_compress_build from host views (the T_hot bracket: upload included)")
+    ap.add_argument("--workload", type=str, default=None, help="a named workload of autocycler_amd.synth.WORKLOADS (overrides --assemblies/--genome/--kmer)")
     ap.add_argument("--emu", action="store_true", help="dry run of this script on the CPU emulation (tests/_emu), small sizes only")
     ap.add_argument("--variants", type=str, default="base;AC_TABLE_SHIFT=0,AC_MINKEY_VARIANT=0;AC_TABLE_SHIFT=2;base")
     args = ap.parse_args()
@@ -45,7 +47,11 @@ def main():
     k = args.kmer
     ns = argparse.Namespace(assemblies=args.assemblies, genome=args.genome, plasmid=100_000, sub=1e-4, indel=1e-5, species="per-gpu")
     t0 = time.time()
-    seqs, fn, hd = bench.make_inputs(ns, 0, False)
+    if args.workload:
+        k, args.assemblies, gen = synth.WORKLOADS[args.workload]
+        seqs, fn, hd = synth.flatten(gen())
+    else:
+        seqs, fn, hd = bench.make_inputs(ns, 0, False)
     h_seqs = bench.prepare(lib, k, seqs, fn, hd, args.assemblies, threads=os.cpu_count() or 1, repair=0)
     del seqs
     n = lib.ac_seqs_count(h_seqs)
@@ -69,8 +75,21 @@ def main():
         raise RuntimeError(lib.ac_last_error().decode())
     print(json.dumps({"prep_s": time.time() - t0, "bases": bases, "sequences": n, "repair_matches": nm.value}), flush=True)
 
+    hviews = None
+    if args.host_entry:      # the repaired text back in pageable host memory, one view per sequence (what the Rust caller holds)
+        if hip is not None:
+            assert hip.hipMemcpy(text.ctypes.data_as(C.c_void_p), d_text, C.c_size_t(n_text), C.c_int(2)) == 0
+        hviews = (_capi.SeqView * n)()
+        for i in range(n):
+            hviews[i].fwd = C.cast(C.c_void_p(text.ctypes.data + off[i]), C.c_char_p)
+            hviews[i].length = lens[i]; hviews[i].id = ids[i]
+
     def build():
         h = C.c_void_p()
+        if hviews is not None:
+            if lib.ac_compress_build(C.c_uint32(k), C.c_uint32(args.assemblies), hviews, C.c_uint32(n), C.c_int(0), C.byref(h)):
+                raise RuntimeError(lib.ac_last_error().decode())
+            return _capi.Graph(lib, h, n)
         if lib.ac_compress_build_device(C.c_uint32(k), C.c_uint32(args.assemblies), d_text, C.c_uint64(n_text), off, lens, ids, d1, d2,
                                         C.c_uint32(n), C.c_int(0), C.byref(h)):
             raise RuntimeError(lib.ac_last_error().decode())
@@ -97,11 +116,13 @@ def main():
                 hip.hipDeviceSynchronize()
             ts = []
             ins = []
+            upl = []
             for _ in range(args.steps):
                 t1 = time.perf_counter()
                 g = build()
                 ts.append((time.perf_counter() - t1) * 1e3)
                 ins.append(g.timings()["insert_kernel_ms"])
+                upl.append((g.timings()["upload_device_ms"], g.timings()["h2d"] * 1e3, g.timings()["total_device"] * 1e3))
                 g.close()
             lib.ac_set_stage_timing(C.c_int(1))
             g = build()
@@ -113,6 +134,8 @@ def main():
             ts_sorted = sorted(ts)
             print(json.dumps({"variant": variant, "ms_median": ts_sorted[len(ts) // 2], "ms_min": ts_sorted[0], "ms_mean": sum(ts) / len(ts),
                               "Mbp_s_median": bases / 1e3 / ts_sorted[len(ts) // 2], "insert_kernel_ms": sum(ins) / len(ins),
+                              **({"upload_device_ms": sorted(u[0] for u in upl)[len(upl) // 2], "upload_host_side_ms": sorted(u[1] for u in upl)[len(upl) // 2],
+                                  "build_ms": sorted(u[2] for u in upl)[len(upl) // 2]} if hviews is not None else {}),
                               "stages_ms": {a: round(b * 1e3, 3) for a, b in tm.items() if isinstance(b, float) and b > 2e-5 and a != "insert_kernel_ms"},
                               "table_capacity": tm["table_capacity"], "insert_launches": tm["insert_launches"], "unitigs": st["unitigs"], "gfa_md5": dg}), flush=True)
         except Exception as e:      # a variant that fails must not take the others with it

@@ -41,7 +41,8 @@ typedef int stream_t;
 // ---- atomics --------------------------------------------------------------------------------------
 #ifdef AC_EMU
 inline u64 atomic_cas64(u64* p, u64 expected, u64 desired) { u64 old = *p; if (old == expected) *p = desired; return old; }
-inline void atomic_min64(u64* p, u64 v) { if (v < *p) *p = v; }
+inline u64 atomic_min64(u64* p, u64 v) { u64 o = *p; if (v < o) *p = v; return o; }
+inline void atomic_xor64(u64* p, u64 v) { *p ^= v; }
 inline u32 atomic_add32(u32* p, u32 v) { u32 o = *p; *p += v; return o; }
 inline u64 atomic_add64(u64* p, u64 v) { u64 o = *p; *p += v; return o; }
 inline void atomic_or32(u32* p, u32 v) { *p |= v; }
@@ -51,7 +52,8 @@ inline void atomic_max32(u32* p, u32 v) { if (v > *p) *p = v; }
 __device__ inline u64 atomic_cas64(u64* p, u64 expected, u64 desired) {
     return (u64)atomicCAS((unsigned long long*)p, (unsigned long long)expected, (unsigned long long)desired);
 }
-__device__ inline void atomic_min64(u64* p, u64 v) { atomicMin((unsigned long long*)p, (unsigned long long)v); }
+__device__ inline u64 atomic_min64(u64* p, u64 v) { return (u64)atomicMin((unsigned long long*)p, (unsigned long long)v); }
+__device__ inline void atomic_xor64(u64* p, u64 v) { atomicXor((unsigned long long*)p, (unsigned long long)v); }
 __device__ inline u32 atomic_add32(u32* p, u32 v) { return atomicAdd(p, v); }
 __device__ inline u64 atomic_add64(u64* p, u64 v) { return (u64)atomicAdd((unsigned long long*)p, (unsigned long long)v); }
 __device__ inline void atomic_or32(u32* p, u32 v) { atomicOr(p, v); }

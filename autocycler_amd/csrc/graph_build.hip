@@ -71,6 +71,8 @@ struct Table {
     const u64* occ;   // optional (lookups after the insert): bit s set <=> slot s is occupied.  2 MB for 16 M slots, so it
                       // stays in L2 and answers the majority of the lookups of ABSENT k-mers (their first slot is empty
                       // with probability 1 - load) without touching the table, which only lives in the Infinity Cache
+    u64* novel;       // during the insert only: bit p toggles when p becomes / stops being the position a slot holds, so that at
+                      // the end of the insert bit p is set <=> p is the smallest occurrence of its canonical k-mer
 };
 
 // Largest s with off[s] <= p; valid iff p is a k-mer start of that sequence.
@@ -175,23 +177,36 @@ static const u64 NOREF = ~0ULL;
 // taken on them stays valid; claiming is decided by the CAS alone.
 // Returns the position q < p of an EARLIER occurrence of the same canonical k-mer if the slot showed one
 // (*same = it reads in the same orientation as the occurrence at p), else NOREF.
+// *mine_now = p has just become the position its slot holds (claimed an empty slot, or lowered a larger position): the
+// caller toggles bit p of the novel bitmap (a wavefront does it for its 64 lanes with one 64-bit atomic); the bit of a
+// position this call displaced is toggled here.  Every position becomes the slot value at most once and is displaced at most
+// once, and XOR commutes, so whatever order the atomics land in, the bitmap ends with exactly the final slot positions set.
 template <int W> AC_D u64 table_insert(const TextCtx& t, const Table& tb, const Key<W>& ukey, bool isdot, bool flipped, u64 p,
-                                       u32* claimed, u32* err, bool* same) {
+                                       u32* claimed, u32* err, bool* same, bool* mine_now) {
     u64 h = key_hash<W>(ukey);
     u64 mine = slot_make(h, isdot, p);
     u64 s = h & tb.cap_mask;
+    *mine_now = false;
     for (int probes = 0; probes < MAX_PROBES_INSERT; probes++) {
         u64 v = tb.slots[s];
         if (v == SLOT_EMPTY) {
             u64 old = atomic_cas64(&tb.slots[s], SLOT_EMPTY, mine);
-            if (old == SLOT_EMPTY) { (*claimed)++; return NOREF; }
+            if (old == SLOT_EMPTY) { (*claimed)++; *mine_now = true; return NOREF; }
             v = old;
         }
         if (slot_tag_eq(v, mine)) {
             if (slot_pos(v) == p) return NOREF;
             int m = claimant_match<W>(t, v, ukey);
             if (m) {
-                if (slot_pos(v) > p) { atomic_min64(&tb.slots[s], mine); return NOREF; }
+                if (slot_pos(v) > p) {
+                    u64 old = atomic_min64(&tb.slots[s], mine);      // the same key's word: tag and isdot agree, positions order it
+                    if (old > mine) {
+                        *mine_now = true;
+                        u64 q = slot_pos(old);
+                        atomic_xor64(&tb.novel[q >> 6], 1ULL << (q & 63));
+                    }
+                    return NOREF;
+                }
                 *same = ((m == 2) == flipped);
                 return slot_pos(v);
             }
@@ -263,8 +278,6 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 // Device memory one build of an n_text-byte text needs, roughly: packed text + bitmaps (~0.6 B/position), staging slots
 // of the path walk (4 B/position), k-mer table and per-k-mer arrays (sized by distinct content), unitig-sized buffers.
 [[maybe_unused]] static size_t arena_estimate(u64 n_text, bool owns_text) { return (size_t)n_text * (owns_text ? 8 : 7) + ((size_t)768 << 20); }
-// Tuning knobs of the insert (environment, read once): AC_INSERT_VARIANT=1 selects the thread-per-chunk kernel,
-// AC_INSERT_CHUNK the largest wavefront chunk (positions).
 // Tuning knobs, read on every build so that one process can compare settings (tools/ab_knobs.py; measurements in
 // profiles/r03*_ab_knobs_configC.jsonl):
 //   AC_TABLE_SHIFT    k-mer table capacity = 2^n x the reference-style sizing.  Default 1 (load factor ~0.23 instead of ~0.46 on
@@ -286,10 +299,10 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static u32 path_chunk() { const char* e = getenv("AC_PATH_CHUNK"); int v = e ? atoi(e) : 256; return (u32)(v < 64 ? 64 : (v > 4096 ? 4096 : v)); }
 [[maybe_unused]] static u32 remap_block() { const char* e = getenv("AC_REMAP_BLOCK"); int v = e ? atoi(e) : 4096; v = v < 64 ? 64 : (v > 65536 ? 65536 : v); return (u32)(v & ~63); }
 [[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 3 ? 3 : v); }
-[[maybe_unused]] static int insert_variant() { static int v = [] { const char* e = getenv("AC_INSERT_VARIANT"); return e ? atoi(e) : 0; }(); return v; }
 [[maybe_unused]] static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
-[[maybe_unused]] static u64 wave_chunk_rest() { const char* e = getenv("AC_INSERT_CHUNK_REST"); u64 x = e ? (u64)atoll(e) : 4096; return (std::max<u64>(x, 256) + 63) & ~63ULL; }   // longest chunk of the one-launch rest
+[[maybe_unused]] static u64 wave_chunk_rest() { const char* e = getenv("AC_INSERT_CHUNK_REST"); u64 x = e ? (u64)atoll(e) : 16384; return (std::max<u64>(x, 256) + 63) & ~63ULL; }   // longest chunk of the one-launch rest (r04c: 4096 / 8192 / 16384 = 0.90 / 0.84 / 0.82 ms)
 [[maybe_unused]] static u64 upload_threads() { const char* e = getenv("AC_UPLOAD_THREADS"); long x = e ? atol(e) : 8; return (u64)(x < 1 ? 1 : (x > 64 ? 64 : x)); }   // host threads filling the pinned staging ring
+[[maybe_unused]] static bool insert_profile() { static const bool v = getenv("AC_INSERT_PROFILE") != nullptr; return v; }      // measurement only
 [[maybe_unused]] static bool insert_adaptive() { const char* e = getenv("AC_INSERT_ADAPT"); return e ? atoi(e) != 0 : true; }
 [[maybe_unused]] static u64 insert_growth() { const char* e = getenv("AC_INSERT_GROWTH"); long x = e ? atol(e) : 2; return (u64)(x < 2 ? 2 : x); }      // phase i+1 ends at growth x the end of phase i
 [[maybe_unused]] static u64 insert_waves_target() { const char* e = getenv("AC_INSERT_WAVES"); long x = e ? atol(e) : 16384; return (u64)(x < 1024 ? 1024 : x); }   // wavefronts a long phase is cut into
@@ -375,8 +388,8 @@ struct GraphBuilder::Impl {
         if (t.n_text >= POS_MASK) throw DeviceError("input too large for 40-bit text positions");
         if (t.n_seqs == 0 || t.n_text < (u64)k + 2) throw DeviceError("no sequences");
     }
-    template <int W> void insert(const PackedText& t, u32 hint, DBuf<u64>* slots_out, u64* cap_out, u64* n_distinct_out);
-    void novel_bitmap(const PackedText& t, const DBuf<u64>& sl, u64 c, DBuf<u64>* bm_out, DBuf<u64>* occ_out);
+    template <int W> void insert(const PackedText& t, u32 hint, DBuf<u64>* slots_out, u64* cap_out, u64* n_distinct_out, DBuf<u64>* bm_out);
+    void occupancy_bitmap(const DBuf<u64>& sl, u64 c, DBuf<u64>* occ_out);
     DBuf<u64> occ;             // slot-occupancy bitmap of the graph table
     Table graph_table() const { return Table{const_cast<u64*>(slots.ptr()), cap - 1, occ.ptr()}; }
     template <int W> void fragments();
@@ -391,7 +404,7 @@ struct GraphBuilder::Impl {
 // K2 insert.  Capacity from the reference's own capacity hint (assembly_count, kmer_graph.rs:40): similar assemblies
 // share most k-mers.  Overflow -> retry with a larger table.
 template <int W>
-void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots_out, u64* cap_out, u64* n_distinct_out) {
+void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots_out, u64* cap_out, u64* n_distinct_out, DBuf<u64>* bm_out) {
     TextCtx t = pt.ctx((int)k);
     const u64 p_end_all = pt.n_text - (u64)k + 1;     // one past the last window that fits in the text
     if (hint == 0) hint = 1;
@@ -407,14 +420,16 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
     c <<= table_shift();
     DBuf<InsertStats> istats(257);       // [256].real doubles as the kernel's error word: one D2H reads everything
     DBuf<u64> sl;
+    DBuf<u64> nbm(pt.n_text / 64 + 2);   // K3a falls out of the insert: bit p set <=> p is the smallest occurrence of its canonical k-mer
     u64 n_distinct = 0;
     for (;;) {
         sl.alloc(c);
         sl.fill_bytes(0xFF);
+        nbm.fill_bytes(0);
         counters.fill_bytes(0);
         istats.fill_bytes(0);
         u32* ierr = (u32*)&istats.ptr()[256].real;
-        Table tb{sl.ptr(), c - 1, nullptr};
+        Table tb{sl.ptr(), c - 1, nullptr, nbm.ptr()};
         stream_sync();
 #ifndef AC_EMU
         hipEvent_t e0, e1;
@@ -435,7 +450,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
             u64 pe = (pb == 0) ? first : pb * insert_growth();
             if (rest_at_once || pe > p_end_all || p_end_all - pe < (1u << 16)) pe = p_end_all;
             u64 len = pe - pb;
-            if (insert_variant() == 0) {      // one wavefront per chunk: >= ~16 K wavefronts when the phase is long
+            {      // one wavefront per chunk: >= ~16 K wavefronts when the phase is long
                 u64 c = (len / insert_waves_target() + 63) & ~63ULL;
                 u32 chunk = (u32)std::min<u64>(std::max<u64>(c, 256), rest_at_once ? wave_chunk_rest() : wave_chunk_max());
                 u64 n_waves = (len + chunk - 1) / chunk;
@@ -444,13 +459,21 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
 #else
                 u64 blocks = (n_waves + 3) / 4;
                 if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
-                hipLaunchKernelGGL(insert_wave_kernel<W>, dim3((unsigned)blocks), dim3(256), 0, 0, t, tb, pb, pe, chunk, istats.ptr(), ierr);
-                AC_HIP_CHECK(hipGetLastError());
+                if (insert_profile()) {      // measurement only: per-wavefront cycle split of this launch on stderr
+                    DBuf<u64> prof(16);
+                    prof.fill_bytes(0);
+                    hipLaunchKernelGGL((insert_wave_kernel<W, true>), dim3((unsigned)blocks), dim3(256), 0, 0, t, tb, pb, pe, chunk, istats.ptr(), ierr, prof.ptr());
+                    AC_HIP_CHECK(hipGetLastError());
+                    std::vector<u64> h = to_host(prof, 16);
+                    fprintf(stderr, "insert launch %u: positions %llu chunk %u waves %llu | opener %llu steps avg %.0f cy | wide %llu steps avg %.0f cy | follow %llu runs avg %.0f cy | "
+                            "wave avg %.0f cy, longest %llu cy\n", launches, (unsigned long long)len, chunk, (unsigned long long)h[7],
+                            (unsigned long long)h[1], h[1] ? (double)h[0] / h[1] : 0.0, (unsigned long long)h[3], h[3] ? (double)h[2] / h[3] : 0.0,
+                            (unsigned long long)h[5], h[5] ? (double)h[4] / h[5] : 0.0, h[7] ? (double)h[6] / h[7] : 0.0, (unsigned long long)h[8]);
+                } else {
+                    hipLaunchKernelGGL((insert_wave_kernel<W, false>), dim3((unsigned)blocks), dim3(256), 0, 0, t, tb, pb, pe, chunk, istats.ptr(), ierr, (u64*)nullptr);
+                    AC_HIP_CHECK(hipGetLastError());
+                }
 #endif
-            } else {                          // one thread per chunk (kept for comparison: AC_INSERT_VARIANT=1)
-                u32 chunk = 64;
-                while (chunk < 1024 && len / chunk > (1u << 19)) chunk *= 2;   // >= ~0.5 M threads when the phase is long
-                launch((len + chunk - 1) / chunk, InsertFunctor<W>{t, tb, pb, pe, chunk, istats.ptr(), ierr});
             }
             launches++;
             pb = pe;
@@ -486,26 +509,24 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
     *slots_out = std::move(sl);
     *cap_out = c;
     *n_distinct_out = n_distinct;
+    *bm_out = std::move(nbm);
 }
 
-// K3a: bit p set <=> text position p is the smallest occurrence of its canonical k-mer.
-inline void GraphBuilder::Impl::novel_bitmap(const PackedText& t, const DBuf<u64>& sl, u64 c, DBuf<u64>* bm_out, DBuf<u64>* occ_out) {
-    u64 n_bm_words = t.n_text / 64 + 1;
-    bm_out->alloc(n_bm_words);
-    bm_out->fill_bytes(0);
+// Slot-occupancy bitmap of a finished table (one ballot word per wavefront of the scan; no atomics).
+inline void GraphBuilder::Impl::occupancy_bitmap(const DBuf<u64>& sl, u64 c, DBuf<u64>* occ_out) {
     occ_out->alloc((c + 63) / 64);
-    occ_out->fill_bytes(0);
-    launch_full(c, MarkFunctor{sl.ptr(), (u32*)bm_out->ptr(), occ_out->ptr()});
+#ifdef AC_EMU
+    occ_out->fill_bytes(0);      // the serial emulation ORs bit by bit; the device writes whole ballot words
+#endif
+    launch_full(c, MarkFunctor{sl.ptr(), occ_out->ptr()});
 }
 
 // Sharded phase 1 (after the local insert): novel runs of this rank -> fragment text + one meta record per fragment.
 template <int W> void GraphBuilder::Impl::fragments() {
     DBuf<u64> lslots, lbm; u64 lcap = 0, ln = 0;
-    insert<W>(loc, tm->local_hint, &lslots, &lcap, &ln);
+    insert<W>(loc, tm->local_hint, &lslots, &lcap, &ln, &lbm);
     tm->n_local_distinct = ln;
     lap(&tm->insert);
-    DBuf<u64> locc;
-    novel_bitmap(loc, lslots, lcap, &lbm, &locc);
     u64 nw = loc.n_text / 64 + 1;
     DBuf<u32> ns(nw + 1), ne(nw + 1), so(nw + 1), eo(nw + 1);
     ns.fill_bytes(0); ne.fill_bytes(0);
@@ -534,14 +555,14 @@ template <int W> void GraphBuilder::Impl::fragments() {
 template <int W> void GraphBuilder::Impl::table() {
     PackedText& g = *G;
     check_sizes(g);
-    insert<W>(g, tm->graph_hint, &slots, &cap, &N);
+    insert<W>(g, tm->graph_hint, &slots, &cap, &N, &bm);
     tm->table_capacity = cap;
     tm->n_distinct = N;
     lap(G == &loc ? &tm->insert : &tm->union_insert);
 
     // K3 novel-position bitmap -> sorted novel list + rank support
     u64 n_bm_words = g.n_text / 64 + 1;
-    novel_bitmap(g, slots, cap, &bm, &occ);
+    occupancy_bitmap(slots, cap, &occ);
     DBuf<u32> wcnt(n_bm_words);
     wprefix.alloc(n_bm_words);
     launch(n_bm_words, PopcFunctor{bm.ptr(), wcnt.ptr()});
@@ -643,20 +664,21 @@ template <int W> void GraphBuilder::Impl::walk() {
     depth.alloc(U, true); minpos_fwd.alloc(U); minpos_rev.alloc(U);
     minpos_fwd.fill_bytes(0xFF); minpos_rev.fill_bytes(0xFF);
     DBuf<u64> wcount(n_walkers + 1), woff(n_walkers + 1);
-    DBuf<int32_t> stage(n_walkers * PC);
+    DBuf<int32_t> stage(((n_walkers + 63) / 64) * 64 * PC);
     DBuf<u32> seq_tid(loc.n_seqs), seq_j(loc.n_seqs);
     path_off.alloc((u64)loc.n_seqs + 1);
     wcount.fill_bytes(0);
     const bool filter = path_filter();
     maybe_dest_valid = filter;
     if (filter) { maybe_dest.alloc((u64)U * 2); launch((u64)U * 2, MaybeDestFunctor{links.ptr(), maybe_dest.ptr()}); }
+    launch((u64)U * 10, WlinkFlagFunctor{filter ? maybe_dest.ptr() : nullptr, wlinks.ptr(), counters.ptr() + 4});
     launch(n_walkers, PathWalkFunctor<W>{t, g, tb, nv, uc, wlinks.ptr(), PC, stage.ptr(), wcount.ptr(), seq_tid.ptr(), seq_j.ptr(),
                                         depth.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), counters.ptr() + 4, filter ? maybe_dest.ptr() : nullptr,
                                         path_diag()});
     exclusive_scan_u64(wcount.ptr(), woff.ptr(), n_walkers + 1);
     n_ent = read_scalar(woff.ptr() + n_walkers);
     ent_val.alloc(n_ent);
-    launch(n_walkers, PathCompactFunctor{stage.ptr(), wcount.ptr(), woff.ptr(), PC, ent_val.ptr()});
+    launch_full(((n_walkers + 63) / 64) * 64, PathCompactFunctor{stage.ptr(), wcount.ptr(), woff.ptr(), PC, n_walkers, ent_val.ptr()});
     launch(loc.n_seqs, PathOffFunctor{seq_tid.ptr(), seq_j.ptr(), woff.ptr(), path_off.ptr()});
     tm->n_path_entries = n_ent;
     copy_h2d(path_off.ptr() + loc.n_seqs, &n_ent, 8);

@@ -124,7 +124,7 @@ struct FindResult { u64 pos; int claimant_flipped; bool found; };
 template <int W> AC_HD FindResult table_find(const TextCtx& t, const Table& tb, const Key<W>& ukey, bool isdot) {
     u64 h = key_hash<W>(ukey);
     u64 tag = slot_make(h, isdot, 0);
-    u64 s = h & tb.cap_mask;
+    u64 s = key_home<W>(ukey, t.k, isdot, h) & tb.cap_mask;
     FindResult r; r.found = false; r.pos = 0; r.claimant_flipped = 0;
     if (tb.occ && !((tb.occ[s >> 6] >> (s & 63)) & 1)) return r;
     for (int probes = 0; probes < MAX_PROBES; probes++) {
@@ -185,7 +185,7 @@ template <int W> AC_D u64 table_insert(const TextCtx& t, const Table& tb, const 
                                        u32* claimed, u32* err, bool* same, bool* mine_now) {
     u64 h = key_hash<W>(ukey);
     u64 mine = slot_make(h, isdot, p);
-    u64 s = h & tb.cap_mask;
+    u64 s = key_home<W>(ukey, t.k, isdot, h) & tb.cap_mask;
     *mine_now = false;
     for (int probes = 0; probes < MAX_PROBES_INSERT; probes++) {
         u64 v = tb.slots[s];
@@ -741,11 +741,12 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             prio.fill_bytes(0xFF);
             launch(J, CandListFunctor{order1.ptr(), cflag.ptr(), cpos.ptr(), clist.ptr(), prio.ptr()});
             launch(C, FillU32Functor{level.ptr(), 1u});
-            DBuf<u32> changed(8);
+            DBuf<u32> changed(8), preds(C * MAX_PREDS); DBuf<u8> npred(C);
+            launch(C, LevelPredsFunctor{L, cand.ptr(), clist.ptr(), prio.ptr(), C, preds.ptr(), npred.ptr()});
             for (;;) {   // longest-path levels of the conflict DAG by relaxation (monotone, so stale reads only delay); eight
                 changed.fill_bytes(0);       // sweeps per host check, converged when the last of them changed nothing
                 for (int it = 0; it < 8; it++)
-                    launch(C, LevelRelaxFunctor{L, cand.ptr(), clist.ptr(), prio.ptr(), level.ptr(), changed.ptr() + it});
+                    launch(C, LevelRelaxFunctor{preds.ptr(), npred.ptr(), C, level.ptr(), changed.ptr() + it, it ? changed.ptr() + it - 1 : nullptr});
                 if (to_host(changed, 8)[7] == 0) break;
             }
             DBuf<u64> lkey(C);

@@ -365,6 +365,26 @@ AC_UNROLL_W
     return h;
 }
 
+// Home slot of a k-mer in the table: a hash of its canonical MIDDLE (the k-2 bases without the first and the last one), not of
+// the whole key.  The four successors X[1..k)+c of a k-mer X share the middle X[2..k), its four predecessors the middle
+// X[0..k-2): all the neighbours a degree / link computation asks about (kmer_graph.rs:136-166, three of four of them absent) sit
+// in ONE probe cluster, i.e. one cache line of the table instead of one random line each — the degree kernel was bound by
+// exactly those line fetches.  At most 16 k-mers share a middle, members of a cluster are told apart by the fingerprint of the
+// whole key and verified against the text as before, so only the placement changes, never a result.  Dot k-mers (sequence ends)
+// and k < 3 hash the whole key.  `full_hash` = key_hash(key).
+template <int W> AC_HD u64 key_home(const Key<W>& key, int k, bool isdot, u64 full_hash) {
+    if (isdot || k < 3) return full_hash;
+    Key<W> v = key;
+    v.w[0] &= ~((u64)255 << 56);
+    const Key<W> mm = key_kmask<W>(k - 2);
+    Key<W> m = key_shr<W>(v, 2);
+AC_UNROLL_W
+    for (int i = 0; i < W; i++) m.w[i] &= mm.w[i];
+    Key<W> r = key_rc<W>(m, k - 2);
+    const Key<W> c = key_lt<W>(r, m) ? r : m;
+    return key_hash<W>(c) ^ 0x5851F42D4C957F2DULL;
+}
+
 // ---- hash-table slot word ------------------------------------------------------------------------
 // [fp:23][isdot:1][pos:40]; EMPTY = all ones.  The slot stores the *text position* of the smallest
 // occurrence of its canonical k-mer (the reference stores a raw pointer into the sequence,

@@ -104,6 +104,8 @@ WORKLOADS = {
     # strains 1 % apart.  The genome is 1 Mbp instead of 5 because the oracle keeps the reference's per-k-mer heap records
     # (kmer_graph.rs:36-41) and nearly every k-mer of such an input is distinct: 100 x 5 Mbp would need several hundred GB.
     "configEprime_k51": (51, 100, lambda: make_mixed_species(5, 20, genome=1_000_000, plasmid=20_000, strain_div=1e-2, sub=1e-4, indel=1e-5, seed=77_000)),
+    # E2: the same model with ~2 Mbp genomes (about the largest mixed-species input whose oracle run fits the 62 GB build container)
+    "configE2_k51": (51, 100, lambda: make_mixed_species(5, 20, genome=2_000_000, plasmid=40_000, strain_div=1e-2, sub=1e-4, indel=1e-5, seed=78_000)),
     # mini-E: 2 species x 40 strains x 5 Mbp — configs[4]'s per-GPU shape at N = 8 is 125 assemblies; no oracle golden (memory)
     "configEmini_k51": (51, 80, lambda: make_mixed_species(2, 40, genome=5_000_000, plasmid=100_000, strain_div=1e-2, sub=1e-4, indel=1e-5, seed=77_000)),
 }

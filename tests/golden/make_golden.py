@@ -44,6 +44,7 @@ out = {"what": "autocycler_oracle compress (oracle/: C++ restatement of the refe
        "post": dict(zip(("unitigs", "links", "total_length"), map(int, st[1]))),
        "seconds": dict(zip(("load_and_end_repair_8_threads", "kmer_graph", "unitig_graph", "simplify", "save"), map(float, m.groups()))),
        "wall_seconds": round(wall),
+       **({"oracle_env": {"ORACLE_NO_POSITION_RESERVE": "1 (capacity hint of kmer_graph.rs:40 not applied; output unaffected)"}} if os.environ.get("ORACLE_NO_POSITION_RESERVE") else {}),
        "host": "build container: 8 vCPUs, 62 GB; hot stages (k-mer graph, unitig graph, simplify) on one core like the reference"}
 (ROOT / "tests" / "golden" / f"{name}.json").write_text(json.dumps(out, indent=1) + "\n")
 print(json.dumps(out, indent=1))

@@ -20,7 +20,7 @@ for a, b in zip(b"ACGT", b"TGCA"):
     COMP[a] = b
 
 
-def build(n_assemblies, k=51, genome=5_000_000, pieces=1, device_repair=False):
+def build(n_assemblies, k=51, genome=5_000_000, pieces=1, device_repair=False, plasmid=None, seed=51_000):
     """pieces > 1: every replicon is cut into that many contigs (fragmented assemblies: thousands of sequences)."""
     import torch
     import bench
@@ -30,7 +30,7 @@ def build(n_assemblies, k=51, genome=5_000_000, pieces=1, device_repair=False):
     lib.ac_seqs_count.restype = C.c_uint32
     lib.ac_seqs_free.argtypes = [C.c_void_p]
     seqs, fn, hd = [], [], []
-    for i, contigs in enumerate(synth.make_assemblies(n_assemblies, genome=genome, plasmid=genome // 50, seed=51_000)):
+    for i, contigs in enumerate(synth.make_assemblies(n_assemblies, genome=genome, plasmid=genome // 50 if plasmid is None else plasmid, seed=seed)):
         for header, s in contigs:
             cuts = np.linspace(0, len(s), pieces + 1).astype(int) if len(s) >= 200 * pieces else np.array([0, len(s)])
             for j in range(len(cuts) - 1):
@@ -153,15 +153,25 @@ def test_config_d_prime_k101():
     assert U > 10000
 
 
-@pytest.mark.parametrize("golden_name,extra", [("configC_k51", []), ("configDprime_k101", ["--assemblies", "24", "--genome", "10000000", "--kmer", "101"]),
-                                               ("configB_k51", ["--assemblies", "12"])])
-def test_gfa_digest_equals_the_oracle(golden_name, extra):
+def test_config_d_full_size_k101():
+    # BASELINE configs[3] at FULL size on one MI355X: 24 x 100 Mbp, k = 101 (2.4 G bases, ~126 M distinct canonical k-mers).  The
+    # oracle cannot hold it, so the device result is checked through the size-independent properties.
+    g, seqs, fn, hd = build(24, k=101, genome=100_000_000, device_repair=True, plasmid=0, seed=101_000)
+    assert sum(len(s) for s in seqs) > 2_390_000_000
+    U = check_properties(g, seqs, 101)
+    assert U > 100_000
+    assert g.kmer_count > 240_000_000
+
+
+@pytest.mark.parametrize("golden_name", ["configC_k51", "configDprime_k101", "configB_k51", "configEprime_k51"])
+def test_gfa_digest_equals_the_oracle(golden_name):
     """Bit-exact parity at full size: the GFA built on the device (end repair on the device text, build, GFA text — the flow of
     tools/ab_knobs.py, run here as the same torch-free process) has the md5 the ORACLE produced for the same FASTA files on the CPU
     (tests/golden/*.json, made by tests/golden/make_configC_golden.sh: 26 and 12 minutes of the restated reference path), and the
     same unitig count.  configC_k51 = BASELINE configs[2] (96 x ~5 Mbp, k = 51: the benchmark workload); configDprime_k101 = the
-    scaled replica of configs[3] (24 x ~10 Mbp, k = 101: four-word keys); configB_k51 = BASELINE configs[1] (12 x ~5 Mbp, k = 51;
-    golden recorded after the round's GPU allowance was used up: first compared by the round-end run)."""
+    scaled replica of configs[3] (24 x ~10 Mbp, k = 101: four-word keys); configB_k51 = BASELINE configs[1] (12 x ~5 Mbp, k = 51);
+    configEprime_k51 = the scaled replica of configs[4] (mixed species: 5 species x 20 strains 1 % apart x ~1 Mbp = 100 assemblies,
+    1.73 M unitigs, a 310 MB GFA; tests/golden/make_golden.py, 32 minutes of the oracle)."""
     import json
     import os
     import subprocess
@@ -169,7 +179,7 @@ def test_gfa_digest_equals_the_oracle(golden_name, extra):
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     golden = json.loads((root / "tests" / "golden" / (golden_name + ".json")).read_text())
-    out = subprocess.run([sys.executable, str(root / "tools" / "ab_knobs.py"), "--variants", "base", "--steps", "1"] + extra,
+    out = subprocess.run([sys.executable, str(root / "tools" / "ab_knobs.py"), "--variants", "base", "--steps", "1", "--workload", golden_name],
                          env={**os.environ, "AC_NO_TORCH": "1"}, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]

@@ -257,3 +257,33 @@ def test_full_size_goldens_are_consistent(name, k):
     assert g["kmers"] == 2 * g["pre"]["total_length"]
     assert g["pre"]["unitigs"] == g["post"]["unitigs"] and g["pre"]["links"] == g["post"]["links"]
     assert g["post"]["total_length"] < g["pre"]["total_length"]
+
+
+def test_position_reserve_is_only_a_hint():
+    """ORACLE_NO_POSITION_RESERVE=1 (used to record tests/golden/configEprime_k51.json within the container's memory) skips the
+    reference's Vec::with_capacity(assembly_count) per k-mer (kmer_graph.rs:40): a capacity hint — the whole compress output must be
+    byte-identical with and without it (run in a fresh process each way: the switch is read once)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = ("import sys, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import oracle_lib as O, seqgen\n"
+            "from autocycler_amd import synth\n"
+            "h = hashlib.md5()\n"
+            "for k, seed in ((9, 3), (21, 7), (51, 13)):\n"
+            "    seqs, fn, hd = seqgen.make_case(seed, k)\n"
+            "    gfa, st, _ = O.Seqs.from_raw(k, seqs, filenames=fn, headers=hd).compress(k)\n"
+            "    h.update(gfa.encode()); h.update(repr(sorted(st.items())).encode())\n"
+            "seqs, fn, hd = synth.flatten(synth.make_mixed_species(2, 3, genome=20000, plasmid=1500, seed=5))\n"
+            "gfa, st, _ = O.Seqs.from_raw(51, [s.tobytes().decode() for s in seqs], filenames=fn, headers=hd, assembly_count=6).compress(51)\n"
+            "h.update(gfa.encode()); print(h.hexdigest())\n") % (str(root), str(root / "tests"))
+    import os
+    outs = []
+    for env in ({}, {"ORACLE_NO_POSITION_RESERVE": "1"}):
+        e = {k: v for k, v in os.environ.items() if k != "ORACLE_NO_POSITION_RESERVE"}
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip())
+    assert outs[0] == outs[1] and len(outs[0]) == 32

@@ -119,6 +119,9 @@ int ac_release_memory(void) {
         Arena::pinned_host().release_all();
         PinnedPool::get().trim();
         release_host_stager();
+#ifndef AC_EMU
+        Mailbox::get().release();
+#endif
     });
 }
 uint32_t ac_max_kmer(void) { int m = max_supported_k(); return (uint32_t)(m % 2 ? m : m - 1); }

@@ -87,6 +87,7 @@ class Arena {
     }
     // Start of a build: everything handed out so far is dead.
     void reset() {
+        on_reset();
         if (blocks_.size() > 1) {   // coalesce: next build gets one block big enough for the last one
             size_t total = 0;
             for (auto& b : blocks_) { total += b.cap; raw_free(b.p); }
@@ -106,6 +107,7 @@ class Arena {
         blocks_.push_back(b);
     }
     void release_all() {
+        on_reset();
         for (auto& b : blocks_) raw_free(b.p);
         blocks_.clear();
     }
@@ -116,6 +118,7 @@ class Arena {
   private:
     struct Block { void* p; size_t cap, used; };
     explicit Arena(bool host) : host_(host) {}
+    void on_reset();      // (defined after FillQueue)
     void* raw_alloc(size_t bytes) {
 #ifdef AC_EMU
         void* p = malloc(bytes);
@@ -202,6 +205,63 @@ class PinnedPool {
     size_t held_ = 0;
 };
 
+// ---- deferred, fused fills ---------------------------------------------------------------------------------------------------
+// A build zeroes / 0xFF-fills ~50 buffers, most of them a few hundred KB: as hipMemsetAsync each is its own 4-6 us launch and the
+// host cannot issue them faster.  Fills on stream 0 are queued instead and go out as ONE kernel right before the next operation on
+// that stream (every launch, copy, sort, scan and synchronisation of this file calls flush_fills() first; the few direct HIP calls
+// of graph_build.hip do the same).  Fills on any other stream are issued at once.
+#ifndef AC_EMU
+static const int FILL_MAX = 16;
+struct FillArgs { void* p[FILL_MAX]; u64 bytes[FILL_MAX]; u64 tile0[FILL_MAX + 1]; u32 word[FILL_MAX]; int n; };
+template <int UNUSED> __global__ void __launch_bounds__(256) fill_many_kernel(FillArgs a) {      // a tile = 16 KB of one region
+    const u64 tile = blockIdx.x;
+    int r = 0;
+    while (r + 1 < a.n && a.tile0[r + 1] <= tile) r++;
+    const u64 base = (tile - a.tile0[r]) * 16384;
+    u8* p = (u8*)a.p[r];
+    const u64 nb = a.bytes[r];
+    const u32 w = a.word[r];
+    const uint4 v = make_uint4(w, w, w, w);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const u64 o = base + (u64)j * 4096 + (u64)threadIdx.x * 16;
+        if (o + 16 <= nb) *(uint4*)(p + o) = v;
+        else if (o < nb) { for (u64 b = o; b < nb; b++) p[b] = (u8)w; }
+    }
+}
+class FillQueue {
+  public:
+    static FillQueue& get() { static FillQueue q; return q; }
+    void add(void* p, size_t bytes, int byte) {
+        if (n_ == FILL_MAX) flush();
+        const u32 b = (u32)(byte & 0xFF);
+        a_.p[n_] = p; a_.bytes[n_] = bytes; a_.word[n_] = b | (b << 8) | (b << 16) | (b << 24);
+        n_++;
+    }
+    void flush() {
+        if (!n_) return;
+        u64 tiles = 0;
+        for (int i = 0; i < n_; i++) { a_.tile0[i] = tiles; tiles += (a_.bytes[i] + 16383) / 16384; }
+        a_.tile0[n_] = tiles;
+        a_.n = n_;
+        n_ = 0;
+        if (tiles > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+        hipLaunchKernelGGL(fill_many_kernel<0>, dim3((unsigned)tiles), dim3(256), 0, 0, a_);
+        AC_HIP_CHECK(hipGetLastError());
+    }
+    void drop() { n_ = 0; }      // the arena was reset: whatever was queued points at dead buffers
+  private:
+    FillQueue() {}
+    FillArgs a_;
+    int n_ = 0;
+};
+inline void flush_fills() { FillQueue::get().flush(); }
+inline void Arena::on_reset() { if (!host_) FillQueue::get().drop(); }
+#else
+inline void flush_fills() {}
+inline void Arena::on_reset() {}
+#endif
+
 template <class T>
 class DBuf {   // a typed slice of the device arena (no ownership: the arena reset frees everything)
   public:
@@ -223,7 +283,8 @@ class DBuf {   // a typed slice of the device arena (no ownership: the arena res
 #ifdef AC_EMU
         memset(p_, byte, bytes);
 #else
-        AC_HIP_CHECK(hipMemsetAsync(p_, byte, bytes, s));
+        if (s == 0) FillQueue::get().add(p_, bytes, byte);      // deferred: fused with the other fills of this stage
+        else AC_HIP_CHECK(hipMemsetAsync(p_, byte, bytes, s));
 #endif
     }
     T* ptr() { return p_; }
@@ -241,6 +302,7 @@ inline void copy_h2d(void* d, const void* h, size_t bytes, stream_t s = 0) {
 #ifdef AC_EMU
     memcpy(d, h, bytes);
 #else
+    if (s == 0) flush_fills();
     AC_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
 #endif
 }
@@ -249,6 +311,7 @@ inline void copy_d2h_async(void* h, const void* d, size_t bytes, stream_t s = 0)
 #ifdef AC_EMU
     memcpy(h, d, bytes);
 #else
+    if (s == 0) flush_fills();
     AC_HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s));
 #endif
 }
@@ -268,9 +331,85 @@ inline void* pinned_scratch(size_t bytes) {
     return p;
 #endif
 }
+// ---- mailbox read-back -------------------------------------------------------------------------------------------------------
+// A build takes ~20 small host decisions (counts, flags, level tables).  As hipMemcpyAsync + hipStreamSynchronize each of them
+// costs 17-25 us of idle GPU (a blit kernel, its completion signal, the runtime's wake-up).  Instead a tiny kernel on the same
+// stream copies the words into a page of coherent pinned host memory that is mapped into the device's address space and then
+// stores a sequence number behind a system-scope fence; the host spins on that number.  Nothing but the PCIe write latency
+// (~2 us) stands between the producing kernel's end and the host seeing the value.
+#ifndef AC_EMU
+struct MailItem { const void* src; u32 bytes; u32 dst_off; };
+static const int MAIL_MAX_ITEMS = 6;
+struct MailArgs { MailItem it[MAIL_MAX_ITEMS]; int n; u8* box; u64 seq; };
+template <int UNUSED> __global__ void __launch_bounds__(256) mailbox_publish_kernel(MailArgs a) {      // a template only so that every translation unit may hold a copy
+    for (int i = 0; i < a.n; i++) {
+        const u8* s = (const u8*)a.it[i].src;
+        u8* d = a.box + 64 + a.it[i].dst_off;
+        const u32 nb = a.it[i].bytes;
+        if ((((uintptr_t)s | (uintptr_t)d | nb) & 7u) == 0) { for (u32 o = threadIdx.x * 8; o < nb; o += 256 * 8) *(volatile u64*)(d + o) = *(const u64*)(s + o); }
+        else if ((((uintptr_t)s | (uintptr_t)d | nb) & 3u) == 0) { for (u32 o = threadIdx.x * 4; o < nb; o += 256 * 4) *(volatile u32*)(d + o) = *(const u32*)(s + o); }
+        else { for (u32 o = threadIdx.x; o < nb; o += 256) *(volatile u8*)(d + o) = s[o]; }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence_system(); *(volatile u64*)a.box = a.seq; }
+}
+class Mailbox {
+  public:
+    static const size_t CAP = (size_t)64 << 10;      // payload bytes
+    static Mailbox& get() { static Mailbox m; return m; }
+    // Copies the items (device -> host) behind everything enqueued on stream `s` so far and waits for them.
+    void fetch(const MailItem* items, void* const* host_dst, int n, stream_t s) {
+        ensure();
+        if (s == 0) flush_fills();
+        MailArgs a;
+        a.n = n; a.box = d_; a.seq = ++seq_;
+        for (int i = 0; i < n; i++) a.it[i] = items[i];
+        hipLaunchKernelGGL(mailbox_publish_kernel<0>, dim3(1), dim3(256), 0, s, a);
+        AC_HIP_CHECK(hipGetLastError());
+        volatile u64* flag = (volatile u64*)h_;
+        for (u64 spins = 0; *flag != a.seq; spins++) {
+            if ((spins & 0xFFFFF) == 0xFFFFF) {      // ~every few ms: has the stream died under us?
+                hipError_t e = hipStreamQuery(s);
+                if (e != hipSuccess && e != hipErrorNotReady) AC_HIP_CHECK(e);
+                if (e == hipSuccess && *flag != a.seq) {      // the kernel is done but its store is not visible: leave through the slow path
+                    AC_HIP_CHECK(hipStreamSynchronize(s));
+                    if (*flag != a.seq) throw DeviceError("mailbox: the device finished without delivering its read-back");
+                }
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        for (int i = 0; i < n; i++) memcpy(host_dst[i], h_ + 64 + items[i].dst_off, items[i].bytes);
+    }
+    void release() {
+        if (h_) (void)hipHostFree(h_);
+        h_ = nullptr; d_ = nullptr;
+    }
+  private:
+    Mailbox() {}
+    void ensure() {
+        if (h_) return;
+        AC_HIP_CHECK(hipHostMalloc((void**)&h_, CAP + 64, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(h_, 0, CAP + 64);
+        AC_HIP_CHECK(hipHostGetDevicePointer((void**)&d_, h_, 0));
+    }
+    u8* h_ = nullptr; u8* d_ = nullptr;
+    u64 seq_ = 0;
+};
+inline bool use_mailbox() { static const bool v = getenv("AC_NO_MAILBOX") == nullptr; return v; }
+#endif
 inline void copy_d2h(void* h, const void* d, size_t bytes, stream_t s = 0) {
     if (!bytes) return;
 #ifndef AC_EMU
+    if (s == 0) flush_fills();
+    if (use_mailbox() && bytes <= Mailbox::CAP) {
+        MailItem it{d, (u32)bytes, 0};
+        Mailbox::get().fetch(&it, &h, 1, s);
+        return;
+    }
     static const bool use_scratch = getenv("AC_NO_PINNED_SCRATCH") == nullptr;
     if (use_scratch && bytes <= (64 << 10)) {
         void* p = pinned_scratch(bytes);
@@ -285,7 +424,7 @@ inline void copy_d2h(void* h, const void* d, size_t bytes, stream_t s = 0) {
     AC_HIP_CHECK(hipStreamSynchronize(s));
 #endif
 }
-// Several small device arrays -> host with ONE synchronisation (through the pinned scratch page).
+// Several small device arrays -> host with ONE synchronisation (one mailbox publication, or the pinned scratch page).
 class ReadBatch {
   public:
     void add(void* h, const void* d, size_t bytes) { if (bytes) items_.push_back(Item{h, d, bytes}); }
@@ -297,6 +436,15 @@ class ReadBatch {
         size_t total = 0;
         for (auto& it : items_) total += (it.bytes + 63) & ~(size_t)63;
         if (total == 0) return;
+        if (s == 0) flush_fills();
+        if (use_mailbox() && total <= Mailbox::CAP && items_.size() <= (size_t)MAIL_MAX_ITEMS) {
+            MailItem mi[MAIL_MAX_ITEMS]; void* dst[MAIL_MAX_ITEMS];
+            size_t o = 0;
+            for (size_t i = 0; i < items_.size(); i++) { mi[i] = MailItem{items_[i].d, (u32)items_[i].bytes, (u32)o}; dst[i] = items_[i].h; o += (items_[i].bytes + 63) & ~(size_t)63; }
+            Mailbox::get().fetch(mi, dst, (int)items_.size(), s);
+            items_.clear();
+            return;
+        }
         char* p = (char*)pinned_scratch(total);
         size_t o = 0;
         for (auto& it : items_) { AC_HIP_CHECK(hipMemcpyAsync(p + o, it.d, it.bytes, hipMemcpyDeviceToHost, s)); o += (it.bytes + 63) & ~(size_t)63; }
@@ -322,11 +470,13 @@ inline void copy_d2d(void* dst, const void* src, size_t bytes, stream_t s = 0) {
 #ifdef AC_EMU
     memmove(dst, src, bytes);
 #else
+    if (s == 0) flush_fills();
     AC_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
 #endif
 }
 inline void stream_sync(stream_t s = 0) {
 #ifndef AC_EMU
+    if (s == 0) flush_fills();
     AC_HIP_CHECK(hipStreamSynchronize(s));
 #endif
 }
@@ -372,6 +522,7 @@ class SideStream {
 #ifndef AC_EMU
         stream_t s = stream();
         hipEvent_t e = ev_[next_++ % 16];
+        flush_fills();
         AC_HIP_CHECK(hipEventRecord(e, 0));
         AC_HIP_CHECK(hipStreamWaitEvent(s, e, 0));
 #endif
@@ -429,6 +580,7 @@ template <class F> void launch(u64 n, const F& f, stream_t s = 0) {
 #else
     u64 blocks = (n + 255) / 256;
     if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+    if (s == 0) flush_fills();
     hipLaunchKernelGGL(functor_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, s, n, f);
     AC_HIP_CHECK(hipGetLastError());
 #endif
@@ -452,6 +604,7 @@ template <class F> void launch_full(u64 n, const F& f, stream_t s = 0) {
 #else
     u64 blocks = (n + 255) / 256;
     if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+    if (s == 0) flush_fills();
     hipLaunchKernelGGL(functor_kernel_full<F>, dim3((unsigned)blocks), dim3(256), 0, s, n, f);
     AC_HIP_CHECK(hipGetLastError());
 #endif
@@ -499,6 +652,7 @@ inline void sort_pairs_u64_u32(DBuf<u64>& keys, DBuf<u32>& vals, size_t n, int e
     memcpy(k, k2.data(), n * 8); memcpy(v, v2.data(), n * 4);
     (void)end_bit;
 #else
+    if (s == 0) flush_fills();
     DBuf<u64> k2(n); DBuf<u32> v2(n);
     size_t tmp_bytes = 0;
     AC_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, 0, end_bit, s));
@@ -520,6 +674,7 @@ inline void sort_pairs_u64_i32(DBuf<u64>& keys, DBuf<int32_t>& vals, size_t n, i
     memcpy(k, k2.data(), n * 8); memcpy(v, v2.data(), n * 4);
     (void)end_bit;
 #else
+    if (s == 0) flush_fills();
     DBuf<u64> k2(n); DBuf<int32_t> v2(n);
     size_t tmp_bytes = 0;
     AC_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, 0, end_bit, s));
@@ -536,6 +691,7 @@ inline void inclusive_scan_u32(const u32* in, u32* out, size_t n, stream_t s = 0
     u32 acc = 0;
     for (size_t i = 0; i < n; i++) { acc += in[i]; out[i] = acc; }
 #else
+    if (s == 0) flush_fills();
     size_t tmp_bytes = 0;
     AC_HIP_CHECK(rocprim::inclusive_scan(nullptr, tmp_bytes, in, out, n, rocprim::plus<u32>(), s));
     DBuf<u8> tmp(tmp_bytes);
@@ -548,6 +704,7 @@ inline void exclusive_scan_u32(const u32* in, u32* out, size_t n, stream_t s = 0
     u32 acc = 0;
     for (size_t i = 0; i < n; i++) { u32 v = in[i]; out[i] = acc; acc += v; }
 #else
+    if (s == 0) flush_fills();
     size_t tmp_bytes = 0;
     AC_HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, (u32)0, n, rocprim::plus<u32>(), s));
     DBuf<u8> tmp(tmp_bytes);
@@ -560,6 +717,7 @@ inline void exclusive_scan_u64(const u64* in, u64* out, size_t n, stream_t s = 0
     u64 acc = 0;
     for (size_t i = 0; i < n; i++) { u64 v = in[i]; out[i] = acc; acc += v; }
 #else
+    if (s == 0) flush_fills();
     size_t tmp_bytes = 0;
     AC_HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, (u64)0, n, rocprim::plus<u64>(), s));
     DBuf<u8> tmp(tmp_bytes);
@@ -587,6 +745,7 @@ inline void reduce_by_segment(const u32* seg, const V* vals, size_t n, V* out, s
     }
     if (r != n_segments) throw DeviceError("reduce_by_segment: segment count mismatch");
 #else
+    if (s == 0) flush_fills();
     DBuf<u32> uniq(n_segments);
     DBuf<u32> cnt(1);
     size_t tmp_bytes = 0;
@@ -615,6 +774,7 @@ inline void segment_argmin(const u32* seg, size_t n, u32* out, size_t n_segments
     }
     if (r != n_segments) throw DeviceError("segment_argmin: segment count mismatch");
 #else
+    if (s == 0) flush_fills();
     DBuf<u32> uniq(n_segments);
     DBuf<u32> cnt(1);
     rocprim::counting_iterator<u32> idx(0);
@@ -640,6 +800,7 @@ inline void sort_by_key_cmp(DBuf<K>& keys, DBuf<u32>& vals, size_t n, Cmp cmp, s
     for (size_t i = 0; i < n; i++) { k2[i] = k[idx[i]]; v2[i] = v[idx[i]]; }
     memcpy(k, k2.data(), n * sizeof(K)); memcpy(v, v2.data(), n * 4);
 #else
+    if (s == 0) flush_fills();
     DBuf<K> k2(n); DBuf<u32> v2(n);
     size_t tmp_bytes = 0;
     AC_HIP_CHECK(rocprim::merge_sort(nullptr, tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, cmp, s));
@@ -657,6 +818,7 @@ inline void sort_keys_cmp(DBuf<u32>& keys, size_t n, Cmp cmp, stream_t s = 0) {
 #ifdef AC_EMU
     std::stable_sort(keys.ptr(), keys.ptr() + n, cmp);
 #else
+    if (s == 0) flush_fills();
     DBuf<u32> k2(n);
     size_t tmp_bytes = 0;
     AC_HIP_CHECK(rocprim::merge_sort(nullptr, tmp_bytes, keys.ptr(), k2.ptr(), n, cmp, s));

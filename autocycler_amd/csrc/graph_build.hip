@@ -434,6 +434,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
 #ifndef AC_EMU
         hipEvent_t e0, e1;
         AC_HIP_CHECK(hipEventCreate(&e0)); AC_HIP_CHECK(hipEventCreate(&e1));
+        flush_fills();
         AC_HIP_CHECK(hipEventRecord(e0, 0));
 #endif
         // Phases over geometrically growing prefixes: [0, n/A), [n/A, 2n/A), [2n/A, 4n/A), ...  (A = assembly
@@ -459,6 +460,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
 #else
                 u64 blocks = (n_waves + 3) / 4;
                 if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+                flush_fills();
                 if (insert_profile()) {      // measurement only: per-wavefront cycle split of this launch on stderr
                     DBuf<u64> prof(16);
                     prof.fill_bytes(0);
@@ -485,6 +487,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
             }
         }
 #ifndef AC_EMU
+        flush_fills();
         AC_HIP_CHECK(hipEventRecord(e1, 0));
         AC_HIP_CHECK(hipEventSynchronize(e1));
         float ms = 0; AC_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -612,6 +615,7 @@ template <int W> void GraphBuilder::Impl::unitigs() {
 #else
             const u64 blocks = (N + 255) / 256;
             if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+            flush_fills();
             hipLaunchKernelGGL(minkey_wave_kernel<W>, dim3((unsigned)blocks), dim3(256), 0, 0, a);
             AC_HIP_CHECK(hipGetLastError());
 #endif
@@ -1070,6 +1074,7 @@ void GraphBuilder::set_sequences_host(const std::vector<SeqView>& seqs, bool pac
     AC_HIP_CHECK(hipGetDevice(&dev));
     hipStream_t up = st.stream(), pk = st.pack_stream();
     {   // both streams start after whatever stream 0 still has in flight (the table copies above); the fills of bits / mask go
+        flush_fills();
         AC_HIP_CHECK(hipEventRecord(st.begin(), 0));      // first on the pack stream
         AC_HIP_CHECK(hipStreamWaitEvent(up, st.begin(), 0));
         AC_HIP_CHECK(hipStreamWaitEvent(pk, st.begin(), 0));

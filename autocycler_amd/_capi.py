@@ -50,7 +50,7 @@ class Timings(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
-EXPORTS = ["ac_compress_build", "ac_compress_build_device", "ac_text_size", "ac_layout_text", "ac_kmer_count",
+EXPORTS = ["ac_compress_build", "ac_compress_build_device", "ac_pack_text", "ac_text_size", "ac_layout_text", "ac_kmer_count",
            "ac_stats_pre", "ac_stats_post", "ac_unitig_count", "ac_unitig", "ac_unitig_positions", "ac_links",
            "ac_path", "ac_timings_get", "ac_free", "ac_gfa_string", "ac_string_free", "ac_last_error",
            "ac_device_count", "ac_max_kmer", "ac_version", "ac_set_stage_timing", "ac_random_access_ceilings", "ac_release_memory", "ac_end_repair_device", "ac_pairwise_distances", "ac_graph_from_gfa", "ac_graph_kmer_size", "ac_graph_seq_info", "ac_decompress_seq", "ac_decompress",

@@ -152,6 +152,13 @@ int ac_layout_text(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs, uint8_t
     });
 }
 
+int ac_pack_text(const uint8_t* text, uint64_t n_text, uint64_t* bits, uint32_t* mask32, int force_scalar) {
+    return guarded([&] {
+        if (!text || !bits || !mask32) throw DeviceError("null pointer");
+        pack_text_host(text, n_text, bits, mask32, force_scalar != 0);
+    });
+}
+
 int ac_compress_build(uint32_t k, uint32_t assembly_count, const ac_seq_view* seqs, uint32_t n_seqs, int device,
                       ac_graph** out) {
     return guarded([&] {

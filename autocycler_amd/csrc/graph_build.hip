@@ -301,7 +301,8 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 3 ? 3 : v); }
 [[maybe_unused]] static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
 [[maybe_unused]] static u64 wave_chunk_rest() { const char* e = getenv("AC_INSERT_CHUNK_REST"); u64 x = e ? (u64)atoll(e) : 16384; return (std::max<u64>(x, 256) + 63) & ~63ULL; }   // longest chunk of the one-launch rest (r04c: 4096 / 8192 / 16384 = 0.90 / 0.84 / 0.82 ms)
-[[maybe_unused]] static u64 upload_threads() { const char* e = getenv("AC_UPLOAD_THREADS"); long x = e ? atol(e) : 8; return (u64)(x < 1 ? 1 : (x > 64 ? 64 : x)); }   // host threads filling the pinned staging ring
+[[maybe_unused]] static u64 upload_threads() { const char* e = getenv("AC_UPLOAD_THREADS"); long x = e ? atol(e) : 16; return (u64)(x < 1 ? 1 : (x > 128 ? 128 : x)); }   // host threads laying out / packing the text (the byte upload uses at most 8)
+[[maybe_unused]] static bool host_pack() { const char* e = getenv("AC_HOST_PACK"); return e ? atoi(e) != 0 : true; }      // 0: upload the text as bytes and pack on the device
 [[maybe_unused]] static bool insert_profile() { static const bool v = getenv("AC_INSERT_PROFILE") != nullptr; return v; }      // measurement only
 [[maybe_unused]] static bool insert_adaptive() { const char* e = getenv("AC_INSERT_ADAPT"); return e ? atoi(e) != 0 : true; }
 [[maybe_unused]] static u64 insert_growth() { const char* e = getenv("AC_INSERT_GROWTH"); long x = e ? atol(e) : 2; return (u64)(x < 2 ? 2 : x); }      // phase i+1 ends at growth x the end of phase i
@@ -1035,6 +1036,162 @@ static void fill_text_range(const std::vector<SeqView>& seqs, const std::vector<
     }
 }
 
+// K1 on the host: 32 text bytes -> one word of 2-bit codes (first base most significant) + 32 mask bits, exactly what PackFunctor
+// computes on the device.  AVX2 classifies 32 bytes at a time, BMI2 `pext` squeezes 8 codes out of 8 bytes; ~12 GB/s of text per
+// core, so sixteen threads pack as fast as the host's memory delivers the text.
+static void pack_groups_scalar(const u8* t, u64 n_groups, u64* bits, u32* mask) {
+    for (u64 g = 0; g < n_groups; g++) {
+        u64 w = 0; u32 m = 0;
+        for (int i = 0; i < 32; i++) {
+            u32 ch = t[g * 32 + (u64)i];
+            u32 bad = !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
+            u32 c = bad ? 0u : (((ch >> 1) ^ (ch >> 2)) & 3u);
+            w |= (u64)c << (62 - 2 * i);
+            m |= bad << i;
+        }
+        bits[g] = w; mask[g] = m;
+    }
+}
+#if defined(__x86_64__)
+}  // namespace ac
+#include <immintrin.h>
+namespace ac {
+__attribute__((target("avx2,bmi2"))) static void pack_groups_avx2(const u8* t, u64 n_groups, u64* bits, u32* mask) {
+    const __m256i vA = _mm256_set1_epi8('A'), vC = _mm256_set1_epi8('C'), vG = _mm256_set1_epi8('G'), vT = _mm256_set1_epi8('T');
+    const __m256i three = _mm256_set1_epi8(3);
+    const u64 M = 0x0303030303030303ULL;
+    for (u64 g = 0; g < n_groups; g++) {
+        const __m256i v = _mm256_loadu_si256((const __m256i*)(t + g * 32));
+        const __m256i good = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, vA), _mm256_cmpeq_epi8(v, vC)),
+                                             _mm256_or_si256(_mm256_cmpeq_epi8(v, vG), _mm256_cmpeq_epi8(v, vT)));
+        // ((ch >> 1) ^ (ch >> 2)) & 3 per byte: 16-bit shifts only move a neighbour's bit into bit 7, which the mask drops
+        __m256i c = _mm256_and_si256(_mm256_xor_si256(_mm256_srli_epi16(v, 1), _mm256_srli_epi16(v, 2)), three);
+        c = _mm256_and_si256(c, good);
+        mask[g] = ~(u32)_mm256_movemask_epi8(good);
+        alignas(32) u64 q[4];
+        _mm256_store_si256((__m256i*)q, c);
+        bits[g] = (_pext_u64(__builtin_bswap64(q[0]), M) << 48) | (_pext_u64(__builtin_bswap64(q[1]), M) << 32) |
+                  (_pext_u64(__builtin_bswap64(q[2]), M) << 16) | _pext_u64(__builtin_bswap64(q[3]), M);
+    }
+}
+#endif
+static void pack_groups(const u8* t, u64 n_groups, u64* bits, u32* mask) {
+#if defined(__x86_64__)
+    static const bool fast = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && getenv("AC_PACK_SCALAR") == nullptr;
+    if (fast) { pack_groups_avx2(t, n_groups, bits, mask); return; }
+#endif
+    pack_groups_scalar(t, n_groups, bits, mask);
+}
+
+void pack_text_host(const uint8_t* text, uint64_t n_text, uint64_t* bits, uint32_t* mask32, bool force_scalar) {
+    const u64 full = n_text / 32;
+    if (force_scalar) pack_groups_scalar(text, full, bits, mask32); else pack_groups(text, full, bits, mask32);
+    if (n_text % 32) {      // the last, partial group reads as if the text went on with separators
+        u8 tail[32];
+        for (u64 i = 0; i < 32; i++) tail[i] = (full * 32 + i < n_text) ? text[full * 32 + i] : (u8)'$';
+        if (force_scalar) pack_groups_scalar(tail, 1, bits + full, mask32 + full); else pack_groups(tail, 1, bits + full, mask32 + full);
+    }
+}
+
+// Final (end-repaired) sequences: the text never reaches the device as bytes.  Host threads lay a piece of the text out in a
+// cache-resident buffer, pack it (K1 above) straight into a pinned slot, and whoever finishes a 64 MB chunk sends its 16 MB of
+// codes and 8 MB of mask bits: 0.375 bytes per base cross PCIe instead of 1 (config C: 183 MB in ~3.5 ms instead of 487 MB in ~9).
+void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::vector<uint64_t>& off) {
+    const uint32_t k = impl_->k;
+    PackedText& loc = impl_->loc;
+    const u64 n = loc.n_text;
+    HostStager& st = HostStager::get();
+    st.ensure();
+    const u64 CH = (u64)64 << 20, SUB = (u64)1 << 20;      // text bytes per chunk (one pair of copies) / per work item
+    const u64 SLOT_BYTES = CH / 4 + CH / 8;                // codes + mask bits of one chunk
+    [[maybe_unused]] const int NSLOT = (int)((HostStager::SLOT * HostStager::NS) / SLOT_BYTES);
+    [[maybe_unused]] const u64 n_chunks = (n + CH - 1) / CH, subs = CH / SUB;
+    [[maybe_unused]] auto chunk_len = [&](u64 c) { return std::min(n, (c + 1) * CH) - c * CH; };
+    [[maybe_unused]] auto slot_bits = [&](int sl) { return (u64*)(st.slot(0) + (u64)sl * SLOT_BYTES); };
+    [[maybe_unused]] auto slot_mask = [&](int sl) { return (u32*)(st.slot(0) + (u64)sl * SLOT_BYTES + CH / 4); };
+#ifdef AC_EMU
+    loc.pack_alloc();
+    std::vector<u8> tmp(SUB + 64);
+    for (u64 b = 0; b < n; b += SUB) {
+        const u64 e = std::min(n, b + SUB), groups = (e - b + 31) / 32;
+        fill_text_range(seqs, off, k, b, e, tmp.data());
+        for (u64 i = e - b; i < groups * 32; i++) tmp[i] = '$';
+        pack_groups(tmp.data(), groups, loc.bits.ptr() + b / 32, (u32*)loc.mask.ptr() + b / 32);
+    }
+#else
+    int dev = 0;
+    AC_HIP_CHECK(hipGetDevice(&dev));
+    hipStream_t up = st.stream(), pk = st.pack_stream();
+    flush_fills();
+    AC_HIP_CHECK(hipEventRecord(st.begin(), 0));
+    AC_HIP_CHECK(hipStreamWaitEvent(pk, st.begin(), 0));
+    loc.pack_alloc(pk);                                    // zero codes / all-ones mask beyond the text (and under it, until the copies land)
+    AC_HIP_CHECK(hipEventRecord(st.copied(), pk));
+    AC_HIP_CHECK(hipStreamWaitEvent(up, st.copied(), 0));
+    std::atomic<u64> next{0};
+    std::vector<std::atomic<u32>> done(n_chunks), slot_state(n_chunks);      // slot_state: 0 untouched, 1 someone is waiting for the slot, 2 free
+    for (auto& x : done) x.store(0);
+    for (auto& x : slot_state) x.store(0);
+    std::vector<std::atomic<u32>> issued(n_chunks);
+    for (auto& x : issued) x.store(0);
+    std::mutex hip_mu;
+    std::string fail;
+    std::atomic<bool> stop{false};
+    u64* const d_bits = loc.bits.ptr();
+    u32* const d_mask = (u32*)loc.mask.ptr();
+    auto worker = [&] {
+        try {
+            AC_HIP_CHECK(hipSetDevice(dev));
+            std::vector<u8> tmp(SUB + 64);
+            for (u64 item; (item = next.fetch_add(1)) < n_chunks * subs && !stop.load();) {
+                const u64 c = item / subs, sub = item % subs;
+                const u64 clen = chunk_len(c);
+                if (sub * SUB >= clen) continue;
+                const int sl = (int)(c % (u64)NSLOT);
+                if (c >= (u64)NSLOT) {      // the chunk that used this slot before must have left it: one thread waits, the others watch it
+                    u32 expect = 0;
+                    if (slot_state[c].compare_exchange_strong(expect, 1)) {
+                        while (!issued[c - NSLOT].load(std::memory_order_acquire) && !stop.load()) std::this_thread::yield();
+                        if (!stop.load()) AC_HIP_CHECK(hipEventSynchronize(st.event(sl)));
+                        slot_state[c].store(2, std::memory_order_release);
+                    } else {
+                        while (slot_state[c].load(std::memory_order_acquire) != 2 && !stop.load()) std::this_thread::yield();
+                    }
+                    if (stop.load()) break;
+                }
+                const u64 b = c * CH + sub * SUB, e = std::min(c * CH + clen, b + SUB), groups = (e - b + 31) / 32;
+                fill_text_range(seqs, off, k, b, e, tmp.data());
+                for (u64 i = e - b; i < groups * 32; i++) tmp[i] = '$';
+                pack_groups(tmp.data(), groups, slot_bits(sl) + sub * SUB / 32, slot_mask(sl) + sub * SUB / 32);
+                const u32 n_sub = (u32)((clen + SUB - 1) / SUB);
+                if (done[c].fetch_add(1, std::memory_order_acq_rel) + 1 == n_sub) {      // the chunk is complete: send it
+                    const u64 g0 = c * CH / 32, ng = (clen + 31) / 32;
+                    std::lock_guard<std::mutex> lock(hip_mu);
+                    AC_HIP_CHECK(hipMemcpyAsync(d_bits + g0, slot_bits(sl), ng * 8, hipMemcpyHostToDevice, up));
+                    AC_HIP_CHECK(hipMemcpyAsync(d_mask + g0, slot_mask(sl), ng * 4, hipMemcpyHostToDevice, up));
+                    AC_HIP_CHECK(hipEventRecord(st.event(sl), up));
+                    issued[c].store(1, std::memory_order_release);
+                }
+            }
+        } catch (const std::exception& ex) {
+            std::lock_guard<std::mutex> lock(hip_mu);
+            if (fail.empty()) fail = ex.what();
+            stop.store(true);
+        }
+    };
+    const int T = (int)std::max<u64>(1, std::min<u64>({(n + SUB - 1) / SUB, upload_threads(), (u64)std::max(1u, std::thread::hardware_concurrency())}));
+    std::vector<std::thread> pool;
+    for (int i = 1; i < T; i++) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+    if (!fail.empty()) { (void)hipStreamSynchronize(up); (void)hipStreamSynchronize(pk); throw DeviceError(fail); }
+    AC_HIP_CHECK(hipEventRecord(st.done(), up));
+    AC_HIP_CHECK(hipStreamWaitEvent(0, st.done(), 0));
+    st.timed = true;
+#endif
+    loc.packed = true;
+}
+
 void GraphBuilder::set_sequences_host(const std::vector<SeqView>& seqs, bool pack_now) {
     const double t0 = now_s();
     const uint32_t k = impl_->k;
@@ -1052,6 +1209,14 @@ void GraphBuilder::set_sequences_host(const std::vector<SeqView>& seqs, bool pac
     }
     PackedText& loc = impl_->loc;
     loc.n_text = n;
+    if (pack_now && host_pack()) {      // the sequences are final: pack on the host, upload 0.375 B per base
+        Arena::device().reserve(arena_estimate(n, false));
+        loc.d_text = nullptr;
+        loc.set_table(off, len, d1, d2);
+        upload_packed(seqs, off);
+        tm_.h2d = now_s() - t0;
+        return;
+    }
     Arena::device().reserve(arena_estimate(n, true));
     impl_->text_owned.alloc(n + 64);
     loc.d_text = impl_->text_owned.ptr();
@@ -1116,7 +1281,7 @@ void GraphBuilder::set_sequences_host(const std::vector<SeqView>& seqs, bool pac
             stop.store(true);
         }
     };
-    const int T = (int)std::min<u64>(n_chunks, upload_threads());
+    const int T = (int)std::min<u64>(n_chunks, std::min<u64>(upload_threads(), 8));
     std::vector<std::thread> pool;
     for (int i = 1; i < T; i++) pool.emplace_back(worker);
     worker();

@@ -100,6 +100,7 @@ class GraphBuilder {
     struct Impl;   // all device state of one build (graph_build.hip)
 
   private:
+    void upload_packed(const std::vector<SeqView>& seqs, const std::vector<uint64_t>& off);
     Impl* impl_;
     BuildTimings tm_;
 };
@@ -120,6 +121,10 @@ void random_access_ceilings(double* cas_gops, double* read_gops);
 // Brings the HIP context and this library's code objects up on `device` (first use costs ~0.2 s): callable from a helper
 // thread while the caller is still busy on the host.
 void device_warmup(int device);
+
+// K1 on the host (what the packed upload of set_sequences_host runs per piece): n_text bytes -> (n_text + 31) / 32 words of 2-bit
+// codes (first base most significant) and as many 32-bit mask words (bit i = byte i is not a base).
+void pack_text_host(const uint8_t* text, uint64_t n_text, uint64_t* bits, uint32_t* mask32, bool force_scalar);
 
 // Frees the pinned staging ring of the host entry (192 MB; it otherwise stays for the next build of the process).
 void release_host_stager();

@@ -27,7 +27,9 @@ from . import _capi
 class Comm:
     """The collectives a sharded build needs.  world == 1 (or no process group) degenerates to local copies."""
 
-    def __init__(self, device, group=None):
+    def __init__(self, device, group=None, always_collective=False):
+        """always_collective: issue the collectives even in a world of one rank (they are local copies otherwise) — how the
+        device test-suite drives every RCCL call of this module on the one-GPU box (tests/test_sharded_gpu.py)."""
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -38,6 +40,8 @@ class Comm:
             backend = dist.get_backend(group)
         else:
             self.world, self.rank, backend = 1, 0, None
+        self.local_only = self.world == 1 and not (always_collective and backend is not None)
+        self.calls = {}
         # gloo moves host memory: device tensors are staged through the host (CPU test-suite, single-GPU dry runs)
         self.stage = (backend == "gloo") and self.device.type != "cpu"
         self.seconds = 0.0
@@ -50,9 +54,10 @@ class Comm:
 
     def all_gather_sizes(self, values):
         """values: list of ints -> list (per rank) of lists."""
-        if self.world == 1:
+        if self.local_only:
             return [list(values)]
         t0 = time.perf_counter()
+        self.calls["all_gather_into_tensor"] = self.calls.get("all_gather_into_tensor", 0) + 1
         mine = self._out(torch.tensor(values, dtype=torch.int64, device=self.device))
         out = torch.empty(self.world * len(values), dtype=torch.int64, device=mine.device)
         self.dist.all_gather_into_tensor(out, mine, group=self.group)
@@ -62,9 +67,10 @@ class Comm:
 
     def all_gather_padded(self, t, sizes):
         """t: 1-D tensor holding sizes[rank] elements (may be longer); returns the per-rank slices."""
-        if self.world == 1:
+        if self.local_only:
             return [t[:sizes[0]]]
         t0 = time.perf_counter()
+        self.calls["all_gather_into_tensor"] = self.calls.get("all_gather_into_tensor", 0) + 1
         m = max(sizes)
         mine = t if t.numel() == m else torch.cat([t[:sizes[self.rank]], t.new_zeros(m - sizes[self.rank])])
         mine = self._out(mine)
@@ -76,9 +82,10 @@ class Comm:
 
     def gather_padded(self, t, sizes, root):
         """Like all_gather_padded, but only `root` receives (others get None)."""
-        if self.world == 1:
+        if self.local_only:
             return [t[:sizes[0]]]
         t0 = time.perf_counter()
+        self.calls["gather"] = self.calls.get("gather", 0) + 1
         m = max(sizes)
         mine = t if t.numel() == m else torch.cat([t[:sizes[self.rank]], t.new_zeros(m - sizes[self.rank])])
         mine = self._out(mine)
@@ -93,9 +100,10 @@ class Comm:
         return res
 
     def all_reduce(self, t, op):
-        if self.world == 1:
+        if self.local_only:
             return t
         t0 = time.perf_counter()
+        self.calls["all_reduce_" + op] = self.calls.get("all_reduce_" + op, 0) + 1
         x = self._out(t)
         self.dist.all_reduce(x, op=getattr(self.dist.ReduceOp, op), group=self.group)
         if self.stage:
@@ -155,7 +163,7 @@ def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False):
         del parts, mine
         # degree slices of all ranks
         N = lib.ac_shard_distinct_count(h)
-        if comm.world > 1:
+        if not comm.local_only:
             bounds = [N * r // comm.world for r in range(comm.world + 1)]
             dsz = [bounds[r + 1] - bounds[r] for r in range(comm.world)]
             dmine = torch.empty(max(dsz[comm.rank], 1), dtype=torch.int32, device=dev)
@@ -174,10 +182,10 @@ def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False):
         _check(lib, lib.ac_shard_reduce_import(h, C.c_void_p(red.data_ptr()), C.c_void_p(red.data_ptr() + 12 * U)))
         g = C.c_void_p()
         is_root = comm.rank == root
-        want = (1 if is_root else 0) | (0 if (gather_paths and comm.world > 1) else 2)
+        want = (1 if is_root else 0) | (0 if (gather_paths and not comm.local_only) else 2)
         _check(lib, lib.ac_shard_finish(h, C.c_int(want), C.byref(g)))
         graph = _capi.Graph(lib, g, shard.n_seqs)
-        if gather_paths and comm.world > 1:      # paths of all sequences -> root
+        if gather_paths and not comm.local_only:      # paths of all sequences -> root
             ne = lib.ac_shard_path_entries(h)
             psz = comm.all_gather_sizes([ne, shard.n_seqs])
             ent = torch.empty(max(ne, 1), dtype=torch.int32, device=dev)

@@ -70,6 +70,12 @@ typedef struct {
 int ac_compress_build(uint32_t k, uint32_t assembly_count, const ac_seq_view* seqs, uint32_t n_seqs, int device,
                       ac_graph** out);
 
+/* The 2-bit packing the host entry applies before the upload (sequence.rs:39-48 validates the same alphabet): n_text bytes ->
+ * (n_text + 31) / 32 words of 2-bit codes (A, C, G, T = 0..3, first base most significant) and as many 32-bit mask words
+ * (bit i = byte i is not a base).  force_scalar != 0 selects the portable loop instead of the AVX2 / BMI2 one (both are
+ * tested against each other and against the device kernel). */
+int ac_pack_text(const uint8_t* text, uint64_t n_text, uint64_t* bits, uint32_t* mask32, int force_scalar);
+
 /* Same, for a text that is already resident in device memory (benchmarks, multi-GPU shards):
  * d_text[0] = '$', then for every sequence its padded bytes followed by one '$'; n_text bytes in total.
  * seq_off[s] = index of the first padded byte of sequence s (host array). */

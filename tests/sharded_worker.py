@@ -1,6 +1,8 @@
 """One rank of a multi-process sharded build (launched by the tests, one process per rank; gloo on CPU, or two ranks
 sharing the one GPU of the test box with gloo staging).  Usage:
-    python sharded_worker.py RANK WORLD PORT LIB_PATH DEVICE CASES     CASES = "k:seed,k:seed,...", "synth:k", "mixed:k" or "big:assemblies:genome"
+    python sharded_worker.py RANK WORLD PORT LIB_PATH DEVICE CASES [BACKEND]     CASES = "k:seed,k:seed,...", "synth:k", "mixed:k" or "big:assemblies:genome"
+BACKEND (default gloo): "nccl" = RCCL; with WORLD = 1 every collective is still issued (Comm(always_collective=True)), which is how the
+one-GPU test box exercises the RCCL calls of autocycler_amd/sharded.py on device tensors.
 """
 import os
 import sys
@@ -51,9 +53,15 @@ def big_case(lib_path, n_asm, genome, dev, rank, world):
 def main():
     rank, world, port, lib_path, device, cases = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    backend = sys.argv[7] if len(sys.argv) > 7 else "gloo"
     import torch
     import torch.distributed as dist
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(torch.device(device))
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(device))
+    else:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     import seqgen
     import sharded_util
     from autocycler_amd import sharded
@@ -92,13 +100,16 @@ def main():
         if len(seqs) < world:
             continue
         for repair, gather in ((True, True), (False, False)):
-            comm = sharded.Comm(dev)
+            comm = sharded.Comm(dev, always_collective=(backend == "nccl"))
             sharded_util.run_case(lib_path, k, seqs, fn, hd, comm, dev, repair=repair, device_index=dev.index or 0,
                                   gather_paths=gather)
+            if backend == "nccl":
+                for name in ("all_gather_into_tensor", "all_reduce_SUM", "all_reduce_MIN") + (("gather",) if gather else ()):
+                    assert comm.calls.get(name, 0) > 0, f"collective {name} was not issued"
         done += 1
     dist.barrier()
     dist.destroy_process_group()
-    print(f"rank {rank}: {done} cases OK")
+    print(f"rank {rank}: {done} cases OK ({backend})")
 
 
 if __name__ == "__main__":

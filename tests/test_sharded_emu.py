@@ -45,10 +45,10 @@ def _free_port():
     return str(p)
 
 
-def launch(world, lib_path, device, cases, timeout=600):
+def launch(world, lib_path, device, cases, timeout=600, backend="gloo"):
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, str(ROOT / "tests" / "sharded_worker.py"), str(r), str(world), port, str(lib_path),
-                               device, cases], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+                               device, cases, backend], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     try:
         for p in procs:

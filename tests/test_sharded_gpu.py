@@ -53,3 +53,13 @@ def test_two_ranks_realistic_size(lib_path):
     # 12 assemblies of a 2 Mbp genome split over two ranks == the single-device build of the same 12
     outs = launch(2, lib_path, "cuda:0", "big:12:2000000", timeout=900)
     assert "big case" in outs[0]
+
+
+def test_rccl_collectives_world_of_one(lib_path):
+    """Every collective autocycler_amd/sharded.py issues — all_gather_into_tensor (uint8 fragments, int32 degree slices, int64 sizes),
+    all_reduce SUM and MIN (int32), gather (int32 paths, int64 records) — through the nccl backend (= RCCL) on device tensors, in a
+    world of one rank on the test box's single MI355X, with the result checked against the oracle: RCCL is not first exercised on
+    the multi-GPU node.  Multi-rank RCCL itself stays unmeasured until a node with several GPUs runs bench.py."""
+    cases = ",".join(f"{k}:{seed}" for k in (11, 51) for seed in range(6)) + ",synth:51,mixed:51"
+    outs = launch(1, lib_path, "cuda:0", cases, timeout=900, backend="nccl")
+    assert "(nccl)" in outs[0]

@@ -92,6 +92,23 @@ static void validate(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs) {
     }
 }
 
+// The device entries take the text layout from the caller: check it before any kernel indexes the text with it (the header
+// promises errors, not faults).  off[i] = first padded byte of sequence i; every padded sequence is followed by one separator.
+static void validate_layout(uint32_t k, uint64_t n_text, const uint64_t* off, const uint32_t* len, const uint16_t* d1, const uint16_t* d2,
+                            uint32_t n_seqs) {
+    if (k < 1 || k % 2 == 0) throw DeviceError("--kmer must be odd");
+    if (!off || !len || !d1 || !d2) throw DeviceError("null sequence table");
+    uint64_t prev_end = 0;      // index of the separator before the next sequence
+    for (uint32_t i = 0; i < n_seqs; i++) {
+        if (len[i] < k) throw DeviceError("sequence " + std::to_string(i + 1) + " is shorter than k");
+        const uint64_t plen = (uint64_t)len[i] + k - 1;
+        if (off[i] < prev_end + 1) throw DeviceError("sequence table: offset of sequence " + std::to_string(i + 1) + " overlaps the previous sequence or its separator");
+        if (off[i] + plen + 1 > n_text) throw DeviceError("sequence table: sequence " + std::to_string(i + 1) + " runs past the end of the text");
+        if (d1[i] > k - 1 || d2[i] > k - 1 || (uint32_t)d1[i] + d2[i] > k - 1) throw DeviceError("sequence table: more padding dots than k - 1 on sequence " + std::to_string(i + 1));
+        prev_end = off[i] + plen;
+    }
+}
+
 // compress.rs:42-44 behind the ABI: one device pipeline from the packed text to the final UnitigGraph.
 static void build_graph(GraphBuilder& b, uint32_t assembly_count, ac_graph* h) {
     b.build(assembly_count, &h->g);
@@ -187,6 +204,7 @@ int ac_compress_build_device(uint32_t k, uint32_t assembly_count, const void* d_
     return guarded([&] {
         if (!d_text || n_seqs == 0) throw DeviceError("no sequences found in input assemblies");
         if (n_seqs > 32767) throw DeviceError("no more than 32767 input sequences are allowed");
+        validate_layout(k, n_text, seq_off, seq_len, seq_d1, seq_d2, n_seqs);
         std::lock_guard<std::mutex> lock(g_build_mutex);
         if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
         select_device(device);
@@ -218,6 +236,7 @@ int ac_shard_begin(uint32_t k, uint32_t local_assembly_count, const void* d_text
     return guarded([&] {
         if (!d_text || n_seqs == 0) throw DeviceError("no sequences found in input assemblies");
         if (n_seqs > 32767) throw DeviceError("no more than 32767 input sequences are allowed");
+        validate_layout(k, n_text, seq_off, seq_len, seq_d1, seq_d2, n_seqs);
         std::lock_guard<std::mutex> lock(g_build_mutex);
         if (g_live_shards) throw DeviceError("another sharded build is in flight in this process");
         select_device(device);
@@ -372,6 +391,7 @@ int ac_end_repair_device(uint32_t k, void* d_text, uint64_t n_text, const uint64
                          uint16_t* seq_d1, uint16_t* seq_d2, uint32_t n_seqs, int device, double* seconds, uint64_t* n_matches) {
     return guarded([&] {
         if (!d_text || n_seqs == 0) throw DeviceError("no sequences found in input assemblies");
+        validate_layout(k, n_text, seq_off, seq_len, seq_d1, seq_d2, n_seqs);
         std::lock_guard<std::mutex> lock(g_build_mutex);
         if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
         select_device(device);

@@ -304,6 +304,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static u64 upload_threads() { const char* e = getenv("AC_UPLOAD_THREADS"); long x = e ? atol(e) : 16; return (u64)(x < 1 ? 1 : (x > 128 ? 128 : x)); }   // host threads laying out / packing the text (the byte upload uses at most 8)
 [[maybe_unused]] static bool host_pack() { const char* e = getenv("AC_HOST_PACK"); return e ? atoi(e) != 0 : true; }      // 0: upload the text as bytes and pack on the device
 [[maybe_unused]] static bool insert_profile() { static const bool v = getenv("AC_INSERT_PROFILE") != nullptr; return v; }      // measurement only
+[[maybe_unused]] static bool expand_rewrite_always() { return getenv("AC_EXPAND_REWRITE_ALWAYS") != nullptr; }      // tests: compact the expand pool after every host check
 [[maybe_unused]] static bool insert_adaptive() { const char* e = getenv("AC_INSERT_ADAPT"); return e ? atoi(e) != 0 : true; }
 [[maybe_unused]] static u64 insert_growth() { const char* e = getenv("AC_INSERT_GROWTH"); long x = e ? atol(e) : 2; return (u64)(x < 2 ? 2 : x); }      // phase i+1 ends at growth x the end of phase i
 [[maybe_unused]] static u64 insert_waves_target() { const char* e = getenv("AC_INSERT_WAVES"); long x = e ? atol(e) : 16384; return (u64)(x < 1024 ? 1024 : x); }   // wavefronts a long phase is cut into
@@ -773,22 +774,12 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             ExpState e{cur, coff.ptr(), clen.ptr(), pre_off.ptr(), pre_len.ptr(), post_off.ptr(), post_len.ptr(), pool.ptr(),
                        pool_used.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), dirty.ptr(), cand.ptr(), L, shifted.ptr()};
             pool_used.fill_bytes(0);
-            u64 moved = 0;
+            u64 moved = 0, moved_since_rewrite = 0;
             DBuf<u64> shifted2(2);
-            for (;;) {   // two passes per host check: if the first moved nothing the second is an (uncounted) no-op
-                shifted2.fill_bytes(0);
-                for (int half = 0; half < 2; half++) {
-                    e.shifted = shifted2.ptr() + half;
-                    for (u32 lv = 1; lv <= n_levels; lv++)
-                        launch_full((u64)(hb[lv + 1] - hb[lv]), ExpandFunctor{e, clist.ptr(), (u64)hb[lv], (u32)pool.size(), counters.ptr() + 7});
-                }
-                std::vector<u64> sh = to_host(shifted2, 2);
-                moved += sh[0] + sh[1];
-                if (sh[0] == 0) { passes += 1; break; }
-                passes += 2;
-                if (sh[1] == 0) break;
-            }
-            if (moved) {   // rewrite the sequences contiguously, once
+            // Rewrites the sequences contiguously (gained pieces folded into the core views) and empties the pool.  Once after the
+            // last pass — and in between whenever the pool is a quarter full: a side that gains again gets a new piece holding its
+            // old one as well, so without this the pool use of a many-pass input grows with the square of the passes.
+            auto rewrite = [&] {
                 launch((u64)U + 1, ExpLenFunctor{e, len64.ptr(), U});
                 exclusive_scan_u64(len64.ptr(), noff.ptr(), (u64)U + 1);
                 final_total = read_scalar(noff.ptr() + U);
@@ -796,7 +787,32 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                 launch(U, ExpResetFunctor{e, noff.ptr()});
                 std::swap(cur, alt);
                 e.cur = cur;
+                pool_used.fill_bytes(0);
+                moved_since_rewrite = 0;
+            };
+            const u32 pool_limit = (u32)(pool.size() / 4);
+            for (;;) {   // two passes per host check: if the first moved nothing the second is an (uncounted) no-op
+                shifted2.fill_bytes(0);
+                for (int half = 0; half < 2; half++) {
+                    e.shifted = shifted2.ptr() + half;
+                    for (u32 lv = 1; lv <= n_levels; lv++)
+                        launch_full((u64)(hb[lv + 1] - hb[lv]), ExpandFunctor{e, clist.ptr(), (u64)hb[lv], (u32)pool.size(), counters.ptr() + 7});
+                }
+                u64 sh[2]; u32 used = 0;
+                {
+                    ReadBatch rb;
+                    rb.add(sh, shifted2.ptr(), 16);
+                    rb.add(&used, pool_used.ptr(), 4);
+                    rb.run();
+                }
+                moved += sh[0] + sh[1]; moved_since_rewrite += sh[0] + sh[1];
+                if (sh[0] == 0) { passes += 1; break; }
+                passes += 2;
+                if (sh[1] == 0) break;
+                if (used > pool_limit || expand_rewrite_always()) rewrite();
             }
+            if (moved_since_rewrite) rewrite();
+            (void)moved;
         }
     }
     tm->simplify_passes = (u32)passes; tm->n_candidates = n_cand; tm->n_levels = n_levels;
@@ -1093,6 +1109,39 @@ void pack_text_host(const uint8_t* text, uint64_t n_text, uint64_t* bits, uint32
     }
 }
 
+// Packs the groups [g0, g1) of the text layout of `seqs` (group g = text bytes 32 g .. 32 g + 31; bytes beyond the text read as
+// separators).  Groups that lie inside one padded sequence — all but two or three per sequence — are packed straight from the
+// caller's buffer; only the groups that touch a separator are assembled in a 32-byte scratch first.
+static void pack_text_groups(const std::vector<SeqView>& seqs, const std::vector<uint64_t>& off, uint32_t k, u64 n_text, u64 g0, u64 g1,
+                             u64* bits, u32* mask) {
+    const u64 b = g0 * 32;
+    // first sequence whose span [off, off + plen] (the '$' after it included) ends after b
+    size_t lo = 0, hi = seqs.size();
+    while (lo < hi) { size_t mid = (lo + hi) / 2; if (off[mid] + (u64)seqs[mid].length + k - 1 + 1 <= b) lo = mid + 1; else hi = mid; }
+    size_t i = lo;
+    u64 g = g0;
+    auto slow = [&](u64 gg) {      // a group with a separator (or the text's end) in it
+        u8 tmp[32];
+        const u64 tb = gg * 32, te = std::min(n_text, tb + 32);
+        if (tb < te) fill_text_range(seqs, off, k, tb, te, tmp);
+        for (u64 j = te > tb ? te - tb : 0; j < 32; j++) tmp[j] = '$';
+        pack_groups(tmp, 1, bits + (gg - g0), mask + (gg - g0));
+    };
+    while (g < g1) {
+        while (i < seqs.size() && off[i] + (u64)seqs[i].length + k - 1 <= g * 32) i++;      // sequence i ends at or before this group's start
+        if (i >= seqs.size()) { slow(g++); continue; }
+        const u64 s0 = off[i], s1 = s0 + (u64)seqs[i].length + k - 1;      // padded bytes of sequence i: [s0, s1)
+        if (g * 32 < s0) { slow(g++); continue; }
+        const u64 g_in = std::min(g1, s1 / 32);      // groups [g, g_in) lie wholly inside [s0, s1)
+        if (g_in > g) {
+            pack_groups(seqs[i].fwd + (g * 32 - s0), g_in - g, bits + (g - g0), mask + (g - g0));
+            g = g_in;
+        } else {
+            slow(g++);
+        }
+    }
+}
+
 // Final (end-repaired) sequences: the text never reaches the device as bytes.  Host threads lay a piece of the text out in a
 // cache-resident buffer, pack it (K1 above) straight into a pinned slot, and whoever finishes a 64 MB chunk sends its 16 MB of
 // codes and 8 MB of mask bits: 0.375 bytes per base cross PCIe instead of 1 (config C: 183 MB in ~3.5 ms instead of 487 MB in ~9).
@@ -1111,12 +1160,9 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
     [[maybe_unused]] auto slot_mask = [&](int sl) { return (u32*)(st.slot(0) + (u64)sl * SLOT_BYTES + CH / 4); };
 #ifdef AC_EMU
     loc.pack_alloc();
-    std::vector<u8> tmp(SUB + 64);
     for (u64 b = 0; b < n; b += SUB) {
-        const u64 e = std::min(n, b + SUB), groups = (e - b + 31) / 32;
-        fill_text_range(seqs, off, k, b, e, tmp.data());
-        for (u64 i = e - b; i < groups * 32; i++) tmp[i] = '$';
-        pack_groups(tmp.data(), groups, loc.bits.ptr() + b / 32, (u32*)loc.mask.ptr() + b / 32);
+        const u64 e = std::min(n, b + SUB);
+        pack_text_groups(seqs, off, k, n, b / 32, (e + 31) / 32, loc.bits.ptr() + b / 32, (u32*)loc.mask.ptr() + b / 32);
     }
 #else
     int dev = 0;
@@ -1142,7 +1188,6 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
     auto worker = [&] {
         try {
             AC_HIP_CHECK(hipSetDevice(dev));
-            std::vector<u8> tmp(SUB + 64);
             for (u64 item; (item = next.fetch_add(1)) < n_chunks * subs && !stop.load();) {
                 const u64 c = item / subs, sub = item % subs;
                 const u64 clen = chunk_len(c);
@@ -1159,10 +1204,8 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
                     }
                     if (stop.load()) break;
                 }
-                const u64 b = c * CH + sub * SUB, e = std::min(c * CH + clen, b + SUB), groups = (e - b + 31) / 32;
-                fill_text_range(seqs, off, k, b, e, tmp.data());
-                for (u64 i = e - b; i < groups * 32; i++) tmp[i] = '$';
-                pack_groups(tmp.data(), groups, slot_bits(sl) + sub * SUB / 32, slot_mask(sl) + sub * SUB / 32);
+                const u64 b = c * CH + sub * SUB, e = std::min(c * CH + clen, b + SUB);
+                pack_text_groups(seqs, off, k, n, b / 32, (e + 31) / 32, slot_bits(sl) + sub * SUB / 32, slot_mask(sl) + sub * SUB / 32);
                 const u32 n_sub = (u32)((clen + SUB - 1) / SUB);
                 if (done[c].fetch_add(1, std::memory_order_acq_rel) + 1 == n_sub) {      // the chunk is complete: send it
                     const u64 g0 = c * CH / 32, ng = (clen + 31) / 32;

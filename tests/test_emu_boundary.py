@@ -58,3 +58,33 @@ def test_host_pack_simd_equals_scalar(emu):
         want_bits = (code << (62 - 2 * np.arange(32, dtype=np.uint64))).sum(axis=1, dtype=np.uint64)
         want_mask = ((~good).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(axis=1).astype(np.uint32)
         assert np.array_equal(outs[0][0], want_bits) and np.array_equal(outs[0][1], want_mask)
+
+
+def test_device_entry_rejects_a_bad_sequence_table(emu):
+    """ac_compress_build_device / ac_shard_begin / ac_end_repair_device index the text with the caller's table — a table
+    that does not describe the text must come back as an error (never a fault or a silent wrong graph)."""
+    import ctypes as C
+    import numpy as np
+    lib = _capi.load_library(emu)
+    k = 11
+    seqs = ["ACGTTGCATGCATGGCATCGATCGGCTA", "GGCATCGATCGGCTAACGTTGCATGCAT"]
+    text = ("$" + "$".join("." * 5 + s + "." * 5 for s in seqs) + "$").encode()
+    buf = np.frombuffer(text, dtype=np.uint8).copy()
+    good_off = [1, 1 + len(seqs[0]) + 10 + 1]
+    lens = [len(s) for s in seqs]
+
+    def run(off, ln, d1=(5, 5), d2=(5, 5), n_text=len(text)):
+        g = C.c_void_p()
+        rc = lib.ac_compress_build_device(C.c_uint32(k), C.c_uint32(2), buf.ctypes.data_as(C.c_void_p), C.c_uint64(n_text), (C.c_uint64 * 2)(*off),
+                                          (C.c_uint32 * 2)(*ln), (C.c_uint16 * 2)(1, 2), (C.c_uint16 * 2)(*d1), (C.c_uint16 * 2)(*d2), C.c_uint32(2),
+                                          C.c_int(0), C.byref(g))
+        if rc == 0:
+            lib.ac_free(g)
+        return rc, lib.ac_last_error().decode()
+    assert run(good_off, lens)[0] == 0
+    assert "shorter than k" in run(good_off, [5, lens[1]])[1]
+    assert "overlaps" in run([1, 20], lens)[1]
+    assert "overlaps" in run([0, good_off[1]], lens)[1]
+    assert "past the end" in run(good_off, [lens[0], lens[1] + 3])[1]
+    assert "past the end" in run(good_off, lens, n_text=len(text) - 2)[1]
+    assert "padding dots" in run(good_off, lens, d1=(11, 5))[1]

@@ -36,7 +36,7 @@ def main(fetch_csv, write_csv, n_text, tag):
     print(json.dumps({
         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), python bench.py --steps 2 "
                   f"--warmup 1 --no-cpu-baseline on MI355X; profiles/{tag}_pmc_*_configC.csv",
-        "kernel": "insert_wave_kernel<2> (8 phase launches per build, summed)",
+        "kernel": "insert_wave_kernel<2> (3 phase launches per build, summed)",
         "fetch_size_raw_bytes": kf, "write_size_raw_bytes": kw,
         "calibration": {"kernel": "functor_kernel<PackFunctor>: reads n_text bytes with 16 B/lane loads, writes 0.375*n_text bytes",
                         "n_text": n_text, "fetch_raw_over_known": fcal, "write_raw_over_known": wcal},

@@ -305,6 +305,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static bool host_pack() { const char* e = getenv("AC_HOST_PACK"); return e ? atoi(e) != 0 : true; }      // 0: upload the text as bytes and pack on the device
 [[maybe_unused]] static bool insert_profile() { static const bool v = getenv("AC_INSERT_PROFILE") != nullptr; return v; }      // measurement only
 [[maybe_unused]] static bool expand_rewrite_always() { return getenv("AC_EXPAND_REWRITE_ALWAYS") != nullptr; }      // tests: compact the expand pool after every host check
+[[maybe_unused]] static u64 expand_wave_limit() { const char* e = getenv("AC_EXPAND_WAVE_LIMIT"); return e ? (u64)atoll(e) : 65536; }      // junctions per level from which expand_repeats runs a thread (not a wavefront) per junction
 [[maybe_unused]] static bool insert_adaptive() { const char* e = getenv("AC_INSERT_ADAPT"); return e ? atoi(e) != 0 : true; }
 [[maybe_unused]] static u64 insert_growth() { const char* e = getenv("AC_INSERT_GROWTH"); long x = e ? atol(e) : 2; return (u64)(x < 2 ? 2 : x); }      // phase i+1 ends at growth x the end of phase i
 [[maybe_unused]] static u64 insert_waves_target() { const char* e = getenv("AC_INSERT_WAVES"); long x = e ? atol(e) : 16384; return (u64)(x < 1024 ? 1024 : x); }   // wavefronts a long phase is cut into
@@ -725,8 +726,8 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     DBuf<u32> clen(U), pre_off(U, true), pre_len(U, true), post_off(U, true), post_len(U, true);
     copy_d2d(coff.ptr(), useq_off.ptr(), (size_t)U * 8);
     copy_d2d(clen.ptr(), ulen.ptr(), (size_t)U * 4);
-    DBuf<u8> seq_alt(total), pool(std::min<u64>(2 * total + 4096, 0xFFFFFFF0ULL)), dirty((u64)U * 2);
-    DBuf<u64> shifted(1); DBuf<u32> pool_used(1);
+    DBuf<u8> seq_alt(total), pool(std::min<u64>(8 * total + (1u << 20), 0xFFFFFFF0ULL)), dirty((u64)U * 2);
+    DBuf<u64> shifted(1); DBuf<u32> pool_used(EXP_SUBPOOLS + 1);
     copy_d2d(dirty.ptr(), cand.ptr(), (size_t)U * 2);
     u8* cur = useq.ptr(); u8* alt = seq_alt.ptr();
     u64 final_total = total;
@@ -790,26 +791,47 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                 pool_used.fill_bytes(0);
                 moved_since_rewrite = 0;
             };
-            const u32 pool_limit = (u32)(pool.size() / 4);
+            const u32 sub_limit = (u32)(pool.size() / 2 / EXP_SUBPOOLS / 2);      // a region half full (or anything in the overflow half) asks for a rewrite
             for (;;) {   // two passes per host check: if the first moved nothing the second is an (uncounted) no-op
                 shifted2.fill_bytes(0);
                 for (int half = 0; half < 2; half++) {
                     e.shifted = shifted2.ptr() + half;
-                    for (u32 lv = 1; lv <= n_levels; lv++)
-                        launch_full((u64)(hb[lv + 1] - hb[lv]), ExpandFunctor{e, clist.ptr(), (u64)hb[lv], (u32)pool.size(), counters.ptr() + 7});
+                    for (u32 lv = 1; lv <= n_levels; lv++) {
+                        const u64 cnt = (u64)(hb[lv + 1] - hb[lv]);
+                        if (cnt == 0) continue;
+#ifdef AC_EMU
+                        launch_full(cnt, ExpandFunctor{e, clist.ptr(), (u64)hb[lv], (u32)pool.size(), counters.ptr() + 7});
+#else
+                        // a wavefront per junction while a level is small (its time is one junction's dependency chain); a thread per
+                        // junction when a level has so many that the lanes are better spent on different junctions (mixed-species
+                        // inputs: a million short shifts per level)
+                        if (cnt >= expand_wave_limit()) {
+                            launch_full(cnt, ExpandFunctor{e, clist.ptr(), (u64)hb[lv], (u32)pool.size(), counters.ptr() + 7});
+                            continue;
+                        }
+                        const u64 blocks = (cnt + 3) / 4;
+                        if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+                        flush_fills();
+                        hipLaunchKernelGGL(expand_wave_kernel<W>, dim3((unsigned)blocks), dim3(256), 0, 0, e, clist.ptr(), (u64)hb[lv], cnt, (u32)pool.size(), counters.ptr() + 7);
+                        AC_HIP_CHECK(hipGetLastError());
+#endif
+                    }
                 }
                 u64 sh[2]; u32 used = 0;
                 {
+                    std::vector<u32> pu(EXP_SUBPOOLS + 1);
                     ReadBatch rb;
                     rb.add(sh, shifted2.ptr(), 16);
-                    rb.add(&used, pool_used.ptr(), 4);
+                    rb.add(pu.data(), pool_used.ptr(), (EXP_SUBPOOLS + 1) * 4);
                     rb.run();
+                    for (u32 q = 0; q < EXP_SUBPOOLS; q++) used = std::max(used, pu[q]);
+                    if (pu[EXP_SUBPOOLS]) used = 0xFFFFFFFFu;
                 }
                 moved += sh[0] + sh[1]; moved_since_rewrite += sh[0] + sh[1];
                 if (sh[0] == 0) { passes += 1; break; }
                 passes += 2;
                 if (sh[1] == 0) break;
-                if (used > pool_limit || expand_rewrite_always()) rewrite();
+                if (used > sub_limit || expand_rewrite_always()) rewrite();
             }
             if (moved_since_rewrite) rewrite();
             (void)moved;

@@ -55,7 +55,8 @@ EXPORTS = ["ac_compress_build", "ac_compress_build_device", "ac_pack_text", "ac_
            "ac_path", "ac_timings_get", "ac_free", "ac_gfa_string", "ac_string_free", "ac_last_error",
            "ac_device_count", "ac_max_kmer", "ac_version", "ac_set_stage_timing", "ac_random_access_ceilings", "ac_release_memory", "ac_end_repair_device", "ac_pairwise_distances", "ac_graph_from_gfa", "ac_graph_kmer_size", "ac_graph_seq_info", "ac_decompress_seq", "ac_decompress",
            "ac_shard_begin", "ac_shard_fragment_sizes", "ac_shard_fragments_export", "ac_shard_build_union",
-           "ac_shard_unitig_count", "ac_shard_local_distinct", "ac_shard_set_distinct_upper_bound", "ac_shard_distinct_count", "ac_shard_degrees_export", "ac_shard_build_graph", "ac_gfa_string_parts", "ac_shard_reduce_export", "ac_shard_reduce_import", "ac_shard_finish",
+           "ac_shard_unitig_count", "ac_shard_table_capacity", "ac_shard_bitmap_words", "ac_shard_bitmap_export", "ac_shard_build_novel", "ac_shard_links_export", "ac_shard_links_import",
+           "ac_shard_query_count", "ac_shard_query_key_words", "ac_shard_queries_export", "ac_shard_answer", "ac_shard_walk", "ac_shard_local_distinct", "ac_shard_set_distinct_upper_bound", "ac_shard_distinct_count", "ac_shard_degrees_export", "ac_shard_build_graph", "ac_gfa_string_parts", "ac_shard_reduce_export", "ac_shard_reduce_import", "ac_shard_finish",
            "ac_shard_path_entries", "ac_shard_paths_export", "ac_shard_free", "ac_graph_set_paths", "ac_graph_seq_count", "ac_path_counts",
            "ac_seqs_load", "ac_seqs_from_raw", "ac_seqs_count", "ac_seqs_assembly_count", "ac_seqs_views", "ac_seqs_get",
            "ac_seqs_repair_seconds", "ac_seqs_metrics_yaml", "ac_seqs_free", "ac_compress_seqs", "ac_compress_dir"]
@@ -110,6 +111,11 @@ def load_library(path=None):
     lib.ac_shard_path_entries.restype = C.c_uint64
     lib.ac_shard_path_entries.argtypes = [C.c_void_p]
     lib.ac_shard_free.argtypes = [C.c_void_p]
+    for name in ("ac_shard_table_capacity", "ac_shard_bitmap_words", "ac_shard_query_count"):
+        getattr(lib, name).restype = C.c_uint64
+        getattr(lib, name).argtypes = [C.c_void_p]
+    lib.ac_shard_query_key_words.restype = C.c_uint32
+    lib.ac_shard_query_key_words.argtypes = [C.c_void_p]
     lib.ac_graph_seq_count.restype = C.c_uint32
     lib.ac_graph_seq_count.argtypes = [C.c_void_p]
     _libs[key] = lib

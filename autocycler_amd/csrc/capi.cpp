@@ -227,7 +227,9 @@ struct ac_shard {
     std::vector<uint16_t> seq_ids;
     std::vector<uint32_t> seq_lens;
     int device = 0;
-    int phase = 0;   // 1 = fragments ready, 2 = union graph + walk done, 3 = reduced quantities imported, 4 = finished
+    uint32_t n_shards = 1;
+    int phase = 0;   // 1 fragments ready, 2 owned k-mers inserted, 3 novel list + degree words, 4 unitigs + link words, 5 links complete + walk
+                     // queries ready, 6 walked, 7 reduced quantities imported, 8 finished
 };
 
 int ac_shard_begin(uint32_t k, uint32_t local_assembly_count, const void* d_text, uint64_t n_text, const uint64_t* seq_off,
@@ -277,31 +279,98 @@ int ac_shard_build_union(ac_shard* s, uint32_t rank, uint32_t n_shards, const vo
         std::lock_guard<std::mutex> lock(g_build_mutex);
         select_device(s->device);
         s->b->shard_build_union(rank, n_shards, (const uint8_t*)d_union_text, n_union_text, d_meta, n_fragments_total);
+        s->n_shards = n_shards;
         s->phase = 2;
     });
 }
+uint64_t ac_shard_bitmap_words(const ac_shard* s) { return s->phase >= 2 ? s->b->bitmap_words() : 0; }
+int ac_shard_bitmap_export(ac_shard* s, void* d_out_u64) {
+    return guarded([&] {
+        if (s->phase != 2) throw DeviceError("ac_shard_bitmap_export: wrong phase");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->bitmap_export(d_out_u64);
+    });
+}
+int ac_shard_build_novel(ac_shard* s, const void* d_bitmap_sum_u64) {
+    return guarded([&] {
+        if (s->phase != 2) throw DeviceError("ac_shard_build_novel: wrong phase");
+        if (!d_bitmap_sum_u64 && s->n_shards > 1) throw DeviceError("ac_shard_build_novel: the summed bitmap is required when there are several shards");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->shard_build_novel(d_bitmap_sum_u64);
+        s->phase = 3;
+    });
+}
 uint64_t ac_shard_distinct_count(const ac_shard* s) { return s->b->distinct_count(); }
+uint64_t ac_shard_table_capacity(const ac_shard* s) { return s->b->timings().table_capacity; }
 int ac_shard_degrees_export(ac_shard* s, void* d_out_u32) {
     return guarded([&] {
-        if (s->phase != 2) throw DeviceError("ac_shard_degrees_export: wrong phase");
+        if (s->phase != 3) throw DeviceError("ac_shard_degrees_export: wrong phase");
         std::lock_guard<std::mutex> lock(g_build_mutex);
         select_device(s->device);
         s->b->degrees_export(d_out_u32);
     });
 }
-int ac_shard_build_graph(ac_shard* s, const void* d_degrees_all_u32) {
+int ac_shard_build_graph(ac_shard* s, const void* d_degrees_sum_u32) {
     return guarded([&] {
-        if (s->phase != 2) throw DeviceError("ac_shard_build_graph: wrong phase");
+        if (s->phase != 3) throw DeviceError("ac_shard_build_graph: wrong phase");
+        if (!d_degrees_sum_u32 && s->n_shards > 1) throw DeviceError("ac_shard_build_graph: the summed degree words are required when there are several shards");
         std::lock_guard<std::mutex> lock(g_build_mutex);
         select_device(s->device);
-        s->b->shard_build_graph(d_degrees_all_u32);
-        s->phase = 3;
+        s->b->shard_build_graph(d_degrees_sum_u32);
+        s->phase = 4;
     });
 }
 uint32_t ac_shard_unitig_count(const ac_shard* s) { return s->b->unitig_count(); }
+int ac_shard_links_export(ac_shard* s, void* d_links_i32, void* d_wlinks_i64) {
+    return guarded([&] {
+        if (s->phase != 4) throw DeviceError("ac_shard_links_export: wrong phase");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->links_export(d_links_i32, d_wlinks_i64);
+    });
+}
+int ac_shard_links_import(ac_shard* s, const void* d_links_i32, const void* d_wlinks_i64) {
+    return guarded([&] {
+        if (s->phase != 4) throw DeviceError("ac_shard_links_import: wrong phase");
+        if ((!d_links_i32 || !d_wlinks_i64) && s->n_shards > 1) throw DeviceError("ac_shard_links_import: the summed link words are required when there are several shards");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->links_import(d_links_i32, d_wlinks_i64);
+        s->phase = 5;
+    });
+}
+uint64_t ac_shard_query_count(const ac_shard* s) { return s->phase >= 5 ? s->b->query_count() : 0; }
+uint32_t ac_shard_query_key_words(const ac_shard* s) { return s->b->query_key_words(); }
+int ac_shard_queries_export(ac_shard* s, void* d_out_u64) {
+    return guarded([&] {
+        if (s->phase != 5) throw DeviceError("ac_shard_queries_export: wrong phase");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->queries_export(d_out_u64);
+    });
+}
+int ac_shard_answer(ac_shard* s, const void* d_keys_u64, uint64_t n_queries, void* d_out_u64) {
+    return guarded([&] {
+        if (s->phase != 5) throw DeviceError("ac_shard_answer: wrong phase");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->answer_queries(d_keys_u64, n_queries, d_out_u64);
+    });
+}
+int ac_shard_walk(ac_shard* s, const void* d_answers_u64) {
+    return guarded([&] {
+        if (s->phase != 5) throw DeviceError("ac_shard_walk: wrong phase");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->shard_walk(d_answers_u64);
+        s->phase = 6;
+    });
+}
 int ac_shard_reduce_export(ac_shard* s, void* d_sum_i32, void* d_min_i32) {
     return guarded([&] {
-        if (s->phase != 3) throw DeviceError("ac_shard_reduce_export: wrong phase");
+        if (s->phase != 6) throw DeviceError("ac_shard_reduce_export: wrong phase");
         std::lock_guard<std::mutex> lock(g_build_mutex);
         select_device(s->device);
         s->b->reduce_export((int32_t*)d_sum_i32, (int32_t*)d_min_i32);
@@ -309,16 +378,16 @@ int ac_shard_reduce_export(ac_shard* s, void* d_sum_i32, void* d_min_i32) {
 }
 int ac_shard_reduce_import(ac_shard* s, const void* d_sum_i32, const void* d_min_i32) {
     return guarded([&] {
-        if (s->phase != 3) throw DeviceError("ac_shard_reduce_import: wrong phase");
+        if (s->phase != 6) throw DeviceError("ac_shard_reduce_import: wrong phase");
         std::lock_guard<std::mutex> lock(g_build_mutex);
         select_device(s->device);
         s->b->reduce_import((const int32_t*)d_sum_i32, (const int32_t*)d_min_i32);
-        s->phase = 4;
+        s->phase = 7;
     });
 }
 int ac_shard_finish(ac_shard* s, int want, ac_graph** out) {
     return guarded([&] {
-        if (s->phase != 4) throw DeviceError("ac_shard_finish: wrong phase");
+        if (s->phase != 7) throw DeviceError("ac_shard_finish: wrong phase");
         std::lock_guard<std::mutex> lock(g_build_mutex);
         select_device(s->device);
         auto h = std::make_unique<ac_graph>();
@@ -328,14 +397,14 @@ int ac_shard_finish(ac_shard* s, int want, ac_graph** out) {
         h->tm = s->b->timings();
         h->host_arrays = (want & 1) != 0;
         h->host_paths = (want & 2) != 0;
-        s->phase = 5;
+        s->phase = 8;
         *out = h.release();
     });
 }
 uint64_t ac_shard_path_entries(const ac_shard* s) { return s->b->path_entry_count(); }
 int ac_shard_paths_export(ac_shard* s, void* d_out_i32) {
     return guarded([&] {
-        if (s->phase != 5) throw DeviceError("ac_shard_paths_export: wrong phase");
+        if (s->phase != 8) throw DeviceError("ac_shard_paths_export: wrong phase");
         std::lock_guard<std::mutex> lock(g_build_mutex);
         select_device(s->device);
         s->b->paths_export(d_out_i32);

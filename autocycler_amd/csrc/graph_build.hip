@@ -73,7 +73,12 @@ struct Table {
                       // with probability 1 - load) without touching the table, which only lives in the Infinity Cache
     u64* novel;       // during the insert only: bit p toggles when p becomes / stops being the position a slot holds, so that at
                       // the end of the insert bit p is set <=> p is the smallest occurrence of its canonical k-mer
+    u32 n_owners;     // > 1: one job over several devices (§7) — this table only holds the k-mers whose home hash maps to `my_owner`;
+    u32 my_owner;     // inserts of other keys are skipped, lookups of other keys answer "not here" (their owner answers)
 };
+// Which rank's table a key lives in: a function of the HOME hash (key_home), so a k-mer's four successors — one middle, one
+// home — have one owner, and a grouped probe is answered by a single rank.
+AC_HD bool table_owns(const Table& tb, u64 home_hash) { return tb.n_owners <= 1 || (u32)((home_hash >> 40) % tb.n_owners) == tb.my_owner; }
 
 // Largest s with off[s] <= p; valid iff p is a k-mer start of that sequence.
 AC_HD bool locate(const TextCtx& t, u64 p, u32* s_out, u32* f_out) {
@@ -124,8 +129,10 @@ struct FindResult { u64 pos; int claimant_flipped; bool found; };
 template <int W> AC_HD FindResult table_find(const TextCtx& t, const Table& tb, const Key<W>& ukey, bool isdot) {
     u64 h = key_hash<W>(ukey);
     u64 tag = slot_make(h, isdot, 0);
-    u64 s = key_home<W>(ukey, t.k, isdot, h) & tb.cap_mask;
+    const u64 hh = key_home<W>(ukey, t.k, isdot, h);
+    u64 s = hh & tb.cap_mask;
     FindResult r; r.found = false; r.pos = 0; r.claimant_flipped = 0;
+    if (!table_owns(tb, hh)) return r;
     if (tb.occ && !((tb.occ[s >> 6] >> (s & 63)) & 1)) return r;
     for (int probes = 0; probes < MAX_PROBES; probes++) {
         u64 v = tb.slots[s];
@@ -149,6 +156,14 @@ template <int W> AC_HD bool find_xk(const TextCtx& t, const Table& tb, const XKm
     *pos = r.pos;
     *rel_same = ((r.claimant_flipped != 0) == flipped);
     return true;
+}
+
+// Does this rank's table own the extended k-mer x (always true on a single device)?
+template <int W> AC_HD bool owns_xk(const TextCtx& t, const Table& tb, const XKmer<W>& x) {
+    if (tb.n_owners <= 1) return true;
+    bool flipped;
+    Key<W> uk = xk_canonical<W>(x, t.k, &flipped);
+    return table_owns(tb, key_home<W>(uk, t.k, x.ld > 0 || x.td > 0, key_hash<W>(uk)));
 }
 
 // Rank support over the novel-position bitmap: index of a novel position in the sorted novel list.
@@ -185,8 +200,10 @@ template <int W> AC_D u64 table_insert(const TextCtx& t, const Table& tb, const 
                                        u32* claimed, u32* err, bool* same, bool* mine_now) {
     u64 h = key_hash<W>(ukey);
     u64 mine = slot_make(h, isdot, p);
-    u64 s = key_home<W>(ukey, t.k, isdot, h) & tb.cap_mask;
+    const u64 hh = key_home<W>(ukey, t.k, isdot, h);
+    u64 s = hh & tb.cap_mask;
     *mine_now = false;
+    if (!table_owns(tb, hh)) return NOREF;      // another rank's k-mer
     for (int probes = 0; probes < MAX_PROBES_INSERT; probes++) {
         u64 v = tb.slots[s];
         if (v == SLOT_EMPTY) {
@@ -394,14 +411,19 @@ struct GraphBuilder::Impl {
     template <int W> void insert(const PackedText& t, u32 hint, DBuf<u64>* slots_out, u64* cap_out, u64* n_distinct_out, DBuf<u64>* bm_out);
     void occupancy_bitmap(const DBuf<u64>& sl, u64 c, DBuf<u64>* occ_out);
     DBuf<u64> occ;             // slot-occupancy bitmap of the graph table
-    Table graph_table() const { return Table{const_cast<u64*>(slots.ptr()), cap - 1, occ.ptr()}; }
+    u32 n_owners = 1, my_owner = 0;      // sharded builds: which slice of the key space the graph table holds (§7)
+    Table graph_table() const { return Table{const_cast<u64*>(slots.ptr()), cap - 1, occ.ptr(), nullptr, n_owners, my_owner}; }
     template <int W> void fragments();
     template <int W> void table();                      // K2, K3 on G
-    template <int W> void degrees(u64 lo, u64 hi);      // K5 for novel indices [lo, hi)
+    void novel_list(u64 known_n);
+    template <int W> void degrees();                    // K5, K6 for all novel k-mers
+    template <int W> void walk_queries();               // sharded: the keys this rank's walkers start from
+    template <int W> void answer_queries(const u64* d_keys, u64 n, u64* d_out);   // sharded: the owned ones, looked up in this rank's table
+    DBuf<u64> qkeys; u64 n_queries = 0;
+    const u64* walk_answers = nullptr;                  // sharded: [n_walkers | n_seqs] answers (0 = not found), nullptr = look the table up
     template <int W> void unitigs();                    // K6..K11 on G
     template <int W> void walk();
     template <int W> void tail(FinalGraph* out, bool want_graph, bool want_paths);
-    u64 deg_lo = 0, deg_hi = 0;
 };
 
 // K2 insert.  Capacity from the reference's own capacity hint (assembly_count, kmer_graph.rs:40): similar assemblies
@@ -413,7 +435,10 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
     if (hint == 0) hint = 1;
     u64 est = pt.n_bases / hint;
     u64 c = next_pow2(std::max<u64>(1024, est * 3 + 4096));
-    if (&pt == &uni && distinct_upper) c = next_pow2(std::max<u64>(1024, distinct_upper * 10 / 7 + 4096));   // no retry: an upper bound is known
+    if (&pt == &uni && distinct_upper) {      // an upper bound is known (sum of the ranks' local counts); a rank holds about 1/n_owners of the keys
+        const u64 mine = distinct_upper / std::max<u32>(n_owners, 1) + distinct_upper / (8 * (u64)std::max<u32>(n_owners, 1)) + 4096;
+        c = next_pow2(std::max<u64>(1024, mine * 10 / 7));
+    }
     // the capacity the previous build of a text of this very size ended with (a process that builds the same job again, or a
     // stream of similar jobs, does not pay for the overflow retries twice)
     static u64 memo_n_text = 0, memo_cap = 0; static u32 memo_k = 0;      // (a capacity is a number, not memory: valid on any device)
@@ -432,7 +457,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
         counters.fill_bytes(0);
         istats.fill_bytes(0);
         u32* ierr = (u32*)&istats.ptr()[256].real;
-        Table tb{sl.ptr(), c - 1, nullptr, nbm.ptr()};
+        Table tb{sl.ptr(), c - 1, nullptr, nbm.ptr(), (&pt == &uni) ? n_owners : 1u, (&pt == &uni) ? my_owner : 0u};
         stream_sync();
 #ifndef AC_EMU
         hipEvent_t e0, e1;
@@ -561,30 +586,48 @@ template <int W> void GraphBuilder::Impl::fragments() {
 template <int W> void GraphBuilder::Impl::table() {
     PackedText& g = *G;
     check_sizes(g);
-    insert<W>(g, tm->graph_hint, &slots, &cap, &N, &bm);
+    insert<W>(g, tm->graph_hint, &slots, &cap, &N, &bm);      // sharded builds: only the k-mers this rank owns (N = how many)
     tm->table_capacity = cap;
     tm->n_distinct = N;
     lap(G == &loc ? &tm->insert : &tm->union_insert);
-
-    // K3 novel-position bitmap -> sorted novel list + rank support
-    u64 n_bm_words = g.n_text / 64 + 1;
     occupancy_bitmap(slots, cap, &occ);
+    if (n_owners <= 1) novel_list(N);      // a sharded build first sums the ranks' (disjoint) bitmaps: bitmap_import
+}
+// K3: novel-position bitmap -> sorted novel list + rank support.  known_n = the number of set bits if the caller knows it (the
+// single-device insert counted its claims), 0 = count them here.
+inline void GraphBuilder::Impl::novel_list(u64 known_n) {
+    PackedText& g = *G;
+    u64 n_bm_words = g.n_text / 64 + 1;
     DBuf<u32> wcnt(n_bm_words);
     wprefix.alloc(n_bm_words);
     launch(n_bm_words, PopcFunctor{bm.ptr(), wcnt.ptr()});
     exclusive_scan_u32(wcnt.ptr(), wprefix.ptr(), n_bm_words);
+    if (known_n) N = known_n;
+    else {
+        u32 last[2];
+        ReadBatch rb;
+        rb.add(&last[0], wprefix.ptr() + (n_bm_words - 1), 4);
+        rb.add(&last[1], wcnt.ptr() + (n_bm_words - 1), 4);
+        rb.run();
+        N = (u64)last[0] + last[1];
+        if (N == 0) throw DeviceError("internal error: no k-mers in the union of the shards");
+        tm->n_distinct = N;
+    }
     npos.alloc(N);
     launch(n_bm_words, FillNovelFunctor{bm.ptr(), wprefix.ptr(), npos.ptr()});
     kinfo.alloc(N, true);
     lap(&tm->collect_sort);
 }
 
-// K5 out/in degrees of the novel k-mers [lo, hi) (a sharded build computes one slice per rank and all-gathers them).
-template <int W> void GraphBuilder::Impl::degrees(u64 lo, u64 hi) {
+// K5 out/in degrees + K6 first flags of all novel k-mers.  Sharded builds: every rank goes over all of them but only the probes
+// its table owns find anything (the known text neighbour of a group is counted by the group's owner too), so the ranks' kinfo
+// words are disjoint contributions that add up.
+template <int W> void GraphBuilder::Impl::degrees() {
     PackedText& g = *G;
     Table tb = graph_table();
-    deg_lo = lo; deg_hi = hi;
-    launch(hi - lo, DegreeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kinfo.ptr(), g.any_dots, lo});
+    launch(N, DegreeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kinfo.ptr(), g.any_dots, 0});
+    Novel nv{bm.ptr(), wprefix.ptr()};
+    launch(g.n_seqs, FirstFunctor<W>{g.ctx((int)k), tb, nv, kinfo.ptr(), g.has_flags ? g.seq_flags.ptr() : nullptr});
     lap(&tm->degree);
 }
 
@@ -594,9 +637,6 @@ template <int W> void GraphBuilder::Impl::unitigs() {
     TextCtx t = g.ctx((int)k);
     Table tb = graph_table();
     Novel nv{bm.ptr(), wprefix.ptr()};
-    launch(g.n_seqs, FirstFunctor<W>{t, tb, nv, kinfo.ptr(), g.has_flags ? g.seq_flags.ptr() : nullptr});
-    lap(&tm->degree);
-
     // K7 heads -> unitig ids
     head.alloc(N + 1, true); scan.alloc(N + 1, true);
     launch(N, HeadFunctor{npos.ptr(), kinfo.ptr(), head.ptr(), N});
@@ -660,6 +700,18 @@ template <int W> void GraphBuilder::Impl::unitigs() {
     lap(&tm->links);
 }
 
+// Sharded builds: the keys of this rank's walker starts (see WalkQueryFunctor), and the owned answers to a batch of such keys.
+template <int W> void GraphBuilder::Impl::walk_queries() {
+    const u32 PC = path_chunk();
+    const u64 n_walkers = (loc.n_text + PC - 1) / PC;
+    n_queries = n_walkers + loc.n_seqs;
+    qkeys.alloc(n_queries * W);
+    launch(n_queries, WalkQueryFunctor<W>{loc.ctx((int)k), PC, n_walkers, qkeys.ptr()});
+}
+template <int W> void GraphBuilder::Impl::answer_queries(const u64* d_keys, u64 n, u64* d_out) {
+    launch(n, AnswerFunctor<W>{G->ctx((int)k), graph_table(), d_keys, d_out});
+}
+
 // K10 paths of this rank's sequences against the graph: count, scan, write; first / last unitig of every path.
 template <int W> void GraphBuilder::Impl::walk() {
     TextCtx t = loc.ctx((int)k), g = G->ctx((int)k);
@@ -681,7 +733,7 @@ template <int W> void GraphBuilder::Impl::walk() {
     launch((u64)U * 10, WlinkFlagFunctor{filter ? maybe_dest.ptr() : nullptr, wlinks.ptr(), counters.ptr() + 4});
     launch(n_walkers, PathWalkFunctor<W>{t, g, tb, nv, uc, wlinks.ptr(), PC, stage.ptr(), wcount.ptr(), seq_tid.ptr(), seq_j.ptr(),
                                         depth.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), counters.ptr() + 4, filter ? maybe_dest.ptr() : nullptr,
-                                        path_diag()});
+                                        path_diag(), walk_answers, n_walkers});
     exclusive_scan_u64(wcount.ptr(), woff.ptr(), n_walkers + 1);
     n_ent = read_scalar(woff.ptr() + n_walkers);
     ent_val.alloc(n_ent);
@@ -941,7 +993,9 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
 // cannot instantiate (or inline) anything width-dependent itself.
 template <int W> struct Stages {
     static void table(GraphBuilder::Impl& m);
-    static void degrees(GraphBuilder::Impl& m, u64 lo, u64 hi);
+    static void degrees(GraphBuilder::Impl& m);
+    static void walk_queries(GraphBuilder::Impl& m);
+    static void answer_queries(GraphBuilder::Impl& m, const u64* d_keys, u64 n, u64* d_out);
     static void unitigs(GraphBuilder::Impl& m);
     static void walk(GraphBuilder::Impl& m);
     static void tail(GraphBuilder::Impl& m, FinalGraph* out, bool want_graph, bool want_paths);
@@ -949,7 +1003,9 @@ template <int W> struct Stages {
 };
 #if AC_W_ONLY != 0 || defined(AC_EMU)
 template <int W> void Stages<W>::table(GraphBuilder::Impl& m) { m.template table<W>(); }
-template <int W> void Stages<W>::degrees(GraphBuilder::Impl& m, u64 lo, u64 hi) { m.template degrees<W>(lo, hi); }
+template <int W> void Stages<W>::degrees(GraphBuilder::Impl& m) { m.template degrees<W>(); }
+template <int W> void Stages<W>::walk_queries(GraphBuilder::Impl& m) { m.template walk_queries<W>(); }
+template <int W> void Stages<W>::answer_queries(GraphBuilder::Impl& m, const u64* d_keys, u64 n, u64* d_out) { m.template answer_queries<W>(d_keys, n, d_out); }
 template <int W> void Stages<W>::unitigs(GraphBuilder::Impl& m) { m.template unitigs<W>(); }
 template <int W> void Stages<W>::walk(GraphBuilder::Impl& m) { m.template walk<W>(); }
 template <int W> void Stages<W>::tail(GraphBuilder::Impl& m, FinalGraph* out, bool want_graph, bool want_paths) { m.template tail<W>(out, want_graph, want_paths); }
@@ -1403,7 +1459,7 @@ void GraphBuilder::build(uint32_t assembly_count_hint, FinalGraph* out) {
     m.loc.pack();
     m.lap(&tm_.pack);
     AC_DISPATCH_W(table, (*impl_))
-    AC_DISPATCH_W(degrees, (*impl_, 0, m.N))
+    AC_DISPATCH_W(degrees, (*impl_))
     AC_DISPATCH_W(unitigs, (*impl_))
     AC_DISPATCH_W(walk, (*impl_))
     AC_DISPATCH_W(tail, (*impl_, out, true, true))
@@ -1465,25 +1521,68 @@ void GraphBuilder::shard_build_union(uint32_t rank, uint32_t n_shards, const uin
     tm_.graph_hint = n_shards;
     m.uni.pack();
     m.lap(&tm_.union_pack);
+    m.n_owners = n_shards; m.my_owner = rank;      // this rank's table holds the k-mers whose home hash it owns
     AC_DISPATCH_W(table, (*impl_))
-    // this rank's slice of the degree computation (the one kernel of the graph stage that is both heavy and
-    // embarrassingly parallel over distinct k-mers); the caller all-gathers the slices
-    u64 lo = m.N * rank / n_shards, hi = m.N * (rank + 1) / n_shards;
-    AC_DISPATCH_W(degrees, (*impl_, lo, hi))
+}
+uint64_t GraphBuilder::bitmap_words() const { return impl_->uni.n_text / 64 + 2; }
+void GraphBuilder::bitmap_export(void* d_out) {      // this rank's novel bits (disjoint from every other rank's: the owners partition the keys)
+    copy_d2d(d_out, impl_->bm.ptr(), bitmap_words() * 8);
+    stream_sync();
+}
+void GraphBuilder::shard_build_novel(const void* d_bitmap_sum) {
+    Impl& m = *impl_;
+    m.t0 = now_s();
+    if (d_bitmap_sum) copy_d2d(m.bm.ptr(), d_bitmap_sum, bitmap_words() * 8);
+    else if (m.n_owners > 1) throw DeviceError("the novel bitmaps of the other ranks are missing");
+    m.novel_list(0);
+    AC_DISPATCH_W(degrees, (*impl_))
 }
 uint64_t GraphBuilder::distinct_count() const { return impl_->N; }
 void GraphBuilder::degrees_export(void* d_out) {
     Impl& m = *impl_;
-    copy_d2d(d_out, m.kinfo.ptr() + m.deg_lo, (m.deg_hi - m.deg_lo) * 4);
+    copy_d2d(d_out, m.kinfo.ptr(), m.N * 4);
     stream_sync();
 }
-void GraphBuilder::shard_build_graph(const void* d_kinfo_all) {
+void GraphBuilder::shard_build_graph(const void* d_kinfo_sum) {
     Impl& m = *impl_;
     m.t0 = now_s();
-    if (d_kinfo_all) copy_d2d(m.kinfo.ptr(), d_kinfo_all, m.N * 4);
-    else if (!(m.deg_lo == 0 && m.deg_hi == m.N)) throw DeviceError("degree slices of the other ranks are missing");
+    if (d_kinfo_sum) copy_d2d(m.kinfo.ptr(), d_kinfo_sum, m.N * 4);
+    else if (m.n_owners > 1) throw DeviceError("the degree words of the other ranks are missing");
     AC_DISPATCH_W(unitigs, (*impl_))
+}
+void GraphBuilder::links_export(void* d_links_i32, void* d_wlinks_i64) {
+    Impl& m = *impl_;
+    copy_d2d(d_links_i32, m.links.ptr(), (size_t)m.U * 10 * 4);
+    copy_d2d(d_wlinks_i64, m.wlinks.ptr(), (size_t)m.U * 10 * 8);
+    stream_sync();
+}
+void GraphBuilder::links_import(const void* d_links_i32, const void* d_wlinks_i64) {
+    Impl& m = *impl_;
+    m.t0 = now_s();
+    if (d_links_i32 && d_wlinks_i64) {
+        copy_d2d(m.links.ptr(), d_links_i32, (size_t)m.U * 10 * 4);
+        copy_d2d(m.wlinks.ptr(), d_wlinks_i64, (size_t)m.U * 10 * 8);
+    } else if (m.n_owners > 1) throw DeviceError("the link words of the other ranks are missing");
+    AC_DISPATCH_W(walk_queries, (*impl_))
+}
+uint64_t GraphBuilder::query_count() const { return impl_->n_queries; }
+uint32_t GraphBuilder::query_key_words() const { return (uint32_t)key_words((int)impl_->k); }
+void GraphBuilder::queries_export(void* d_out) {
+    copy_d2d(d_out, impl_->qkeys.ptr(), impl_->n_queries * query_key_words() * 8);
+    stream_sync();
+}
+void GraphBuilder::answer_queries(const void* d_keys, uint64_t n, void* d_out) {
+    AC_DISPATCH_W(answer_queries, (*impl_, (const u64*)d_keys, n, (u64*)d_out))
+    stream_sync();
+}
+void GraphBuilder::shard_walk(const void* d_answers_mine) {
+    Impl& m = *impl_;
+    m.t0 = now_s();
+    if (!d_answers_mine) throw DeviceError("the answers to this rank's walk queries are missing");
+    m.walk_answers = (const u64*)d_answers_mine;
     AC_DISPATCH_W(walk, (*impl_))
+    stream_sync();      // the answers buffer is the caller's
+    m.walk_answers = nullptr;
 }
 uint32_t GraphBuilder::unitig_count() const { return impl_->U; }
 void GraphBuilder::reduce_export(int32_t* d_sum, int32_t* d_min) {

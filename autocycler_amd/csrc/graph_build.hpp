@@ -65,29 +65,43 @@ class GraphBuilder {
     // the device, including expand_repeats and both renumberings; the host only receives the results.
     void build(uint32_t assembly_count_hint, FinalGraph* out);
 
-    // One job sharded by sequence over several devices.  This rank's sequences are set with set_text_device /
-    // set_sequences_host as usual; the collectives between the phases are the caller's (torch.distributed / RCCL).
-    //   1. shard_begin: pack + insert this rank's sequences, cut its novel runs out as "fragments".
-    //      -> all-gather the fragment texts and meta records of all ranks (rank order).
-    //   2. shard_build_union: k-mer table + novel list of the union text ('$' + all fragment texts), identical on
-    //      every rank, and the out/in degrees of this rank's slice of the novel list.
-    //      -> all-gather the degree slices (degrees_export, 4 bytes per distinct k-mer).
-    //   3. shard_build_graph: unitigs in seed order + links (identical on every rank), then the walk of this rank's
-    //      sequences through them.  -> all-reduce (SUM / MIN) the per-unitig buffers of reduce_export.
-    //   4. reduce_import + shard_finish: the order-sensitive tail (identical on every rank); paths of this rank's
-    //      sequences in final numbers (kept per rank, or gathered with paths_export to the rank that writes the GFA).
+    // One job sharded by sequence over several devices, the k-mer table partitioned by key hash.  This rank's
+    // sequences are set with set_text_device; the collectives between the phases are the caller's (torch.distributed / RCCL).
+    //   1. shard_begin: pack + insert this rank's sequences into a LOCAL table, cut its novel runs out as "fragments".
+    //      -> all-gather the fragment texts and meta records of all ranks (rank order) = the union text, on every rank.
+    //   2. shard_build_union: this rank inserts the union-text k-mers it OWNS (owner = home hash mod n_shards) -> its share of
+    //      the novel bitmap.  -> all-reduce SUM of the bitmaps (the owners partition the keys: the shares are disjoint).
+    //   3. shard_build_novel: novel list (identical everywhere); degrees + first flags of ALL novel k-mers, probing only owned
+    //      groups.  -> all-reduce SUM of the degree words.
+    //   4. shard_build_graph: unitigs in seed order (identical everywhere); links, probing only owned groups.
+    //      -> all-reduce SUM of the link words.
+    //   5. links_import: the keys this rank's walkers start from.  -> all-gather of the keys; answer_queries (owned ones) on
+    //      the keys of all ranks; all-reduce SUM of the answers.
+    //   6. shard_walk: the paths of this rank's sequences.  -> all-reduce (SUM / MIN) the per-unitig buffers of reduce_export.
+    //   7. reduce_import + shard_finish: the order-sensitive tail (identical on every rank); paths of this rank's sequences in
+    //      final numbers (kept per rank, or gathered with paths_export to the rank that writes the GFA).
     void shard_begin(uint32_t local_assembly_hint);
     uint64_t local_distinct_count() const;                          // distinct canonical k-mers of this rank's slice
-    void set_distinct_upper_bound(uint64_t n);                      // optional: sum of all ranks' local counts sizes the global table
+    void set_distinct_upper_bound(uint64_t n);                      // optional: sum of all ranks' local counts sizes the owned tables
     uint64_t fragment_text_bytes() const;
     uint64_t fragment_count() const;
     void fragments_export(void* d_text_out, void* d_meta_out);      // device buffers: text bytes, 8 bytes per fragment
     void shard_build_union(uint32_t rank, uint32_t n_shards, const uint8_t* d_union_text, uint64_t n_union_text,
                            const void* d_meta, uint64_t n_frags_total);
-    uint64_t distinct_count() const;                                // N: novel indices [N*r/G, N*(r+1)/G) belong to rank r
-    void degrees_export(void* d_out);                               // this rank's slice, u32 per k-mer
-    void shard_build_graph(const void* d_kinfo_all);                // N u32 (nullptr: single rank, nothing to import)
+    uint64_t bitmap_words() const;                                  // u64 words of the union text's novel bitmap
+    void bitmap_export(void* d_out);
+    void shard_build_novel(const void* d_bitmap_sum);               // nullptr: single rank
+    uint64_t distinct_count() const;                                // N: distinct canonical k-mers of the whole job
+    void degrees_export(void* d_out);                               // N u32: this rank's contributions
+    void shard_build_graph(const void* d_kinfo_sum);                // N u32 (nullptr: single rank)
     uint32_t unitig_count() const;
+    void links_export(void* d_links_i32, void* d_wlinks_i64);       // 10 U words each: this rank's contributions
+    void links_import(const void* d_links_i32, const void* d_wlinks_i64);   // summed (nullptr, nullptr: single rank)
+    uint64_t query_count() const;                                   // walk queries of this rank
+    uint32_t query_key_words() const;                               // u64 words per query key
+    void queries_export(void* d_out);
+    void answer_queries(const void* d_keys, uint64_t n, void* d_out);   // n keys of any ranks -> n u64 (0 where this rank does not own the key)
+    void shard_walk(const void* d_answers_mine);                    // query_count() u64
     void reduce_export(int32_t* d_sum, int32_t* d_min);             // 3U and 2U int32
     void reduce_import(const int32_t* d_sum, const int32_t* d_min);
     void shard_finish(FinalGraph* out, bool want_graph, bool want_paths);

@@ -2,14 +2,22 @@
 
 One process per GPU.  Rank r holds a contiguous slice of the job's sequences (rank order = sequence order) as a
 device-resident text.  The compute is libautocycler_hip.so (ac_shard_* in include/autocycler_hip.h); this module is
-only the plumbing between its phases — three collectives over torch.distributed (backend "nccl" = RCCL over xGMI on
+only the plumbing between its phases — all-gathers and SUM / MIN all-reduces over torch.distributed (backend "nccl" = RCCL over xGMI on
 the GPU box, "gloo" in the CPU test-suite):
 
     ac_shard_begin          local k-mer insert -> this rank's novel runs ("fragments")
       all-gather            fragment text + 8-byte records of every rank           (∝ distinct content, not ∝ input)
-    ac_shard_build_union    identical k-mer table / novel list on every rank; degrees of this rank's slice of it
-      all-gather            degree slices                                           (4 B per distinct k-mer)
-    ac_shard_build_graph    identical unitigs + links on every rank, then the paths of the local sequences
+    ac_shard_build_union    this rank inserts the union-text k-mers it OWNS (owner = hash of the canonical middle mod world):
+                            a table of ~1/world of the job's k-mers
+      all-reduce SUM        the ranks' novel bitmaps (disjoint)                     (1 bit per union-text position)
+    ac_shard_build_novel    novel list; degrees + first flags of all novel k-mers, probing owned groups only
+      all-reduce SUM        degree words                                            (4 B per distinct k-mer)
+    ac_shard_build_graph    unitigs (identical everywhere); links, probing owned groups only
+      all-reduce SUM        link words                                              (120 B per unitig)
+    ac_shard_links_import   the keys this rank's path walkers start from
+      all-gather            the keys of all ranks; ac_shard_answer looks the owned ones up
+      all-reduce SUM        the answers                                             (8 B per 256 input positions)
+    ac_shard_walk           the paths of the local sequences
       all-reduce SUM, MIN   per-unitig depth / path-end counts, smallest positions  (5 x U int32)
     ac_shard_finish         order-sensitive tail (identical on every rank)
       [gather to root]      optional: paths of all sequences in final numbers -> one rank holds the whole GFA;
@@ -161,20 +169,56 @@ def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False):
         _check(lib, lib.ac_shard_build_union(h, C.c_uint32(comm.rank), C.c_uint32(comm.world), C.c_void_p(union.data_ptr()),
                                              C.c_uint64(nb_total), C.c_void_p(meta.data_ptr()), C.c_uint64(nf_total)))
         del parts, mine
-        # degree slices of all ranks
-        N = lib.ac_shard_distinct_count(h)
-        if not comm.local_only:
-            bounds = [N * r // comm.world for r in range(comm.world + 1)]
-            dsz = [bounds[r + 1] - bounds[r] for r in range(comm.world)]
-            dmine = torch.empty(max(dsz[comm.rank], 1), dtype=torch.int32, device=dev)
-            _check(lib, lib.ac_shard_degrees_export(h, C.c_void_p(dmine.data_ptr())))
-            dall = torch.cat(comm.all_gather_padded(dmine, dsz)).contiguous()
-            _check(lib, lib.ac_shard_build_graph(h, C.c_void_p(dall.data_ptr())))
-            del dall, dmine
+        table_capacity = lib.ac_shard_table_capacity(h)
+        solo = comm.local_only       # one rank and no forced collectives: nothing to sum
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        # novel positions: every rank's share (the k-mers it owns) -> the whole bitmap
+        bm = torch.empty(lib.ac_shard_bitmap_words(h), dtype=torch.int64, device=dev)
+        if solo:
+            _check(lib, lib.ac_shard_build_novel(h, None))
         else:
+            _check(lib, lib.ac_shard_bitmap_export(h, ptr(bm)))
+            comm.all_reduce(bm, "SUM")          # disjoint bits: the sum is the OR
+            _check(lib, lib.ac_shard_build_novel(h, ptr(bm)))
+        del bm
+        # degrees + first flags: contributions of the owners
+        N = lib.ac_shard_distinct_count(h)
+        if solo:
             _check(lib, lib.ac_shard_build_graph(h, None))
-        # per-unitig quantities over all sequences
+        else:
+            deg = torch.empty(N, dtype=torch.int32, device=dev)
+            _check(lib, lib.ac_shard_degrees_export(h, ptr(deg)))
+            comm.all_reduce(deg, "SUM")
+            _check(lib, lib.ac_shard_build_graph(h, ptr(deg)))
+            del deg
+        # links: contributions of the owners
         U = lib.ac_shard_unitig_count(h)
+        if solo:
+            _check(lib, lib.ac_shard_links_import(h, None, None))
+        else:
+            lk = torch.empty(10 * U, dtype=torch.int32, device=dev)
+            wl = torch.empty(10 * U, dtype=torch.int64, device=dev)
+            _check(lib, lib.ac_shard_links_export(h, ptr(lk), ptr(wl)))
+            comm.all_reduce(lk, "SUM")
+            comm.all_reduce(wl, "SUM")
+            _check(lib, lib.ac_shard_links_import(h, ptr(lk), ptr(wl)))
+            del lk, wl
+        # where this rank's walkers start: keys to everybody, answers from the owners
+        nq = lib.ac_shard_query_count(h)
+        kw = lib.ac_shard_query_key_words(h)
+        keys = torch.empty(max(nq * kw, 1), dtype=torch.int64, device=dev)
+        _check(lib, lib.ac_shard_queries_export(h, ptr(keys)))
+        qsz = [q[0] for q in comm.all_gather_sizes([nq])]
+        all_keys = torch.cat(comm.all_gather_padded(keys, [q * kw for q in qsz])).contiguous() if not solo else keys
+        nq_total = sum(qsz)
+        ans = torch.empty(max(nq_total, 1), dtype=torch.int64, device=dev)
+        _check(lib, lib.ac_shard_answer(h, ptr(all_keys), C.c_uint64(nq_total), ptr(ans)))
+        comm.all_reduce(ans, "SUM")
+        q0 = sum(qsz[:comm.rank])
+        mine_ans = ans[q0:q0 + nq].contiguous()
+        _check(lib, lib.ac_shard_walk(h, ptr(mine_ans)))
+        del keys, all_keys, ans, mine_ans
+        # per-unitig quantities over all sequences
         red = torch.empty(5 * U, dtype=torch.int32, device=dev)
         _check(lib, lib.ac_shard_reduce_export(h, C.c_void_p(red.data_ptr()), C.c_void_p(red.data_ptr() + 12 * U)))
         comm.all_reduce(red[:3 * U], "SUM")
@@ -205,6 +249,7 @@ def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False):
                 _check(lib, lib.ac_graph_set_paths(g, C.c_uint32(n_total), ids, lens, cnts, C.c_void_p(all_ent.data_ptr()),
                                                    C.c_int(device_index)))
                 graph.n_seqs = n_total
-        return graph, {"fragments": nf_total, "union_text_bytes": nb_total, "distinct": N, "unitigs": U, "comm_s": comm.seconds}
+        return graph, {"fragments": nf_total, "union_text_bytes": nb_total, "distinct": N, "unitigs": U, "comm_s": comm.seconds,
+                       "table_capacity": table_capacity, "walk_queries": nq}
     finally:
         lib.ac_shard_free(h)

@@ -84,22 +84,32 @@ int ac_compress_build_device(uint32_t k, uint32_t assembly_count, const void* d_
                              const uint16_t* seq_d1, const uint16_t* seq_d2, uint32_t n_seqs, int device,
                              ac_graph** out);
 
-/* ---- one compress job sharded by SEQUENCE over several devices --------------------------------------
- * One process per device; every rank holds a slice of the job's sequences (rank order = sequence order) as a device text
- * laid out as above.  The library never communicates: the three collectives between the phases belong to the caller
- * (torch.distributed over RCCL in autocycler_amd/sharded.py; anything that moves device buffers works).
+/* ---- one compress job over several devices: sequences sharded by rank, the k-mer table partitioned by key hash --
+ * One process per device; every rank holds a slice of the job's sequences (rank order = sequence order) as a device text laid out
+ * as above.  The library never communicates: the collectives between the phases belong to the caller (torch.distributed over
+ * RCCL in autocycler_amd/sharded.py; anything that moves device buffers works).  Every exported buffer holds this rank's
+ * CONTRIBUTIONS — the owners partition the keys, so the ranks' contributions are disjoint and a SUM all-reduce completes them.
  *
- *   ac_shard_begin            pack + insert this rank's sequences (KmerGraph::add_sequences on the slice), cut the runs of
- *                             rank-novel positions out as "fragments" (+ the first and last k-mer of every sequence, which
+ *   ac_shard_begin            pack + insert this rank's sequences into a LOCAL table (KmerGraph::add_sequences on the slice), cut the
+ *                             runs of rank-novel positions out as "fragments" (+ the first and last k-mer of every sequence, which
  *                             carry first_position, kmer_graph.rs:57-60)
  *   [all-gather]              fragment texts and 8-byte meta records of all ranks, concatenated in rank order;
- *                             union text = '$' + the concatenated fragment texts
- *   ac_shard_build_union      global k-mer table + sorted novel list from the union text — identical on every rank — and
- *                             next_kmers / prev_kmers counts (kmer_graph.rs:136-166) for this rank's slice of it:
- *                             novel indices [N*rank/n_shards, N*(rank+1)/n_shards), N = ac_shard_distinct_count()
- *   [all-gather]              ac_shard_degrees_export -> the N u32 of all ranks, rank order
- *   ac_shard_build_graph      unitigs in seed order + links (identical on every rank), then the paths of this rank's
- *                             sequences through them (d_degrees_all = NULL when n_shards == 1)
+ *                             union text = '$' + the concatenated fragment texts (every rank holds it)
+ *   ac_shard_build_union      this rank inserts the union-text k-mers it OWNS: owner = hash of the k-mer's canonical middle mod
+ *                             n_shards — the four successors of a k-mer share the middle, hence the owner — into a table of about
+ *                             1/n_shards of the job's k-mers                          -> ac_shard_bitmap_export (novel positions)
+ *   [all-reduce SUM int64]    the novel bitmaps (disjoint bits: the sum is the OR)
+ *   ac_shard_build_novel      sorted novel list (identical on every rank); next_kmers / prev_kmers counts (kmer_graph.rs:136-166) and
+ *                             first flags of ALL novel k-mers, probing only the groups this rank owns  -> ac_shard_degrees_export
+ *   [all-reduce SUM int32]    the N degree words, N = ac_shard_distinct_count()
+ *   ac_shard_build_graph      unitigs in seed order (identical on every rank); links (create_links, unitig_graph.rs:234-287),
+ *                             probing only owned groups                                                   -> ac_shard_links_export
+ *   [all-reduce SUM]          10 U int32 link words + 10 U int64 walk words, U = ac_shard_unitig_count()
+ *   ac_shard_links_import     the complete links; the keys this rank's path walkers start from      -> ac_shard_queries_export
+ *   [all-gather]              the query keys of all ranks (ac_shard_query_count() x ac_shard_query_key_words() u64 per rank)
+ *   ac_shard_answer           looks the owned ones among ALL ranks' keys up in this rank's table
+ *   [all-reduce SUM int64]    the answers; every rank keeps the slice that answers its own queries
+ *   ac_shard_walk             the paths of this rank's sequences (get_unitig_path_for_sequence, unitig_graph.rs:407-465)
  *   [all-reduce SUM, MIN]     ac_shard_reduce_export -> sum buffer (3U int32: depth, path starts, path ends) and min buffer
  *                             (2U int32: smallest forward / reverse position, biased so signed MIN orders them)
  *   ac_shard_reduce_import    the reduced buffers
@@ -108,7 +118,8 @@ int ac_compress_build_device(uint32_t k, uint32_t assembly_count, const void* d_
  *                             keeps the P lines of its own sequences (ac_gfa_string_parts), or:
  *   [gather]                  ac_shard_paths_export (final numbers) -> the writing rank calls ac_graph_set_paths with the
  *                             paths of all sequences in rank order
- * All `d_` pointers are device pointers into caller-owned buffers of the stated sizes. */
+ * With n_shards == 1 the import pointers may be NULL (nothing to sum).  All `d_` pointers are device pointers into caller-owned
+ * buffers of the stated sizes. */
 typedef struct ac_shard ac_shard;
 int ac_shard_begin(uint32_t k, uint32_t local_assembly_count, const void* d_text, uint64_t n_text, const uint64_t* seq_off,
                    const uint32_t* seq_len, const uint16_t* seq_ids, const uint16_t* seq_d1, const uint16_t* seq_d2,
@@ -117,13 +128,24 @@ int ac_shard_fragment_sizes(const ac_shard*, uint64_t* text_bytes, uint64_t* n_f
 int ac_shard_fragments_export(ac_shard*, void* d_text_out /* text_bytes */, void* d_meta_out /* 8 * n_fragments */);
 uint64_t ac_shard_local_distinct(const ac_shard*);                 /* distinct canonical k-mers of this rank's slice */
 void ac_shard_set_distinct_upper_bound(ac_shard*, uint64_t n);     /* optional, before ac_shard_build_union: the sum of all ranks'
-                                                                      local counts sizes the global k-mer table without a retry */
+                                                                      local counts sizes the owned tables without a retry */
 int ac_shard_build_union(ac_shard*, uint32_t rank, uint32_t n_shards, const void* d_union_text, uint64_t n_union_text,
                          const void* d_meta, uint64_t n_fragments_total);
+uint64_t ac_shard_table_capacity(const ac_shard*);     /* slots of this rank's share of the job's k-mer table */
+uint64_t ac_shard_bitmap_words(const ac_shard*);       /* u64 words of the union text's novel bitmap */
+int ac_shard_bitmap_export(ac_shard*, void* d_out_u64);
+int ac_shard_build_novel(ac_shard*, const void* d_bitmap_sum_u64 /* or NULL */);
 uint64_t ac_shard_distinct_count(const ac_shard*);     /* N: distinct canonical k-mers of the whole job */
-int ac_shard_degrees_export(ac_shard*, void* d_out_u32 /* this rank's slice */);
-int ac_shard_build_graph(ac_shard*, const void* d_degrees_all_u32 /* N, or NULL */);
-uint32_t ac_shard_unitig_count(const ac_shard*);       /* U: sizes the reduce buffers */
+int ac_shard_degrees_export(ac_shard*, void* d_out_u32 /* N */);
+int ac_shard_build_graph(ac_shard*, const void* d_degrees_sum_u32 /* N, or NULL */);
+uint32_t ac_shard_unitig_count(const ac_shard*);       /* U: sizes the link and reduce buffers */
+int ac_shard_links_export(ac_shard*, void* d_links_i32 /* 10 U */, void* d_wlinks_i64 /* 10 U */);
+int ac_shard_links_import(ac_shard*, const void* d_links_sum_i32, const void* d_wlinks_sum_i64 /* or NULL, NULL */);
+uint64_t ac_shard_query_count(const ac_shard*);        /* walk queries of this rank */
+uint32_t ac_shard_query_key_words(const ac_shard*);    /* u64 words per query key (depends on k only) */
+int ac_shard_queries_export(ac_shard*, void* d_out_u64 /* query_count * query_key_words */);
+int ac_shard_answer(ac_shard*, const void* d_keys_u64, uint64_t n_queries, void* d_out_u64 /* n_queries */);
+int ac_shard_walk(ac_shard*, const void* d_answers_u64 /* query_count: this rank's slice of the summed answers */);
 int ac_shard_reduce_export(ac_shard*, void* d_sum_i32 /* 3U */, void* d_min_i32 /* 2U */);
 int ac_shard_reduce_import(ac_shard*, const void* d_sum_i32, const void* d_min_i32);
 int ac_shard_finish(ac_shard*, int want, ac_graph** out);

@@ -50,6 +50,46 @@ def big_case(lib_path, n_asm, genome, dev, rank, world):
     dist.barrier()
 
 
+def partition_case(lib_path, dev, rank, world):
+    """The k-mer table is PARTITIONED over the ranks (owner = hash of the canonical middle): on a mixed-species job — one species
+    per rank, bench.py's N > 1 workload in miniature — every rank's share of the table has about 1/world of the slots the
+    single-device build of the same job needs, the shares of the novel bitmap are disjoint, and the result is still the oracle's."""
+    import torch
+    import torch.distributed as dist
+    import sharded_util
+    from autocycler_amd import compress_build, sharded, synth
+    import oracle_lib as O
+    k = 51
+    seqs, fn, hd = [], [], []
+    for sp in range(world):
+        for i, contigs in enumerate(synth.make_assemblies(2, genome=60_000, plasmid=3_000, sub=1e-3, indel=1e-4, seed=100 + 1000 * sp)):
+            for header, s in contigs:
+                seqs.append(s.tobytes().decode()); fn.append(f"assembly_{2 * sp + i:04d}.fasta"); hd.append(header)
+    comm = sharded.Comm(dev)
+    lib = sharded_util._capi.load_library(lib_path)
+    s_all = O.Seqs.from_raw(k, seqs, filenames=fn, headers=hd, repair=True)
+    loaded = s_all.all()
+    b = sharded_util.slice_bounds(len(loaded), world)
+    shard = sharded_util.local_shard(lib, k, loaded, b[rank], b[rank + 1], 2, dev)
+    g, info = sharded.sharded_build(lib, shard, comm, device_index=dev.index or 0, root=0, gather_paths=True)
+    caps = torch.tensor([info["table_capacity"]], dtype=torch.int64)
+    all_caps = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(all_caps, caps)
+    if rank == 0:
+        gfa_o, st, _ = s_all.compress(k)
+        assert g.gfa(fn, hd) == gfa_o, "partitioned build differs from the oracle"
+        single = compress_build(k, 2 * world, [(q["fwd"], q["length"], q["id"]) for q in loaded], device=dev.index or 0, lib_path=lib_path)
+        single_cap = single.timings()["table_capacity"]
+        per_rank = [int(c.item()) for c in all_caps]
+        distinct = single.timings()["n_distinct"]
+        # a share holds ~distinct / world keys; capacities are powers of two, so allow a factor of two around the ideal share
+        assert max(per_rank) * world <= 2 * single_cap, (per_rank, single_cap)
+        assert min(per_rank) * world * 4 >= single_cap, (per_rank, single_cap)
+        assert max(per_rank) >= distinct // world, (per_rank, distinct)          # ... and still holds its share of the keys
+        print(f"partition case: world {world}, single-device table {single_cap} slots for {distinct} k-mers, per-rank shares {per_rank}")
+    dist.barrier()
+
+
 def main():
     rank, world, port, lib_path, device, cases = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
@@ -70,6 +110,10 @@ def main():
         torch.cuda.set_device(dev)
     done = 0
     for case in cases.split(","):
+        if case == "partition":
+            partition_case(lib_path, dev, rank, world)
+            done += 1
+            continue
         if case.startswith("big:"):
             # a realistic-size job (too big for the oracle): the sharded result must equal the single-device build of the same
             # sequences, which the full-size property tests pin (tests/test_gpu_fullsize.py)

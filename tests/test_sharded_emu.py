@@ -80,6 +80,13 @@ def test_many_ranks_gloo(emu, world):
     assert done >= 3, outs[0][-500:]
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_table_is_partitioned_over_the_ranks(emu, world):
+    # per-rank table capacity ~ 1/N of the single-device one, result still byte-identical to the oracle
+    outs = launch(world, emu, "cpu", "partition", timeout=900)
+    assert f"partition case: world {world}" in outs[0]
+
+
 def test_phase_order_is_enforced(emu):
     """The ac_shard_* calls only work in protocol order, and no other build may start while a sharded one is in flight."""
     import ctypes as C

@@ -20,9 +20,9 @@ before all of them.
     python bench.py [--gpus N --steps K --warmup W] [--assemblies 96 --genome 5000000 --kmer 51]
 
 N > 1: launched by torch.distributed.run, one rank per GPU.  Default `--mode sharded`: ONE compress job of
-N x 96 assemblies, sharded by sequence (rank r holds assemblies 96r .. 96r+95); the ranks exchange their novel-run
-fragments and degree slices (all-gather) and the per-unitig depths / positions (all-reduce) over RCCL —
-autocycler_amd/sharded.py.  Weak scaling: 96 assemblies per GPU; by default the job is a mixed-species one (species r
+N x 96 assemblies, sequences sharded by rank (rank r holds assemblies 96r .. 96r+95), the job's k-mer table partitioned over the
+ranks by key hash; the ranks exchange their novel-run fragments (all-gather), the owners' bitmap / degree / link contributions (SUM
+all-reduce), the walk-start keys and the per-unitig depths / positions over RCCL — autocycler_amd/sharded.py.  Weak scaling: 96 assemblies per GPU; by default the job is a mixed-species one (species r
 on rank r, like BASELINE.json configs[4]) so that the output per GPU is fixed too; `--species one` makes all N x 96
 assemblies one species (the P lines of such a job grow with N^2).
 `--mode independent`: every rank builds the graph of its own 96-assembly set (N unrelated jobs, no data-path collective).
@@ -448,8 +448,10 @@ def main():
                  ("pack", "insert", "collect_sort", "degree", "segment", "minkey", "rank", "links", "paths", "seqs", "analysis", "expand", "finalize", "d2h",
                   "total_device") + (("fragments", "union_pack", "union_insert") if mode == "sharded" else ())}
         sharding = {"single": "one device", "independent": "by assembly set, one unrelated compress job per GPU",
-                    "sharded": "ONE job sharded by sequence over the ranks: all-gather of novel-run fragments and of degree slices, "
-                               "per-unitig all-reduce; unitigs + links end in rank 0's host RAM, the paths (P lines) " +
+                    "sharded": "ONE job: sequences sharded by rank, the k-mer table partitioned over the ranks by key hash (owner = hash of the "
+                               "canonical middle): all-gather of novel-run fragments, SUM all-reduces of the owners' bitmap / degree / link "
+                               "contributions, walk-start keys all-gathered and answered by their owners, per-unitig all-reduce; unitigs + "
+                               "links end in rank 0's host RAM, the paths (P lines) " +
                                ("of all sequences too (gathered)" if args.gather_paths else "of each rank's sequences in that rank's host RAM") +
                                " (autocycler_amd/sharded.py)"}[mode]
         line = {

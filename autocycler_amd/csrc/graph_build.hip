@@ -312,7 +312,13 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static bool path_filter() { const char* e = getenv("AC_PATH_FILTER"); return e ? atoi(e) != 0 : true; }   // smallest positions only for possible expand_repeats destinations
 [[maybe_unused]] static int seq_layout() { const char* e = getenv("AC_SEQ_LAYOUT"); return e ? (atoi(e) != 0 ? 1 : 0) : 0; }      // 1 = interleaved byte ownership in the two sequence writers (not measured yet)
 [[maybe_unused]] static u64 seq_threads(u64 total) { return seq_layout() ? ((total + 4095) / 4096) * 64 : (total + 63) / 64; }
-[[maybe_unused]] static int path_diag() { const char* e = getenv("AC_PATH_DIAG"); return e ? (atoi(e) & 3) : 0; }      // measurement only: the result is wrong when set
+// AC_PATH_DIAG (skips the walk's depth atomics / position updates to price them: the result is WRONG when set) only exists in
+// builds made with -DAC_MEASUREMENT_KNOBS; the shipped library ignores the variable.
+#ifdef AC_MEASUREMENT_KNOBS
+[[maybe_unused]] static int path_diag() { const char* e = getenv("AC_PATH_DIAG"); return e ? (atoi(e) & 3) : 0; }
+#else
+[[maybe_unused]] static int path_diag() { return 0; }
+#endif
 [[maybe_unused]] static u32 path_chunk() { const char* e = getenv("AC_PATH_CHUNK"); int v = e ? atoi(e) : 256; return (u32)(v < 64 ? 64 : (v > 4096 ? 4096 : v)); }
 [[maybe_unused]] static u32 remap_block() { const char* e = getenv("AC_REMAP_BLOCK"); int v = e ? atoi(e) : 4096; v = v < 64 ? 64 : (v > 65536 ? 65536 : v); return (u32)(v & ~63); }
 [[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 3 ? 3 : v); }
@@ -1288,8 +1294,12 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
                 if (done[c].fetch_add(1, std::memory_order_acq_rel) + 1 == n_sub) {      // the chunk is complete: send it
                     const u64 g0 = c * CH / 32, ng = (clen + 31) / 32;
                     std::lock_guard<std::mutex> lock(hip_mu);
+                    // codes and mask bits of a chunk travel on two streams (two copy engines): the smaller copy no longer sits
+                    // between two big ones on one queue.  The slot is free again when both have left it.
+                    AC_HIP_CHECK(hipMemcpyAsync(d_mask + g0, slot_mask(sl), ng * 4, hipMemcpyHostToDevice, pk));
+                    AC_HIP_CHECK(hipEventRecord(st.copied(), pk));
                     AC_HIP_CHECK(hipMemcpyAsync(d_bits + g0, slot_bits(sl), ng * 8, hipMemcpyHostToDevice, up));
-                    AC_HIP_CHECK(hipMemcpyAsync(d_mask + g0, slot_mask(sl), ng * 4, hipMemcpyHostToDevice, up));
+                    AC_HIP_CHECK(hipStreamWaitEvent(up, st.copied(), 0));
                     AC_HIP_CHECK(hipEventRecord(st.event(sl), up));
                     issued[c].store(1, std::memory_order_release);
                 }
@@ -1538,15 +1548,15 @@ void GraphBuilder::shard_build_novel(const void* d_bitmap_sum) {
     AC_DISPATCH_W(degrees, (*impl_))
 }
 uint64_t GraphBuilder::distinct_count() const { return impl_->N; }
-void GraphBuilder::degrees_export(void* d_out) {
+void GraphBuilder::degrees_export(void* d_out) {      // one byte per k-mer: [first(rc T):1][first(T):1][in:3][out:3]
     Impl& m = *impl_;
-    copy_d2d(d_out, m.kinfo.ptr(), m.N * 4);
+    launch(m.N, KinfoPackFunctor{m.kinfo.ptr(), (u8*)d_out});
     stream_sync();
 }
 void GraphBuilder::shard_build_graph(const void* d_kinfo_sum) {
     Impl& m = *impl_;
     m.t0 = now_s();
-    if (d_kinfo_sum) copy_d2d(m.kinfo.ptr(), d_kinfo_sum, m.N * 4);
+    if (d_kinfo_sum) launch(m.N, KinfoUnpackFunctor{(const u8*)d_kinfo_sum, m.kinfo.ptr()});
     else if (m.n_owners > 1) throw DeviceError("the degree words of the other ranks are missing");
     AC_DISPATCH_W(unitigs, (*impl_))
 }

@@ -92,8 +92,8 @@ class GraphBuilder {
     void bitmap_export(void* d_out);
     void shard_build_novel(const void* d_bitmap_sum);               // nullptr: single rank
     uint64_t distinct_count() const;                                // N: distinct canonical k-mers of the whole job
-    void degrees_export(void* d_out);                               // N u32: this rank's contributions
-    void shard_build_graph(const void* d_kinfo_sum);                // N u32 (nullptr: single rank)
+    void degrees_export(void* d_out);                               // N bytes: this rank's contributions
+    void shard_build_graph(const void* d_kinfo_sum);                // N bytes (nullptr: single rank)
     uint32_t unitig_count() const;
     void links_export(void* d_links_i32, void* d_wlinks_i64);       // 10 U words each: this rank's contributions
     void links_import(const void* d_links_i32, const void* d_wlinks_i64);   // summed (nullptr, nullptr: single rank)

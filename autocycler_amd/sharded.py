@@ -11,7 +11,7 @@ the GPU box, "gloo" in the CPU test-suite):
                             a table of ~1/world of the job's k-mers
       all-reduce SUM        the ranks' novel bitmaps (disjoint)                     (1 bit per union-text position)
     ac_shard_build_novel    novel list; degrees + first flags of all novel k-mers, probing owned groups only
-      all-reduce SUM        degree words                                            (4 B per distinct k-mer)
+      all-reduce SUM        degree bytes                                            (1 B per distinct k-mer)
     ac_shard_build_graph    unitigs (identical everywhere); links, probing owned groups only
       all-reduce SUM        link words                                              (120 B per unitig)
     ac_shard_links_import   the keys this rank's path walkers start from
@@ -186,7 +186,7 @@ def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False):
         if solo:
             _check(lib, lib.ac_shard_build_graph(h, None))
         else:
-            deg = torch.empty(N, dtype=torch.int32, device=dev)
+            deg = torch.empty(N, dtype=torch.uint8, device=dev)
             _check(lib, lib.ac_shard_degrees_export(h, ptr(deg)))
             comm.all_reduce(deg, "SUM")
             _check(lib, lib.ac_shard_build_graph(h, ptr(deg)))

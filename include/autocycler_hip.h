@@ -101,7 +101,7 @@ int ac_compress_build_device(uint32_t k, uint32_t assembly_count, const void* d_
  *   [all-reduce SUM int64]    the novel bitmaps (disjoint bits: the sum is the OR)
  *   ac_shard_build_novel      sorted novel list (identical on every rank); next_kmers / prev_kmers counts (kmer_graph.rs:136-166) and
  *                             first flags of ALL novel k-mers, probing only the groups this rank owns  -> ac_shard_degrees_export
- *   [all-reduce SUM int32]    the N degree words, N = ac_shard_distinct_count()
+ *   [all-reduce SUM uint8]    the N degree bytes, N = ac_shard_distinct_count()
  *   ac_shard_build_graph      unitigs in seed order (identical on every rank); links (create_links, unitig_graph.rs:234-287),
  *                             probing only owned groups                                                   -> ac_shard_links_export
  *   [all-reduce SUM]          10 U int32 link words + 10 U int64 walk words, U = ac_shard_unitig_count()
@@ -136,8 +136,8 @@ uint64_t ac_shard_bitmap_words(const ac_shard*);       /* u64 words of the union
 int ac_shard_bitmap_export(ac_shard*, void* d_out_u64);
 int ac_shard_build_novel(ac_shard*, const void* d_bitmap_sum_u64 /* or NULL */);
 uint64_t ac_shard_distinct_count(const ac_shard*);     /* N: distinct canonical k-mers of the whole job */
-int ac_shard_degrees_export(ac_shard*, void* d_out_u32 /* N */);
-int ac_shard_build_graph(ac_shard*, const void* d_degrees_sum_u32 /* N, or NULL */);
+int ac_shard_degrees_export(ac_shard*, void* d_out_u8 /* N bytes: out (3 bits), in (3 bits), the two first flags */);
+int ac_shard_build_graph(ac_shard*, const void* d_degrees_sum_u8 /* N bytes, or NULL */);
 uint32_t ac_shard_unitig_count(const ac_shard*);       /* U: sizes the link and reduce buffers */
 int ac_shard_links_export(ac_shard*, void* d_links_i32 /* 10 U */, void* d_wlinks_i64 /* 10 U */);
 int ac_shard_links_import(ac_shard*, const void* d_links_sum_i32, const void* d_wlinks_sum_i64 /* or NULL, NULL */);

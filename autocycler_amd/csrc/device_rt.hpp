@@ -698,6 +698,19 @@ inline void inclusive_scan_u32(const u32* in, u32* out, size_t n, stream_t s = 0
     AC_HIP_CHECK(rocprim::inclusive_scan(tmp.ptr(), tmp_bytes, in, out, n, rocprim::plus<u32>(), s));
 #endif
 }
+inline void inclusive_max_scan_u32(const u32* in, u32* out, size_t n, stream_t s = 0) {
+    if (!n) return;
+#ifdef AC_EMU
+    u32 acc = 0;
+    for (size_t i = 0; i < n; i++) { acc = in[i] > acc ? in[i] : acc; out[i] = acc; }
+#else
+    if (s == 0) flush_fills();
+    size_t tmp_bytes = 0;
+    AC_HIP_CHECK(rocprim::inclusive_scan(nullptr, tmp_bytes, in, out, n, rocprim::maximum<u32>(), s));
+    DBuf<u8> tmp(tmp_bytes);
+    AC_HIP_CHECK(rocprim::inclusive_scan(tmp.ptr(), tmp_bytes, in, out, n, rocprim::maximum<u32>(), s));
+#endif
+}
 inline void exclusive_scan_u32(const u32* in, u32* out, size_t n, stream_t s = 0) {
     if (!n) return;
 #ifdef AC_EMU

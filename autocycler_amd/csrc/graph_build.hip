@@ -305,13 +305,10 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 //   AC_PATH_FILTER    1 (default): the walk keeps smallest positions only for unitig sides that can become expand_repeats
 //                     destinations (paths stage 1.35 -> 1.25 ms).
 //   AC_REMAP_BLOCK    path entries per wavefront in the final renumbering.
-//   AC_SEQ_LAYOUT     1 = the two sequence writers (K12, materialise) interleave the bytes of a wavefront; default 0 until measured.
 //   AC_INSERT_CHUNK / AC_INSERT_GROWTH / AC_INSERT_WAVES   insert phases: longest wavefront chunk, prefix growth factor, wavefronts per phase;
 //   AC_INSERT_ADAPT (default 1) / AC_INSERT_CHUNK_REST      redundant text: everything after the second phase in one launch, and its longest chunk.
 [[maybe_unused]] static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : 1; }
 [[maybe_unused]] static bool path_filter() { const char* e = getenv("AC_PATH_FILTER"); return e ? atoi(e) != 0 : true; }   // smallest positions only for possible expand_repeats destinations
-[[maybe_unused]] static int seq_layout() { const char* e = getenv("AC_SEQ_LAYOUT"); return e ? (atoi(e) != 0 ? 1 : 0) : 0; }      // 1 = interleaved byte ownership in the two sequence writers (not measured yet)
-[[maybe_unused]] static u64 seq_threads(u64 total) { return seq_layout() ? ((total + 4095) / 4096) * 64 : (total + 63) / 64; }
 // AC_PATH_DIAG (skips the walk's depth atomics / position updates to price them: the result is WRONG when set) only exists in
 // builds made with -DAC_MEASUREMENT_KNOBS; the shipped library ignores the variable.
 #ifdef AC_MEASUREMENT_KNOBS
@@ -329,6 +326,12 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static bool insert_profile() { static const bool v = getenv("AC_INSERT_PROFILE") != nullptr; return v; }      // measurement only
 [[maybe_unused]] static bool expand_rewrite_always() { return getenv("AC_EXPAND_REWRITE_ALWAYS") != nullptr; }      // tests: compact the expand pool after every host check
 [[maybe_unused]] static u64 expand_wave_limit() { const char* e = getenv("AC_EXPAND_WAVE_LIMIT"); return e ? (u64)atoll(e) : 65536; }      // junctions per level from which expand_repeats runs a thread (not a wavefront) per junction
+#ifdef AC_EMU
+[[maybe_unused]] static bool seq_writer_plain() { return true; }
+#else
+[[maybe_unused]] static bool seq_writer_plain() { const char* e = getenv("AC_SEQ_WRITER"); return e && atoi(e) == 0; }      // 0 = always the search-per-thread writers
+#endif
+[[maybe_unused]] static bool seq_writer_forced() { const char* e = getenv("AC_SEQ_WRITER"); return e && atoi(e) == 1; }    // 1 = always the indexed / LDS-tiled writers
 [[maybe_unused]] static bool insert_adaptive() { const char* e = getenv("AC_INSERT_ADAPT"); return e ? atoi(e) != 0 : true; }
 [[maybe_unused]] static u64 insert_growth() { const char* e = getenv("AC_INSERT_GROWTH"); long x = e ? atol(e) : 2; return (u64)(x < 2 ? 2 : x); }      // phase i+1 ends at growth x the end of phase i
 [[maybe_unused]] static u64 insert_waves_target() { const char* e = getenv("AC_INSERT_WAVES"); long x = e ? atol(e) : 16384; return (u64)(x < 1024 ? 1024 : x); }   // wavefronts a long phase is cut into
@@ -760,8 +763,33 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     // K12 sequences
     u64 total = N;   // sum of unitig lengths == number of distinct canonical k-mers
     DBuf<u8> useq(total);
-    launch(seq_threads(total), SeqFunctor{g.bits.ptr(), useq_off.ptr(), ustartpos.ptr(), ulen.ptr(), uorient.ptr(), U, total,
-                                         (int)(k / 2), useq.ptr(), seq_layout()});
+    // (both sequence writers: one thread per 64 output bytes; on the device through the block index + LDS tile of seq_write_kernel)
+    auto write_seqs = [&](int mode, const ExpState* es, const u64* off, u64 n_bytes, u8* dst) {
+        // the indexed / LDS-tiled writer pays for its index (four small launches) from ~16 MB of output on: config C (7.8 MB) 6.02 vs
+        // 5.97 ms per build with it, E' (45 MB) 24.9 vs 26.6, config D (126 MB): see DESIGN.md §6
+        if (seq_writer_plain() || (n_bytes < ((u64)16 << 20) && !seq_writer_forced())) {
+            if (mode == 0) launch((n_bytes + 63) / 64, SeqFunctor{g.bits.ptr(), off, ustartpos.ptr(), ulen.ptr(), uorient.ptr(), U, n_bytes, (int)(k / 2), dst});
+            else launch((n_bytes + 63) / 64, MaterializeFunctor{*es, off, U, n_bytes, dst});
+            return;
+        }
+#ifndef AC_EMU
+        const u64 n_blocks = (n_bytes + 63) / 64;
+        if (n_blocks == 0) return;
+        DBuf<u32> bmax(n_blocks), first(n_blocks);
+        bmax.fill_bytes(0);
+        launch(U, BlockMaxFunctor{off, U, n_blocks, bmax.ptr()});
+        inclusive_max_scan_u32(bmax.ptr(), first.ptr(), n_blocks);
+        const u64 grid = (n_blocks + 255) / 256;
+        if (grid > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+        SeqSrc q{g.bits.ptr(), ustartpos.ptr(), ulen.ptr(), uorient.ptr(), (int)(k / 2)};
+        ExpState e0{};
+        flush_fills();
+        if (mode == 0) hipLaunchKernelGGL(seq_write_kernel<0>, dim3((unsigned)grid), dim3(256), 0, 0, q, e0, off, first.ptr(), U, n_bytes, dst);
+        else hipLaunchKernelGGL(seq_write_kernel<1>, dim3((unsigned)grid), dim3(256), 0, 0, q, *es, off, first.ptr(), U, n_bytes, dst);
+        AC_HIP_CHECK(hipGetLastError());
+#endif
+    };
+    write_seqs(0, nullptr, useq_off.ptr(), total, useq.ptr());
     lap(&tm->seqs);
 
     // K13 link push order, K14 static analysis for expand_repeats, K15 first renumber_unitigs
@@ -842,7 +870,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                 launch((u64)U + 1, ExpLenFunctor{e, len64.ptr(), U});
                 exclusive_scan_u64(len64.ptr(), noff.ptr(), (u64)U + 1);
                 final_total = read_scalar(noff.ptr() + U);
-                launch(seq_threads(final_total), MaterializeFunctor{e, noff.ptr(), U, final_total, alt, seq_layout()});
+                write_seqs(1, &e, noff.ptr(), final_total, alt);
                 launch(U, ExpResetFunctor{e, noff.ptr()});
                 std::swap(cur, alt);
                 e.cur = cur;

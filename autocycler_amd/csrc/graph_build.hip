@@ -318,7 +318,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 #endif
 [[maybe_unused]] static u32 path_chunk() { const char* e = getenv("AC_PATH_CHUNK"); int v = e ? atoi(e) : 256; return (u32)(v < 64 ? 64 : (v > 4096 ? 4096 : v)); }
 [[maybe_unused]] static u32 remap_block() { const char* e = getenv("AC_REMAP_BLOCK"); int v = e ? atoi(e) : 4096; v = v < 64 ? 64 : (v > 65536 ? 65536 : v); return (u32)(v & ~63); }
-[[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 3 ? 3 : v); }
+[[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); if (!e) return -1; int v = atoi(e); return v < 0 ? 0 : (v > 3 ? 3 : v); }      // -1 = automatic
 [[maybe_unused]] static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
 [[maybe_unused]] static u64 wave_chunk_rest() { const char* e = getenv("AC_INSERT_CHUNK_REST"); u64 x = e ? (u64)atoll(e) : 16384; return (std::max<u64>(x, 256) + 63) & ~63ULL; }   // longest chunk of the one-launch rest (r04c: 4096 / 8192 / 16384 = 0.90 / 0.84 / 0.82 ms)
 [[maybe_unused]] static u64 upload_threads() { const char* e = getenv("AC_UPLOAD_THREADS"); long x = e ? atol(e) : 16; return (u64)(x < 1 ? 1 : (x > 128 ? 128 : x)); }   // host threads laying out / packing the text (the byte upload uses at most 8)
@@ -448,13 +448,16 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
         const u64 mine = distinct_upper / std::max<u32>(n_owners, 1) + distinct_upper / (8 * (u64)std::max<u32>(n_owners, 1)) + 4096;
         c = next_pow2(std::max<u64>(1024, mine * 10 / 7));
     }
+    if (c > next_pow2(pt.n_bases * 2 + 1024)) c = next_pow2(pt.n_bases * 2 + 1024);
+    // Twice the reference-style capacity (load ~0.23 on similar assemblies: short probe clusters) while that keeps the table around
+    // the size of the Infinity Cache; a table that is far beyond it anyway (config D: 4 GB) gains nothing from being sparser and its
+    // scans and claims get cheaper when it is not (config D 49.5 -> 45.0 ms per build at shift 0).
+    const int shift = table_shift() >= 0 ? table_shift() : (c > (1ULL << 25) ? 0 : 1);
+    c <<= shift;
     // the capacity the previous build of a text of this very size ended with (a process that builds the same job again, or a
     // stream of similar jobs, does not pay for the overflow retries twice)
-    static u64 memo_n_text = 0, memo_cap = 0; static u32 memo_k = 0;      // (a capacity is a number, not memory: valid on any device)
-    if (pt.n_text == memo_n_text && k == memo_k && memo_cap > c) c = memo_cap;
-    if (c > next_pow2(pt.n_bases * 2 + 1024)) c = next_pow2(pt.n_bases * 2 + 1024);
-    const u64 c_default = c;
-    c <<= table_shift();
+    static u64 memo_n_text = 0, memo_cap = 0; static u32 memo_k = 0; static int memo_shift = -2;      // (a capacity is a number, not memory: valid on any device)
+    if (pt.n_text == memo_n_text && k == memo_k && memo_shift == table_shift() && memo_cap > c) c = memo_cap;
     DBuf<InsertStats> istats(257);       // [256].real doubles as the kernel's error word: one D2H reads everything
     DBuf<u64> sl;
     DBuf<u64> nbm(pt.n_text / 64 + 2);   // K3a falls out of the insert: bit p set <=> p is the smallest occurrence of its canonical k-mer
@@ -545,7 +548,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
         tm->insert_kernel_ms = 0; tm->insert_launches = 0;
     }
     if (n_distinct >= 0xFFFFFFF0ULL) throw DeviceError("too many distinct k-mers for 32-bit novel indices");
-    memo_n_text = pt.n_text; memo_k = k; memo_cap = std::max(c >> table_shift(), c_default);
+    memo_n_text = pt.n_text; memo_k = k; memo_cap = c; memo_shift = table_shift();
     *slots_out = std::move(sl);
     *cap_out = c;
     *n_distinct_out = n_distinct;

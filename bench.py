@@ -514,11 +514,12 @@ def main():
                 "insert": {"slot_claims": st["n_local_distinct"] or st["n_distinct"], "kernel_ms": ins_ms,
                            "claims_only_bound_ms": (st["n_local_distinct"] or st["n_distinct"]) / cas.value / 1e6,
                            "frac_of_cas_ceiling": (st["n_local_distinct"] or st["n_distinct"]) / cas.value / 1e6 / ins_ms},
-                "degree": {"lookups": 6 * st["n_distinct"], "stage_ms": deg_ms,
-                           "lookups_only_bound_ms": 6 * st["n_distinct"] / rd.value / 1e6,
-                           "frac_of_read_ceiling": 6 * st["n_distinct"] / rd.value / 1e6 / deg_ms},
-                "note": "bounds count only the unavoidable random accesses (one CAS per distinct k-mer; six lookups of absent neighbours "
-                        "per distinct k-mer); the kernels also read the packed text and dereference it on every tag match"}
+                "degree": {"cluster_walks": 2 * st["n_distinct"], "stage_ms": deg_ms,
+                           "walks_only_bound_ms": 2 * st["n_distinct"] / rd.value / 1e6,
+                           "frac_of_read_ceiling": 2 * st["n_distinct"] / rd.value / 1e6 / deg_ms},
+                "note": "bounds count only the unavoidable random accesses (one CAS per distinct k-mer; two probe-cluster walks per distinct "
+                        "k-mer — the successors of a k-mer share one cluster since the home slot is hashed from the canonical middle, the "
+                        "predecessors another); the kernels also read the packed text and dereference it on every tag match"}
         if independent is not None:
             line["independent_jobs"] = independent
         if mode == "sharded":

@@ -76,7 +76,6 @@ static void select_device(int device) {
         if (arena_device >= 0) {
             if (g_live_shards) throw DeviceError("a sharded build is in flight on device " + std::to_string(arena_device) + ": this process cannot use device " + std::to_string(device) + " until it is freed");
             Arena::device().release_all();
-            Arena::pinned_host().release_all();
         }
         arena_device = device;
     }
@@ -133,7 +132,6 @@ int ac_release_memory(void) {
         std::lock_guard<std::mutex> lock(g_build_mutex);
         if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
         Arena::device().release_all();
-        Arena::pinned_host().release_all();
         PinnedPool::get().trim();
         release_host_stager();
 #ifndef AC_EMU

@@ -70,7 +70,6 @@ __device__ inline void atomic_max32(u32* p, u32 v) { atomicMax(p, v); }
 class Arena {
   public:
     static Arena& device() { static Arena a(false); return a; }
-    static Arena& pinned_host() { static Arena a(true); return a; }
     void* alloc(size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255;
         if (bytes == 0) bytes = 256;
@@ -459,12 +458,6 @@ class ReadBatch {
     std::vector<Item> items_;
 };
 
-// Device -> pinned host arena (valid until the next build resets the arena); no sync.
-template <class T> T* to_pinned_async(const T* d, size_t n, stream_t s = 0) {
-    T* h = (T*)Arena::pinned_host().alloc((n ? n : 1) * sizeof(T));
-    copy_d2h_async(h, d, n * sizeof(T), s);
-    return h;
-}
 inline void copy_d2d(void* dst, const void* src, size_t bytes, stream_t s = 0) {
     if (!bytes) return;
 #ifdef AC_EMU

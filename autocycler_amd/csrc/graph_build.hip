@@ -1080,10 +1080,9 @@ void device_warmup(int device) {
 
 // ---- GraphBuilder ------------------------------------------------------------------------------------------------
 GraphBuilder::GraphBuilder(uint32_t k) : impl_(new Impl) {
-    // A builder owns the arenas for its lifetime (the C ABI serialises builds): whatever the previous build
-    // left there — device buffers and the pinned RawGraph its host tail has already consumed — is dead.
+    // A builder owns the device arena for its lifetime (the C ABI serialises builds): whatever the previous build left there is
+    // dead.  Nothing a caller can reach lives in it: every array of an ac_graph is a pinned block of its own (PinnedPool) or host heap.
     Arena::device().reset();
-    Arena::pinned_host().reset();
     impl_->k = k;
     if (k < 1 || (k % 2) == 0) throw DeviceError("k must be odd");
     if ((int)k > max_supported_k())

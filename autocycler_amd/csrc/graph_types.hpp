@@ -6,17 +6,6 @@
 
 namespace ac {
 
-// Read-only view of an array in the pinned host arena (valid until the next build on this process).
-template <class T> struct Span {
-    const T* p = nullptr;
-    size_t n = 0;
-    const T& operator[](size_t i) const { return p[i]; }
-    size_t size() const { return n; }
-    const T* data() const { return p; }
-    const T* begin() const { return p; }
-    const T* end() const { return p + n; }
-};
-
 // A block of host memory handed to the caller together with its deleter (pinned memory from a recycling pool
 // in the HIP build, so device -> host copies into it run at full PCIe rate and cost no allocation in steady state).
 struct HostBlock {

@@ -333,6 +333,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 #endif
 [[maybe_unused]] static bool seq_writer_forced() { const char* e = getenv("AC_SEQ_WRITER"); return e && atoi(e) == 1; }    // 1 = always the indexed / LDS-tiled writers
 [[maybe_unused]] static u64 seed_radix_limit() { const char* e = getenv("AC_SEED_RADIX_LIMIT"); return e ? (u64)atoll(e) : (1u << 19); }      // unitigs from which the seed order is a radix sort
+[[maybe_unused]] static bool upload_overlap() { const char* e = getenv("AC_UPLOAD_OVERLAP"); return e ? atoi(e) != 0 : true; }      // host entry: first insert phases while the upload's tail is in flight
 [[maybe_unused]] static bool insert_adaptive() { const char* e = getenv("AC_INSERT_ADAPT"); return e ? atoi(e) != 0 : true; }
 [[maybe_unused]] static u64 insert_growth() { const char* e = getenv("AC_INSERT_GROWTH"); long x = e ? atol(e) : 2; return (u64)(x < 2 ? 2 : x); }      // phase i+1 ends at growth x the end of phase i
 [[maybe_unused]] static u64 insert_waves_target() { const char* e = getenv("AC_INSERT_WAVES"); long x = e ? atol(e) : 16384; return (u64)(x < 1024 ? 1024 : x); }   // wavefronts a long phase is cut into
@@ -422,6 +423,9 @@ struct GraphBuilder::Impl {
     void occupancy_bitmap(const DBuf<u64>& sl, u64 c, DBuf<u64>* occ_out);
     DBuf<u64> occ;             // slot-occupancy bitmap of the graph table
     u32 n_owners = 1, my_owner = 0;      // sharded builds: which slice of the key space the graph table holds (§7)
+    // host entry: stream 0 only waited for the FIRST chunk of the packed upload; positions below upload_avail are on the device, the
+    // rest arrives while the first insert phases run (upload_done = the event behind the last chunk)
+    void* upload_done = nullptr; u64 upload_avail = 0; bool upload_pending = false;
     Table graph_table() const { return Table{const_cast<u64*>(slots.ptr()), cap - 1, occ.ptr(), nullptr, n_owners, my_owner}; }
     template <int W> void fragments();
     template <int W> void table();                      // K2, K3 on G
@@ -492,6 +496,13 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
             u64 pe = (pb == 0) ? first : pb * insert_growth();
             if (rest_at_once || pe > p_end_all || p_end_all - pe < (1u << 16)) pe = p_end_all;
             u64 len = pe - pb;
+#ifndef AC_EMU
+            if (upload_pending && &pt == &loc && pe + (u64)k + 8192 > upload_avail) {      // this phase reads beyond the first uploaded chunk
+                flush_fills();
+                AC_HIP_CHECK(hipStreamWaitEvent(0, (hipEvent_t)upload_done, 0));
+                upload_pending = false;
+            }
+#endif
             {      // one wavefront per chunk: >= ~16 K wavefronts when the phase is long
                 u64 c = (len / insert_waves_target() + 63) & ~63ULL;
                 u32 chunk = (u32)std::min<u64>(std::max<u64>(c, 256), rest_at_once ? wave_chunk_rest() : wave_chunk_max());
@@ -1112,7 +1123,7 @@ class HostStager {
         if (created_) {
             (void)hipStreamDestroy(s_); (void)hipStreamDestroy(pk_);
             for (auto& e : ev_) (void)hipEventDestroy(e);
-            (void)hipEventDestroy(done_); (void)hipEventDestroy(begin_); (void)hipEventDestroy(copied_);
+            (void)hipEventDestroy(done_); (void)hipEventDestroy(begin_); (void)hipEventDestroy(copied_); (void)hipEventDestroy(first_);
             created_ = false;
         }
         if (!ring_) AC_HIP_CHECK(hipHostMalloc((void**)&ring_, SLOT * NS, hipHostMallocDefault));
@@ -1122,6 +1133,7 @@ class HostStager {
         AC_HIP_CHECK(hipEventCreate(&done_));
         AC_HIP_CHECK(hipEventCreate(&begin_));
         AC_HIP_CHECK(hipEventCreateWithFlags(&copied_, hipEventDisableTiming));
+        AC_HIP_CHECK(hipEventCreateWithFlags(&first_, hipEventDisableTiming));
         created_ = true; dev_ = dev;
 #else
         if (!ring_) ring_ = (u8*)malloc(SLOT * NS);
@@ -1143,6 +1155,7 @@ class HostStager {
     hipEvent_t& done() { return done_; }
     hipEvent_t& begin() { return begin_; }
     hipEvent_t& copied() { return copied_; }
+    hipEvent_t& first() { return first_; }
     bool timed = false;                            // begin / done bracket an upload whose duration has not been read yet
 #else
     stream_t stream() { return 0; }
@@ -1155,7 +1168,7 @@ class HostStager {
 #ifndef AC_EMU
     hipStream_t s_ = nullptr, pk_ = nullptr;
     hipEvent_t ev_[NS];
-    hipEvent_t done_, begin_, copied_;
+    hipEvent_t done_, begin_, copied_, first_;
 #endif
 };
 void release_host_stager() { HostStager::get().release(); }
@@ -1343,6 +1356,7 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
                     AC_HIP_CHECK(hipMemcpyAsync(d_bits + g0, slot_bits(sl), ng * 8, hipMemcpyHostToDevice, up));
                     AC_HIP_CHECK(hipStreamWaitEvent(up, st.copied(), 0));
                     AC_HIP_CHECK(hipEventRecord(st.event(sl), up));
+                    if (c == 0) AC_HIP_CHECK(hipEventRecord(st.first(), up));
                     issued[c].store(1, std::memory_order_release);
                 }
             }
@@ -1359,7 +1373,13 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
     for (auto& t : pool) t.join();
     if (!fail.empty()) { (void)hipStreamSynchronize(up); (void)hipStreamSynchronize(pk); throw DeviceError(fail); }
     AC_HIP_CHECK(hipEventRecord(st.done(), up));
-    AC_HIP_CHECK(hipStreamWaitEvent(0, st.done(), 0));
+    // stream 0 goes ahead as soon as the FIRST chunk is there: the first insert phases only read the head of the text, and the
+    // insert waits for `done` before it launches anything that reads further (Impl::insert)
+    const bool overlap = upload_overlap() && n > CH;
+    AC_HIP_CHECK(hipStreamWaitEvent(0, overlap ? st.first() : st.done(), 0));
+    impl_->upload_done = (void*)st.done();
+    impl_->upload_avail = std::min(n, CH);
+    impl_->upload_pending = overlap;
     st.timed = true;
 #endif
     loc.packed = true;

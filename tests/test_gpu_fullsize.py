@@ -188,3 +188,24 @@ def test_gfa_digest_equals_the_oracle(golden_name):
     assert base and "error" not in base[0], rows
     assert base[0]["unitigs"] == golden["post"]["unitigs"]
     assert base[0]["gfa_md5"] == golden["gfa_md5"]
+
+
+@pytest.mark.parametrize("variants", ["base", "AC_UPLOAD_OVERLAP=0", "AC_HOST_PACK=0", "AC_UPLOAD_THREADS=5"])
+def test_host_entry_full_size_digest(variants):
+    """The HOST entry (ac_compress_build from pageable per-sequence buffers: host-side 2-bit pack, chunked upload through the pinned
+    ring, first insert phases overlapping the upload's tail) on the whole config C — 487 MB of text, eight 64 MB chunks — gives the
+    oracle's GFA digest, with the overlap off, with the byte upload + device pack, and with an odd number of packing threads."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    golden = json.loads((root / "tests" / "golden" / "configC_k51.json").read_text())
+    out = subprocess.run([sys.executable, str(root / "tools" / "ab_knobs.py"), "--variants", variants, "--steps", "1", "--workload", "configC_k51", "--host-entry"],
+                         env={**os.environ, "AC_NO_TORCH": "1"}, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{") and '"variant"' in l]
+    assert rows and "error" not in rows[0], rows
+    assert rows[0]["gfa_md5"] == golden["gfa_md5"] and rows[0]["unitigs"] == golden["post"]["unitigs"]
+    assert rows[0]["upload_device_ms"] > 0

@@ -106,6 +106,11 @@ WORKLOADS = {
     "configEprime_k51": (51, 100, lambda: make_mixed_species(5, 20, genome=1_000_000, plasmid=20_000, strain_div=1e-2, sub=1e-4, indel=1e-5, seed=77_000)),
     # E2: the same model with ~2 Mbp genomes (about the largest mixed-species input whose oracle run fits the 62 GB build container)
     "configE2_k51": (51, 100, lambda: make_mixed_species(5, 20, genome=2_000_000, plasmid=40_000, strain_div=1e-2, sub=1e-4, indel=1e-5, seed=78_000)),
+    # bench.py's one-job workload at N GPUs (species r = 96 assemblies of the config C model on rank r) as ONE single-device job: what
+    # the replicated stages of the sharded build cost a rank at that N
+    "benchjob2_k51": (51, 192, lambda: [a for sp in range(2) for a in make_assemblies(96, seed=51_000 + 1000 * sp)]),
+    "benchjob4_k51": (51, 384, lambda: [a for sp in range(4) for a in make_assemblies(96, seed=51_000 + 1000 * sp)]),
+    "benchjob8_k51": (51, 768, lambda: [a for sp in range(8) for a in make_assemblies(96, seed=51_000 + 1000 * sp)]),
     # mini-E: 2 species x 40 strains x 5 Mbp — configs[4]'s per-GPU shape at N = 8 is 125 assemblies; no oracle golden (memory)
     "configEmini_k51": (51, 80, lambda: make_mixed_species(2, 40, genome=5_000_000, plasmid=100_000, strain_div=1e-2, sub=1e-4, indel=1e-5, seed=77_000)),
 }

@@ -295,18 +295,25 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 // Device memory one build of an n_text-byte text needs, roughly: packed text + bitmaps (~0.6 B/position), staging slots
 // of the path walk (4 B/position), k-mer table and per-k-mer arrays (sized by distinct content), unitig-sized buffers.
 [[maybe_unused]] static size_t arena_estimate(u64 n_text, bool owns_text) { return (size_t)n_text * (owns_text ? 8 : 7) + ((size_t)768 << 20); }
-// Tuning knobs, read on every build so that one process can compare settings (tools/ab_knobs.py; measurements in
-// profiles/r03*_ab_knobs_configC.jsonl):
-//   AC_TABLE_SHIFT    k-mer table capacity = 2^n x the reference-style sizing.  Default 1 (load factor ~0.23 instead of ~0.46 on
-//                     similar assemblies): the occupancy bitmap then answers 77 % instead of 54 % of the lookups of absent
-//                     neighbours, and the degree kernel is bound by exactly the table lines those lookups fetch.
+// Tuning knobs (environment), read on every build so that one process can compare settings (tools/ab_knobs.py; measurements in
+// profiles/r03*_ab_knobs_configC.jsonl, profiles/r04*_ab_*.jsonl).  None of them changes a result (tests: *_tuning_knobs_*):
+//   AC_TABLE_SHIFT    k-mer table capacity = 2^n x the reference-style sizing.  Unset = automatic: 1 (load ~0.23 on similar
+//                     assemblies: short probe clusters) while the table stays about cache-sized, 0 for tables far beyond it.
 //   AC_MINKEY_VARIANT 1 (default) = wavefront segmented min with the keys in registers, 0 = key records + library reduce-by-key.
-//   AC_PATH_CHUNK     text positions per path walker (default 256; 128 and 512 measured slower).
+//   AC_SEED_RADIX_LIMIT  unitigs from which the seed order is W radix passes instead of the comparator merge sort (default 2^19).
+//   AC_PATH_CHUNK     text positions per path walker (default 256; 128, 512 and 1024 measured slower).
 //   AC_PATH_FILTER    1 (default): the walk keeps smallest positions only for unitig sides that can become expand_repeats
-//                     destinations (paths stage 1.35 -> 1.25 ms).
+//                     destinations.
 //   AC_REMAP_BLOCK    path entries per wavefront in the final renumbering.
 //   AC_INSERT_CHUNK / AC_INSERT_GROWTH / AC_INSERT_WAVES   insert phases: longest wavefront chunk, prefix growth factor, wavefronts per phase;
-//   AC_INSERT_ADAPT (default 1) / AC_INSERT_CHUNK_REST      redundant text: everything after the second phase in one launch, and its longest chunk.
+//   AC_INSERT_ADAPT (default 1) / AC_INSERT_CHUNK_REST      redundant text: everything after the second phase in one launch, and its longest chunk (16384).
+//   AC_EXPAND_WAVE_LIMIT   junctions per level from which expand_repeats runs a thread instead of a wavefront per junction (65536).
+//   AC_EXPAND_REWRITE_ALWAYS  rewrite the sequences contiguously after every host check of the expand passes (tests).
+//   AC_SEQ_WRITER     0 / 1 = always the search-per-thread / the indexed LDS-tiled sequence writers (default: by output size).
+//   AC_UPLOAD_THREADS (16) / AC_HOST_PACK (1) / AC_UPLOAD_OVERLAP (1)   host entry: packing threads, 2-bit pack on the host, first
+//                     insert phases while the upload's tail is in flight.
+//   AC_NO_MAILBOX     (read once) small read-backs through hipMemcpyAsync + synchronise instead of the mapped mailbox page.
+//   AC_INSERT_PROFILE (read once) per-wavefront cycle split of every insert launch on stderr (measurement).
 [[maybe_unused]] static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : 1; }
 [[maybe_unused]] static bool path_filter() { const char* e = getenv("AC_PATH_FILTER"); return e ? atoi(e) != 0 : true; }   // smallest positions only for possible expand_repeats destinations
 // AC_PATH_DIAG (skips the walk's depth atomics / position updates to price them: the result is WRONG when set) only exists in

@@ -105,3 +105,27 @@ def two_device_ordinals(lib_path):
         assert gfa1 == gfa0
     g2, gfa2, _ = parity_util.check_case(k, seqs, fn, hd, lib_path=lib_path, device=0)
     assert gfa2 == gfa0 and g0.stats_post == g2.stats_post
+
+
+def build_c_client(out_dir, lib_dir=None):
+    """Compiles tests/c_client/client.c — a pedantic C99 translation unit including only include/autocycler_hip.h — against the
+    product library: the header is what a foreign-function binding sees, so it must be valid C and every symbol must link."""
+    lib_dir = Path(lib_dir) if lib_dir else ROOT / "autocycler_amd"
+    exe = Path(out_dir) / "c_client"
+    subprocess.check_call(["gcc", "-std=c99", "-D_GNU_SOURCE", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", str(ROOT / "include"),
+                           str(ROOT / "tests" / "c_client" / "client.c"), "-o", str(exe), "-L", str(lib_dir), "-lautocycler_hip",
+                           f"-Wl,-rpath,{lib_dir}"])
+    return exe
+
+
+def c_client_matches_the_oracle(tmp_path, k, seqs, assembly_count):
+    """The C client on the device: same GFA as the oracle for the same padded, end-repaired sequences."""
+    exe = build_c_client(tmp_path)
+    fn = [f"f{i}" for i in range(len(seqs))]; hd = [f"h{i}" for i in range(len(seqs))]
+    s = O.Seqs.from_raw(k, seqs, filenames=fn, headers=hd, repair=True, assembly_count=assembly_count)
+    gfa_o, st, _ = s.compress(k)
+    text = "".join(f"{q['id']} {q['length']} {q['fwd'].decode()}\n" for q in s.all())
+    pr = subprocess.run([str(exe), str(k), str(assembly_count), "0"], input=text, capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    assert pr.stdout == gfa_o
+    assert f"kmers {st['kmers']} pre {st['unitigs_pre']} {st['links_pre']} {st['length_pre']} post {st['unitigs_post']} {st['links_post']} {st['length_post']}" in pr.stderr

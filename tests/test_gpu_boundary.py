@@ -60,3 +60,15 @@ def test_decompress_a_device_built_graph(lib, tmp_path):
     assert lib.ac_decompress(str(p).encode(), None, str(one).encode(), C.c_int(4)) == 0, lib.ac_last_error()
     want = "".join(f">{f}__{h}\n{s}\n" for f, h, s in sorted(zip(fn, hd, seqs), key=lambda x: x[0]))
     assert one.read_text() == want
+
+
+@pytest.mark.parametrize("k", [9, 51])
+def test_c_client(lib, tmp_path, k):
+    """A plain C99 program bound to include/autocycler_hip.h (tests/c_client/client.c) — the view a Rust / cgo / JNI binding has of
+    the library — builds the same GFA as the oracle on the device."""
+    from test_gpu_parity import _synth_case
+    seqs, fn, hd = seqgen.make_case(7, k)
+    B.c_client_matches_the_oracle(tmp_path, k, seqs, len(set(fn)))
+    if k == 51:
+        seqs, fn, hd = _synth_case(4, 30_000, 2_000, 1e-3, 1e-4, 5)
+        B.c_client_matches_the_oracle(tmp_path, k, seqs, 4)

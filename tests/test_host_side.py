@@ -36,6 +36,18 @@ def test_header_symbols_exported_by_product_library():
     assert b"gfx950" in lib.ac_version()
 
 
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/autocycler_hip.h compiles as pedantic C99 and a C client links against the product library (no GPU needed to link);
+    run without a device it fails with the library's error text and exit code 1, the way the Rust shim would call quit_with_error."""
+    import subprocess
+    import boundary_cases as B
+    import torch
+    exe = B.build_c_client(tmp_path)
+    if not torch.cuda.is_available():
+        pr = subprocess.run([str(exe), "9", "1", "0"], input="1 14 ....ACGTACGTACGTAC....\n", capture_output=True, text=True, timeout=120)
+        assert pr.returncode == 1 and "Error:" in pr.stderr and ("no HIP device" in pr.stderr or "HIP error" in pr.stderr or "no CPU fallback" in pr.stderr), pr.stderr
+
+
 def test_product_library_has_no_cpu_fallback():
     """Without a GPU the build call must fail loudly instead of computing on the CPU."""
     import torch

@@ -46,6 +46,7 @@ inline void atomic_xor64(u64* p, u64 v) { *p ^= v; }
 inline u32 atomic_add32(u32* p, u32 v) { u32 o = *p; *p += v; return o; }
 inline u64 atomic_add64(u64* p, u64 v) { u64 o = *p; *p += v; return o; }
 inline void atomic_or32(u32* p, u32 v) { *p |= v; }
+inline void atomic_or64(u64* p, u64 v) { *p |= v; }
 inline void atomic_min32(u32* p, u32 v) { if (v < *p) *p = v; }
 inline void atomic_max32(u32* p, u32 v) { if (v > *p) *p = v; }
 #else
@@ -57,6 +58,7 @@ __device__ inline void atomic_xor64(u64* p, u64 v) { atomicXor((unsigned long lo
 __device__ inline u32 atomic_add32(u32* p, u32 v) { return atomicAdd(p, v); }
 __device__ inline u64 atomic_add64(u64* p, u64 v) { return (u64)atomicAdd((unsigned long long*)p, (unsigned long long)v); }
 __device__ inline void atomic_or32(u32* p, u32 v) { atomicOr(p, v); }
+__device__ inline void atomic_or64(u64* p, u64 v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
 __device__ inline void atomic_min32(u32* p, u32 v) { atomicMin(p, v); }
 __device__ inline void atomic_max32(u32* p, u32 v) { atomicMax(p, v); }
 #endif

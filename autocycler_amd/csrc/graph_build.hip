@@ -75,7 +75,22 @@ struct Table {
                       // the end of the insert bit p is set <=> p is the smallest occurrence of its canonical k-mer
     u32 n_owners;     // > 1: one job over several devices (§7) — this table only holds the k-mers whose home hash maps to `my_owner`;
     u32 my_owner;     // inserts of other keys are skipped, lookups of other keys answer "not here" (their owner answers)
+    u64* sflags;      // during the insert only (optional): two SIBLING bits per slot (sib_note); MarkFunctor moves them to text positions
 };
+// Sibling bits.  Two k-mers of one middle are siblings in x (same first base, read in the orientation in which the middle is
+// canonical: key_place) or in y (same last base); a k-mer WITHOUT a sibling in x / y is the only successor / predecessor its text
+// neighbour can have, which the degree pass (DegreeLightFunctor) uses to skip the probe.  The insert finds the siblings for free:
+// the k-mers of one middle share a home slot, so of any two of them the one in the LATER slot walked over the earlier one when it
+// looked for its place (the earlier slot was occupied by then, or the walker would have taken it), and the tag shows middle
+// fingerprint, x and y.  It marks both slots.  A clear bit is exact; a set bit may be a 13-bit fingerprint coincidence between
+// different middles in one cluster, which only costs the probe.
+AC_D void sib_note(const Table& tb, u64 s, u32 fl) { if (fl) atomic_or64(&tb.sflags[s >> 5], (u64)fl << (2 * (s & 31))); }
+// v: an occupied slot a walker for the real k-mer with slot word `mine` passes.  Returns the sibling bits the two share.
+AC_HD u32 sib_bits(u64 v, u64 mine) {
+    const u64 d = v ^ mine;
+    if ((d >> TAG_MFP_SHIFT) != 0 || slot_isdot(v) || (d >> 41) == 0) return 0;      // another middle / a dot k-mer / the same tag
+    return (((d >> TAG_X_SHIFT) & 3) == 0 ? 1u : 0u) | (((d >> TAG_Y_SHIFT) & 3) == 0 ? 2u : 0u);
+}
 // Which rank's table a key lives in: a function of the HOME hash (key_home), so a k-mer's four successors — one middle, one
 // home — have one owner, and a grouped probe is answered by a single rank.
 AC_HD bool table_owns(const Table& tb, u64 home_hash) { return tb.n_owners <= 1 || (u32)((home_hash >> 40) % tb.n_owners) == tb.my_owner; }
@@ -127,9 +142,9 @@ template <int W> AC_HD int claimant_match(const TextCtx& t, u64 v, const Key<W>&
 struct FindResult { u64 pos; int claimant_flipped; bool found; };
 
 template <int W> AC_HD FindResult table_find(const TextCtx& t, const Table& tb, const Key<W>& ukey, bool isdot) {
-    u64 h = key_hash<W>(ukey);
-    u64 tag = slot_make(h, isdot, 0);
-    const u64 hh = key_home<W>(ukey, t.k, isdot, h);
+    const KeyPlace pl = key_place<W>(ukey, t.k, isdot, key_hash<W>(ukey));
+    u64 tag = slot_make(pl.tag, isdot, 0);
+    const u64 hh = pl.home;
     u64 s = hh & tb.cap_mask;
     FindResult r; r.found = false; r.pos = 0; r.claimant_flipped = 0;
     if (!table_owns(tb, hh)) return r;
@@ -198,23 +213,26 @@ static const u64 NOREF = ~0ULL;
 // once, and XOR commutes, so whatever order the atomics land in, the bitmap ends with exactly the final slot positions set.
 template <int W> AC_D u64 table_insert(const TextCtx& t, const Table& tb, const Key<W>& ukey, bool isdot, bool flipped, u64 p,
                                        u32* claimed, u32* err, bool* same, bool* mine_now) {
-    u64 h = key_hash<W>(ukey);
-    u64 mine = slot_make(h, isdot, p);
-    const u64 hh = key_home<W>(ukey, t.k, isdot, h);
+    const KeyPlace pl = key_place<W>(ukey, t.k, isdot, key_hash<W>(ukey));
+    u64 mine = slot_make(pl.tag, isdot, p);
+    const u64 hh = pl.home;
     u64 s = hh & tb.cap_mask;
     *mine_now = false;
     if (!table_owns(tb, hh)) return NOREF;      // another rank's k-mer
+    const bool note = tb.sflags != nullptr && !isdot;
+    u32 my_fl = 0;
     for (int probes = 0; probes < MAX_PROBES_INSERT; probes++) {
         u64 v = tb.slots[s];
         if (v == SLOT_EMPTY) {
             u64 old = atomic_cas64(&tb.slots[s], SLOT_EMPTY, mine);
-            if (old == SLOT_EMPTY) { (*claimed)++; *mine_now = true; return NOREF; }
+            if (old == SLOT_EMPTY) { (*claimed)++; *mine_now = true; if (note) sib_note(tb, s, my_fl); return NOREF; }
             v = old;
         }
         if (slot_tag_eq(v, mine)) {
-            if (slot_pos(v) == p) return NOREF;
+            if (slot_pos(v) == p) { if (note) sib_note(tb, s, my_fl); return NOREF; }
             int m = claimant_match<W>(t, v, ukey);
             if (m) {
+                if (note) sib_note(tb, s, my_fl);
                 if (slot_pos(v) > p) {
                     u64 old = atomic_min64(&tb.slots[s], mine);      // the same key's word: tag and isdot agree, positions order it
                     if (old > mine) {
@@ -227,6 +245,9 @@ template <int W> AC_D u64 table_insert(const TextCtx& t, const Table& tb, const 
                 *same = ((m == 2) == flipped);
                 return slot_pos(v);
             }
+        } else if (note) {
+            const u32 fl = sib_bits(v, mine);
+            if (fl) { sib_note(tb, s, fl); my_fl |= fl; }
         }
         s = (s + 1) & tb.cap_mask;
     }
@@ -325,6 +346,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 #endif
 [[maybe_unused]] static u32 path_chunk() { const char* e = getenv("AC_PATH_CHUNK"); int v = e ? atoi(e) : 256; return (u32)(v < 64 ? 64 : (v > 4096 ? 4096 : v)); }
 [[maybe_unused]] static u32 remap_block() { const char* e = getenv("AC_REMAP_BLOCK"); int v = e ? atoi(e) : 4096; v = v < 64 ? 64 : (v > 65536 ? 65536 : v); return (u32)(v & ~63); }
+[[maybe_unused]] static int degree_flags() { const char* e = getenv("AC_DEGREE_FLAGS"); return e ? atoi(e) : 1; }      // 0: every degree by probing; 2: sibling bits inside the one-pass kernel; 1: two passes
 [[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); if (!e) return -1; int v = atoi(e); return v < 0 ? 0 : (v > 3 ? 3 : v); }      // -1 = automatic
 [[maybe_unused]] static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
 [[maybe_unused]] static u64 wave_chunk_rest() { const char* e = getenv("AC_INSERT_CHUNK_REST"); u64 x = e ? (u64)atoll(e) : 16384; return (std::max<u64>(x, 256) + 63) & ~63ULL; }   // longest chunk of the one-launch rest (r04c: 4096 / 8192 / 16384 = 0.90 / 0.84 / 0.82 ms)
@@ -423,17 +445,21 @@ struct GraphBuilder::Impl {
         counters.alloc(8); counters.fill_bytes(0);
     }
     void check_sizes(const PackedText& t) const {
-        if (t.n_text >= POS_MASK) throw DeviceError("input too large for 40-bit text positions");
+        // (2^32 positions short of 2^40: a slot word whose upper half is all ones is then the empty slot and nothing else — MarkFunctor)
+        if (t.n_text >= POS_MASK - (1ULL << 32)) throw DeviceError("input too large for 40-bit text positions");
         if (t.n_seqs == 0 || t.n_text < (u64)k + 2) throw DeviceError("no sequences");
     }
-    template <int W> void insert(const PackedText& t, u32 hint, DBuf<u64>* slots_out, u64* cap_out, u64* n_distinct_out, DBuf<u64>* bm_out);
-    void occupancy_bitmap(const DBuf<u64>& sl, u64 c, DBuf<u64>* occ_out);
+    template <int W> void insert(const PackedText& t, u32 hint, DBuf<u64>* slots_out, u64* cap_out, u64* n_distinct_out, DBuf<u64>* bm_out, bool want_sib = false);
+    DBuf<u64> sflags;          // sibling bits per slot, written by the insert (sib_note); empty = not collected
+    void occupancy_bitmap(const DBuf<u64>& sl, u64 c, DBuf<u64>* occ_out, const u64* sflags_in, u64* sib_out);
     DBuf<u64> occ;             // slot-occupancy bitmap of the graph table
+    DBuf<u64> sib;             // sibling bits of the graph table's real k-mers, two per text position (MarkFunctor); empty = not used
+    DBuf<u64> endset, endset_bloom; u64 endset_mask = 0;      // sequence-end set (EndSetFunctor) and its two filters
     u32 n_owners = 1, my_owner = 0;      // sharded builds: which slice of the key space the graph table holds (§7)
     // host entry: stream 0 only waited for the FIRST chunk of the packed upload; positions below upload_avail are on the device, the
     // rest arrives while the first insert phases run (upload_done = the event behind the last chunk)
     void* upload_done = nullptr; u64 upload_avail = 0; bool upload_pending = false;
-    Table graph_table() const { return Table{const_cast<u64*>(slots.ptr()), cap - 1, occ.ptr(), nullptr, n_owners, my_owner}; }
+    Table graph_table() const { return Table{const_cast<u64*>(slots.ptr()), cap - 1, occ.ptr(), nullptr, n_owners, my_owner, nullptr}; }
     template <int W> void fragments();
     template <int W> void table();                      // K2, K3 on G
     void novel_list(u64 known_n);
@@ -450,7 +476,7 @@ struct GraphBuilder::Impl {
 // K2 insert.  Capacity from the reference's own capacity hint (assembly_count, kmer_graph.rs:40): similar assemblies
 // share most k-mers.  Overflow -> retry with a larger table.
 template <int W>
-void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots_out, u64* cap_out, u64* n_distinct_out, DBuf<u64>* bm_out) {
+void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots_out, u64* cap_out, u64* n_distinct_out, DBuf<u64>* bm_out, bool want_sib) {
     TextCtx t = pt.ctx((int)k);
     const u64 p_end_all = pt.n_text - (u64)k + 1;     // one past the last window that fits in the text
     if (hint == 0) hint = 1;
@@ -480,8 +506,10 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
         nbm.fill_bytes(0);
         counters.fill_bytes(0);
         istats.fill_bytes(0);
+        if (want_sib) { sflags.alloc(c / 32 + 1); sflags.fill_bytes(0); }
+        else sflags = DBuf<u64>();
         u32* ierr = (u32*)&istats.ptr()[256].real;
-        Table tb{sl.ptr(), c - 1, nullptr, nbm.ptr(), (&pt == &uni) ? n_owners : 1u, (&pt == &uni) ? my_owner : 0u};
+        Table tb{sl.ptr(), c - 1, nullptr, nbm.ptr(), (&pt == &uni) ? n_owners : 1u, (&pt == &uni) ? my_owner : 0u, want_sib ? sflags.ptr() : nullptr};
         stream_sync();
 #ifndef AC_EMU
         hipEvent_t e0, e1;
@@ -575,12 +603,12 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
 }
 
 // Slot-occupancy bitmap of a finished table (one ballot word per wavefront of the scan; no atomics).
-inline void GraphBuilder::Impl::occupancy_bitmap(const DBuf<u64>& sl, u64 c, DBuf<u64>* occ_out) {
+inline void GraphBuilder::Impl::occupancy_bitmap(const DBuf<u64>& sl, u64 c, DBuf<u64>* occ_out, const u64* sflags_in, u64* sib_out) {
     occ_out->alloc((c + 63) / 64);
 #ifdef AC_EMU
     occ_out->fill_bytes(0);      // the serial emulation ORs bit by bit; the device writes whole ballot words
 #endif
-    launch_full(c, MarkFunctor{sl.ptr(), occ_out->ptr()});
+    launch_full(c, MarkFunctor{sl.ptr(), occ_out->ptr(), sflags_in, sib_out});
 }
 
 // Sharded phase 1 (after the local insert): novel runs of this rank -> fragment text + one meta record per fragment.
@@ -617,11 +645,15 @@ template <int W> void GraphBuilder::Impl::fragments() {
 template <int W> void GraphBuilder::Impl::table() {
     PackedText& g = *G;
     check_sizes(g);
-    insert<W>(g, tm->graph_hint, &slots, &cap, &N, &bm);      // sharded builds: only the k-mers this rank owns (N = how many)
+    const bool want_sib = n_owners <= 1 && k >= 3 && degree_flags();      // single device: the degree pass's shortcut (sharded builds probe)
+    insert<W>(g, tm->graph_hint, &slots, &cap, &N, &bm, want_sib);      // sharded builds: only the k-mers this rank owns (N = how many)
     tm->table_capacity = cap;
     tm->n_distinct = N;
     lap(G == &loc ? &tm->insert : &tm->union_insert);
-    occupancy_bitmap(slots, cap, &occ);
+    // the scan moves the sibling bits the insert left per slot to the text positions the slots ended up holding
+    if (want_sib) { sib.alloc(2 * (g.n_text / 64 + 2)); sib.fill_bytes(0); }
+    else sib = DBuf<u64>();
+    occupancy_bitmap(slots, cap, &occ, want_sib ? sflags.ptr() : nullptr, want_sib ? sib.ptr() : nullptr);
     if (n_owners <= 1) novel_list(N);      // a sharded build first sums the ranks' (disjoint) bitmaps: bitmap_import
 }
 // K3: novel-position bitmap -> sorted novel list + rank support.  known_n = the number of set bits if the caller knows it (the
@@ -656,7 +688,37 @@ inline void GraphBuilder::Impl::novel_list(u64 known_n) {
 template <int W> void GraphBuilder::Impl::degrees() {
     PackedText& g = *G;
     Table tb = graph_table();
-    launch(N, DegreeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kinfo.ptr(), g.any_dots, 0});
+    EndSet es{nullptr, 0, nullptr, nullptr};
+    if (sib.size() && g.any_dots && !g.has_flags) {
+        endset_mask = next_pow2(4 * (u64)g.n_seqs + 16) - 1;
+        endset.alloc((endset_mask + 1) * W);
+        endset.fill_bytes(0xFF);
+        endset_bloom.alloc(2 * ENDSET_BLOOM_WORDS);
+        endset_bloom.fill_bytes(0);
+        es = EndSet{endset.ptr(), endset_mask, endset_bloom.ptr(), endset_bloom.ptr() + ENDSET_BLOOM_WORDS};
+        launch(2 * (u64)g.n_seqs, EndSetFunctor<W>{g.ctx((int)k), es});
+    }
+    if (sib.size() && degree_flags() == 1 && (!g.any_dots || es.keys)) {      // settle what the sibling bits settle, queue the rest, probe the queues
+        DegWork wk;
+        wk.rcap = (u32)(N / DEG_REGIONS + N / (4 * DEG_REGIONS) + 64 * DEG_BATCH);
+        wk.ocap = N;
+        DBuf<u64> items((u64)DEG_LISTS * ((u64)DEG_REGIONS * wk.rcap + wk.ocap)); DBuf<u32> counts(DEG_LISTS * (DEG_REGIONS + 1));
+        counts.fill_bytes(0);
+        wk.items = items.ptr(); wk.counts = counts.ptr();
+        const u64 n_thr = (((N + DEG_BATCH - 1) / DEG_BATCH) + 63) & ~63ULL;
+        launch_full(n_thr, DegreeLightFunctor<W>{g.ctx((int)k), npos.ptr(), kinfo.ptr(), g.any_dots, bm.ptr(), sib.ptr(), es, wk, N, n_thr});
+        launch((u64)DEG_LISTS * DEG_REGIONS * DEG_PROBE_THREADS, DegreeProbeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kinfo.ptr(), g.any_dots, wk, es});
+#ifdef AC_EMU
+        if (getenv("AC_DEGREE_DIAG")) {
+            u64 c0 = 0, c1 = 0, sx = 0;
+            for (u32 r = 0; r <= DEG_REGIONS; r++) { c0 += wk.count(0)[r]; c1 += wk.count(1)[r]; }
+            for (u64 w = 0; w < sib.size(); w++) sx += (u64)__builtin_popcountll(sib.ptr()[w]);
+            fprintf(stderr, "degree diag: N %llu, queued real %llu, generic %llu, sibling bits set %llu, any_dots %d\n", (unsigned long long)N,
+                    (unsigned long long)c0, (unsigned long long)c1, (unsigned long long)sx, (int)g.any_dots);
+        }
+#endif
+    } else
+        launch(N, DegreeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kinfo.ptr(), g.any_dots, 0, bm.ptr(), sib.size() ? sib.ptr() : nullptr, es});
     Novel nv{bm.ptr(), wprefix.ptr()};
     launch(g.n_seqs, FirstFunctor<W>{g.ctx((int)k), tb, nv, kinfo.ptr(), g.has_flags ? g.seq_flags.ptr() : nullptr});
     lap(&tm->degree);

@@ -384,14 +384,51 @@ AC_UNROLL_W
     const Key<W> c = key_lt<W>(r, m) ? r : m;
     return key_hash<W>(c) ^ 0x5851F42D4C957F2DULL;
 }
+// The 2-bit code at bit position `bit` (even) of a key.
+template <int W> AC_HD u32 key_code_at(const Key<W>& key, int bit) {
+    const int wi = W - 1 - (bit >> 6);
+    u64 x = 0;
+AC_UNROLL_W
+    for (int i = 0; i < W; i++) x = (i == wi) ? key.w[i] : x;   // constant indices only (see key_shr)
+    return (u32)(x >> (bit & 63)) & 3u;
+}
+// Home hash AND slot tag of a k-mer.  The 23-bit tag of a REAL k-mer (k >= 3) is [mfp:13][x:2][y:2][h:6]: mfp = 13 bits of the home
+// hash that do not take part in the slot index (equal for all the k-mers of one middle), (x, y) = the k-mer's first and last base
+// read in the orientation in which its MIDDLE is canonical, h = 6 bits of the whole key's hash.  Two k-mers of one middle differ in
+// x or y, so the tag still tells the members of a group apart; and two slots of one probe cluster whose mfp agree are (up to a
+// 2^-13 coincidence) k-mers of one middle — which lets a sequential scan of the finished table decide, slot by slot, whether a
+// k-mer has a "sibling" with the same x or the same y, i.e. whether the k-mer before / after it in the text can branch at all
+// (SiblingFunctor, DegreeFunctor).  Dot k-mers and k < 3: 23 bits of the whole key's hash.  The tag is returned in place (bits 63..41).
+struct KeyPlace { u64 home, tag; };
+static const int TAG_X_SHIFT = 41 + 8, TAG_Y_SHIFT = 41 + 6, TAG_MFP_SHIFT = 41 + 10;
+AC_HD u64 tag_compose(u64 home_hash, u32 x, u32 y, u64 full_hash) {
+    return (((home_hash >> 51) << 10) | ((u64)x << 8) | ((u64)y << 6) | (full_hash >> 58)) << 41;
+}
+template <int W> AC_HD KeyPlace key_place(const Key<W>& key, int k, bool isdot, u64 full_hash) {
+    KeyPlace pl;
+    if (isdot || k < 3) { pl.home = full_hash; pl.tag = (full_hash >> 41) << 41; return pl; }
+    Key<W> v = key;
+    v.w[0] &= ~((u64)255 << 56);
+    const Key<W> mm = key_kmask<W>(k - 2);
+    Key<W> m = key_shr<W>(v, 2);
+AC_UNROLL_W
+    for (int i = 0; i < W; i++) m.w[i] &= mm.w[i];
+    Key<W> r = key_rc<W>(m, k - 2);
+    const bool mflip = key_lt<W>(r, m);
+    const Key<W> c = mflip ? r : m;
+    pl.home = key_hash<W>(c) ^ 0x5851F42D4C957F2DULL;
+    const u32 first = key_code_at<W>(v, 2 * (k - 1)), last = (u32)v.w[W - 1] & 3u;
+    pl.tag = tag_compose(pl.home, mflip ? 3u - last : first, mflip ? 3u - first : last, full_hash);
+    return pl;
+}
 
 // ---- hash-table slot word ------------------------------------------------------------------------
-// [fp:23][isdot:1][pos:40]; EMPTY = all ones.  The slot stores the *text position* of the smallest
+// [tag:23][isdot:1][pos:40] (tag: key_place); EMPTY = all ones.  The slot stores the *text position* of the smallest
 // occurrence of its canonical k-mer (the reference stores a raw pointer into the sequence,
 // kmer_graph.rs:26-33); equal keys share fp and isdot, so a 64-bit atomicMin orders by position.
 static const u64 SLOT_EMPTY = ~0ULL;
 static const u64 POS_MASK = (1ULL << 40) - 1;
-AC_HD u64 slot_make(u64 hash, bool isdot, u64 pos) { return ((hash >> 41) << 41) | ((u64)(isdot ? 1 : 0) << 40) | pos; }
+AC_HD u64 slot_make(u64 tag_in_place, bool isdot, u64 pos) { return tag_in_place | ((u64)(isdot ? 1 : 0) << 40) | pos; }
 AC_HD u64 slot_pos(u64 v) { return v & POS_MASK; }
 AC_HD bool slot_isdot(u64 v) { return (v >> 40) & 1; }
 AC_HD bool slot_tag_eq(u64 a, u64 b) { return (a >> 40) == (b >> 40); }

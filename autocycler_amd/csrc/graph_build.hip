@@ -292,22 +292,44 @@ int max_supported_k() { return 501; }   // the reference's own limit (compress.r
 [[maybe_unused]] static int key_words(int k) { int w = words_for_k(k); return w <= 4 ? w : (w <= 8 ? 8 : 16); }
 
 // renumber_unitigs (unitig_graph.rs:295-315): stable sort of `order` by (length desc, sequence asc, depth desc).
+[[maybe_unused]] static bool renum_two_pass() { const char* e = getenv("AC_RENUM_TWO_PASS"); return e && atoi(e) != 0; }      // 1: always the two-pass renumber sort
+[[maybe_unused]] static u32 renum_max_group() { const char* e = getenv("AC_RENUM_MAX_GROUP"); int v = e ? atoi(e) : (int)RENUM_MAX_GROUP; return (u32)(v < 1 ? 1 : (v > (int)RENUM_MAX_GROUP ? (int)RENUM_MAX_GROUP : v)); }      // tests: smaller groups take the fallbacks
 [[maybe_unused]] static void renumber_sort(DBuf<u32>& order, u32 U, const u32* len, const u64* off, const u8* seq, const u32* depth, u32* flag) {
     if (U <= 1) return;
     DBuf<u32> backup(U);
     copy_d2d(backup.ptr(), order.ptr(), (size_t)U * 4);
     DBuf<u64> prefix(U), key(U);
     launch(U, RenumKeyFunctor{len, off, seq, prefix.ptr()});
+    UnitigLess less{len, off, seq, depth};
+    u32 zero = 0;
+    if (!renum_two_pass()) {      // one sort on (length | 16 bases), ties by the comparator
+        launch(U, RenumPassFunctor{order.ptr(), len, depth, prefix.ptr(), 2, key.ptr()});
+        sort_pairs_u64_u32(key, order, U, 64);
+        launch(U, RenumTieFunctor{order.ptr(), U, len, depth, prefix.ptr(), less, flag, 0, renum_max_group()});
+#ifdef AC_EMU
+        if (getenv("AC_DEGREE_DIAG")) {
+            u64 groups = 0, members = 0, biggest = 0, cur = 1, longest = 0;
+            for (u32 i = 1; i <= U; i++) {
+                bool same = i < U && len[order.ptr()[i]] == len[order.ptr()[i - 1]] && (prefix.ptr()[order.ptr()[i]] >> 32) == (prefix.ptr()[order.ptr()[i - 1]] >> 32);
+                if (same) cur++;
+                else { if (cur > 1) { groups++; members += cur; if (cur > biggest) biggest = cur; if (len[order.ptr()[i - 1]] > longest) longest = len[order.ptr()[i - 1]]; } cur = 1; }
+            }
+            fprintf(stderr, "renumber diag: U %u, groups %llu, members %llu, biggest %llu, longest member %llu, flag %u\n", U, (unsigned long long)groups,
+                    (unsigned long long)members, (unsigned long long)biggest, (unsigned long long)longest, *flag);
+        }
+#endif
+        if (!read_scalar(flag)) return;
+        copy_d2d(order.ptr(), backup.ptr(), (size_t)U * 4);      // a large group of unitigs sharing length and 16 bases: the two-pass form
+        copy_h2d(flag, &zero, 4);
+    }
     for (int pass = 0; pass < 2; pass++) {
         launch(U, RenumPassFunctor{order.ptr(), len, depth, prefix.ptr(), pass, key.ptr()});
         sort_pairs_u64_u32(key, order, U, 64);
     }
-    UnitigLess less{len, off, seq, depth};
-    launch(U, RenumTieFunctor{order.ptr(), U, len, prefix.ptr(), less, flag});
+    launch(U, RenumTieFunctor{order.ptr(), U, len, depth, prefix.ptr(), less, flag, 1, renum_max_group()});
     if (read_scalar(flag)) {    // a large group of long unitigs sharing length and 32-base prefix: comparator merge sort
         copy_d2d(order.ptr(), backup.ptr(), (size_t)U * 4);
         sort_keys_cmp(order, U, less);
-        u32 zero = 0;
         copy_h2d(flag, &zero, 4);
     }
 }
@@ -344,8 +366,21 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 #else
 [[maybe_unused]] static int path_diag() { return 0; }
 #endif
-[[maybe_unused]] static u32 path_chunk() { const char* e = getenv("AC_PATH_CHUNK"); int v = e ? atoi(e) : 256; return (u32)(v < 64 ? 64 : (v > 4096 ? 4096 : v)); }
+// Text positions per path walker.  A walker pays one table lookup and then one dependent gather per unitig it steps through: the
+// chunk is sized for ~5 unitigs per walker — 5 x the mean unitig length N / U, to the nearest power of two in [64, 2048] (config C
+// 256, config D 512, E' 64; r06h: C 128 / 256 / 512 = 1.00 / 0.93 / 1.03 ms, D 256 / 512 / 2048 = 2.15 / 1.78 / 1.50 ms, E' 128 /
+// 256 = 1.45 / 1.58 ms).  AC_PATH_CHUNK overrides.
+[[maybe_unused]] static u32 path_chunk(u64 n_kmers, u32 n_unitigs) {
+    const char* e = getenv("AC_PATH_CHUNK");
+    if (e) { int v = atoi(e); return (u32)(v < 64 ? 64 : (v > 4096 ? 4096 : v)); }
+    const u64 want = 5 * n_kmers / std::max<u32>(n_unitigs, 1);
+    u32 pc = 64;
+    while (pc < 2048 && (u64)pc * 3 / 2 < want) pc *= 2;
+    return pc;
+}
 [[maybe_unused]] static u32 remap_block() { const char* e = getenv("AC_REMAP_BLOCK"); int v = e ? atoi(e) : 4096; v = v < 64 ? 64 : (v > 65536 ? 65536 : v); return (u32)(v & ~63); }
+[[maybe_unused]] static bool fill_novel_plain() { const char* e = getenv("AC_FILL_NOVEL"); return e && atoi(e) == 0; }      // 0: a thread per bitmap word
+[[maybe_unused]] static bool table_half() { const char* e = getenv("AC_TABLE_HALF"); return e && atoi(e) != 0; }      // measurement: half the automatic capacity
 [[maybe_unused]] static int degree_flags() { const char* e = getenv("AC_DEGREE_FLAGS"); return e ? atoi(e) : 1; }      // 0: every degree by probing; 2: sibling bits inside the one-pass kernel; 1: two passes
 [[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); if (!e) return -1; int v = atoi(e); return v < 0 ? 0 : (v > 3 ? 3 : v); }      // -1 = automatic
 [[maybe_unused]] static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
@@ -492,6 +527,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
     // scans and claims get cheaper when it is not (config D 49.5 -> 45.0 ms per build at shift 0).
     const int shift = table_shift() >= 0 ? table_shift() : (c > (1ULL << 25) ? 0 : 1);
     c <<= shift;
+    if (table_half() && c > 2048) c >>= 1;
     // the capacity the previous build of a text of this very size ended with (a process that builds the same job again, or a
     // stream of similar jobs, does not pay for the overflow retries twice)
     static u64 memo_n_text = 0, memo_cap = 0; static u32 memo_k = 0; static int memo_shift = -2;      // (a capacity is a number, not memory: valid on any device)
@@ -677,7 +713,18 @@ inline void GraphBuilder::Impl::novel_list(u64 known_n) {
         tm->n_distinct = N;
     }
     npos.alloc(N);
+#ifdef AC_EMU
     launch(n_bm_words, FillNovelFunctor{bm.ptr(), wprefix.ptr(), npos.ptr()});
+#else
+    if (fill_novel_plain()) launch(n_bm_words, FillNovelFunctor{bm.ptr(), wprefix.ptr(), npos.ptr()});
+    else {
+        const u64 blocks = (n_bm_words + 255) / 256;
+        if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+        flush_fills();
+        hipLaunchKernelGGL(fill_novel_wave_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, 0, bm.ptr(), wprefix.ptr(), npos.ptr(), n_bm_words);
+        AC_HIP_CHECK(hipGetLastError());
+    }
+#endif
     kinfo.alloc(N, true);
     lap(&tm->collect_sort);
 }
@@ -806,7 +853,7 @@ template <int W> void GraphBuilder::Impl::unitigs() {
 
 // Sharded builds: the keys of this rank's walker starts (see WalkQueryFunctor), and the owned answers to a batch of such keys.
 template <int W> void GraphBuilder::Impl::walk_queries() {
-    const u32 PC = path_chunk();
+    const u32 PC = path_chunk(N, U);
     const u64 n_walkers = (loc.n_text + PC - 1) / PC;
     n_queries = n_walkers + loc.n_seqs;
     qkeys.alloc(n_queries * W);
@@ -822,7 +869,7 @@ template <int W> void GraphBuilder::Impl::walk() {
     Table tb = graph_table();
     Novel nv{bm.ptr(), wprefix.ptr()};
     UnitigCtx uc{head.ptr(), scan.ptr(), rank.ptr(), uorient.ptr(), ustart.ptr(), ulen.ptr(), U, N};
-    const u32 PC = path_chunk();
+    const u32 PC = path_chunk(N, U);
     u64 n_walkers = (loc.n_text + PC - 1) / PC;
     depth.alloc(U, true); minpos_fwd.alloc(U); minpos_rev.alloc(U);
     minpos_fwd.fill_bytes(0xFF); minpos_rev.fill_bytes(0xFF);

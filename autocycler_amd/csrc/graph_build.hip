@@ -380,7 +380,6 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 }
 [[maybe_unused]] static u32 remap_block() { const char* e = getenv("AC_REMAP_BLOCK"); int v = e ? atoi(e) : 4096; v = v < 64 ? 64 : (v > 65536 ? 65536 : v); return (u32)(v & ~63); }
 [[maybe_unused]] static bool fill_novel_plain() { const char* e = getenv("AC_FILL_NOVEL"); return e && atoi(e) == 0; }      // 0: a thread per bitmap word
-[[maybe_unused]] static bool table_half() { const char* e = getenv("AC_TABLE_HALF"); return e && atoi(e) != 0; }      // measurement: half the automatic capacity
 [[maybe_unused]] static int degree_flags() { const char* e = getenv("AC_DEGREE_FLAGS"); return e ? atoi(e) : 1; }      // 0: every degree by probing; 2: sibling bits inside the one-pass kernel; 1: two passes
 [[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); if (!e) return -1; int v = atoi(e); return v < 0 ? 0 : (v > 3 ? 3 : v); }      // -1 = automatic
 [[maybe_unused]] static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
@@ -527,7 +526,6 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
     // scans and claims get cheaper when it is not (config D 49.5 -> 45.0 ms per build at shift 0).
     const int shift = table_shift() >= 0 ? table_shift() : (c > (1ULL << 25) ? 0 : 1);
     c <<= shift;
-    if (table_half() && c > 2048) c >>= 1;
     // the capacity the previous build of a text of this very size ended with (a process that builds the same job again, or a
     // stream of similar jobs, does not pay for the overflow retries twice)
     static u64 memo_n_text = 0, memo_cap = 0; static u32 memo_k = 0; static int memo_shift = -2;      // (a capacity is a number, not memory: valid on any device)

@@ -380,6 +380,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 }
 [[maybe_unused]] static u32 remap_block() { const char* e = getenv("AC_REMAP_BLOCK"); int v = e ? atoi(e) : 4096; v = v < 64 ? 64 : (v > 65536 ? 65536 : v); return (u32)(v & ~63); }
 [[maybe_unused]] static bool fill_novel_plain() { const char* e = getenv("AC_FILL_NOVEL"); return e && atoi(e) == 0; }      // 0: a thread per bitmap word
+[[maybe_unused]] static u32 seq_bytes_per_thread() { const char* e = getenv("AC_SEQ_BYTES"); int v = e ? atoi(e) : 16; return (u32)(v < 1 ? 1 : (v > 256 ? 256 : v)); }      // plain sequence writers: output bytes per thread
 [[maybe_unused]] static int degree_flags() { const char* e = getenv("AC_DEGREE_FLAGS"); return e ? atoi(e) : 1; }      // 0: every degree by probing; 2: sibling bits inside the one-pass kernel; 1: two passes
 [[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); if (!e) return -1; int v = atoi(e); return v < 0 ? 0 : (v > 3 ? 3 : v); }      // -1 = automatic
 [[maybe_unused]] static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
@@ -908,8 +909,9 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         // the indexed / LDS-tiled writer pays for its index (four small launches) from ~16 MB of output on: config C (7.8 MB) 6.02 vs
         // 5.97 ms per build with it, E' (45 MB) 24.9 vs 26.6, config D (126 MB): see DESIGN.md §6
         if (seq_writer_plain() || (n_bytes < ((u64)16 << 20) && !seq_writer_forced())) {
-            if (mode == 0) launch((n_bytes + 63) / 64, SeqFunctor{g.bits.ptr(), off, ustartpos.ptr(), ulen.ptr(), uorient.ptr(), U, n_bytes, (int)(k / 2), dst});
-            else launch((n_bytes + 63) / 64, MaterializeFunctor{*es, off, U, n_bytes, dst});
+            const u32 per = seq_bytes_per_thread();
+            if (mode == 0) launch((n_bytes + per - 1) / per, SeqFunctor{g.bits.ptr(), off, ustartpos.ptr(), ulen.ptr(), uorient.ptr(), U, n_bytes, (int)(k / 2), dst, per});
+            else launch((n_bytes + per - 1) / per, MaterializeFunctor{*es, off, U, n_bytes, dst, per});
             return;
         }
 #ifndef AC_EMU
@@ -1068,6 +1070,15 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
 
     // K15b second renumber_unitigs (graph_simplification.rs:39): a stable sort of the CURRENT order on the new
     // sequences; K16 per-unitig outputs in final order, links in get_links_for_gfa order, paths in final numbers
+    // D2H on a second stream, each array as soon as it is final, straight into pinned blocks owned by the result; the
+    // paths go in four chunks, each copied while the next is still being renumbered.
+    SideStream& side = SideStream::get();
+    SideStream::Guard side_guard;
+    if (want_graph) {
+        out->seq_block = PinnedPool::get().alloc(final_total);
+        side.after_main();     // sequences are final since the materialise step: their copy runs under the second renumbering
+        copy_d2h_async(out->seq_block.p, cur, final_total, side.stream());
+    }
     DBuf<u32> order2(U);
     copy_d2d(order2.ptr(), order1.ptr(), (size_t)U * 4);
     renumber_sort(order2, U, clen.ptr(), coff.ptr(), cur, depth.ptr(), renum_flag.ptr());
@@ -1077,18 +1088,9 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     double* d_depth = (double*)(meta.ptr() + (size_t)U * 8);
     u32* d_seq_len = (u32*)(meta.ptr() + (size_t)U * 16);
     lcount.fill_bytes(0);
-    // D2H on a second stream, each array as soon as it is final, straight into pinned blocks owned by the result; the
-    // paths go in four chunks, each copied while the next is still being renumbered.
-    SideStream& side = SideStream::get();
-    SideStream::Guard side_guard;
     out->k = k;
     out->n_kmers = 2 * (u64)N;
     out->n_unitigs = U;
-    if (want_graph) {
-        out->seq_block = PinnedPool::get().alloc(final_total);
-        side.after_main();     // sequences are final since the materialise step
-        copy_d2h_async(out->seq_block.p, cur, final_total, side.stream());
-    }
     launch(U, FinalMetaFunctor{order2.ptr(), coff.ptr(), clen.ptr(), depth.ptr(), lcnt.ptr(), number_len.ptr(), d_seq_begin, d_depth,
                                d_seq_len, lcount.ptr()});
     if (want_graph) {

@@ -522,6 +522,17 @@ class SideStream {
         AC_HIP_CHECK(hipStreamWaitEvent(s, e, 0));
 #endif
     }
+    // An event that fires when everything enqueued on the side stream so far is done (valid until 16 more events were taken).
+    void* mark() {
+#ifndef AC_EMU
+        stream_t s = stream();
+        hipEvent_t e = ev_[next_++ % 16];
+        AC_HIP_CHECK(hipEventRecord(e, s));
+        return (void*)e;
+#else
+        return nullptr;
+#endif
+    }
     void sync() noexcept {
 #ifndef AC_EMU
         if (created_) (void)hipStreamSynchronize(s_);

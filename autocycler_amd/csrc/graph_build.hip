@@ -381,6 +381,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static u32 remap_block() { const char* e = getenv("AC_REMAP_BLOCK"); int v = e ? atoi(e) : 4096; v = v < 64 ? 64 : (v > 65536 ? 65536 : v); return (u32)(v & ~63); }
 [[maybe_unused]] static bool fill_novel_plain() { const char* e = getenv("AC_FILL_NOVEL"); return e && atoi(e) == 0; }      // 0: a thread per bitmap word
 [[maybe_unused]] static u32 seq_bytes_per_thread() { const char* e = getenv("AC_SEQ_BYTES"); int v = e ? atoi(e) : 16; return (u32)(v < 1 ? 1 : (v > 256 ? 256 : v)); }      // plain sequence writers: output bytes per thread
+[[maybe_unused]] static bool pack_overlap() { const char* e = getenv("AC_PACK_OVERLAP"); return e ? atoi(e) != 0 : true; }      // 0: K1 of the device entry in one launch
 [[maybe_unused]] static int degree_flags() { const char* e = getenv("AC_DEGREE_FLAGS"); return e ? atoi(e) : 1; }      // 0: every degree by probing; 2: sibling bits inside the one-pass kernel; 1: two passes
 [[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); if (!e) return -1; int v = atoi(e); return v < 0 ? 0 : (v > 3 ? 3 : v); }      // -1 = automatic
 [[maybe_unused]] static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
@@ -494,6 +495,32 @@ struct GraphBuilder::Impl {
     // host entry: stream 0 only waited for the FIRST chunk of the packed upload; positions below upload_avail are on the device, the
     // rest arrives while the first insert phases run (upload_done = the event behind the last chunk)
     void* upload_done = nullptr; u64 upload_avail = 0; bool upload_pending = false;
+    // K1 of the device entry in two launches: the head of the text — what the first insert phase reads — on stream 0, the rest on the
+    // side stream, under that first phase (a bandwidth-bound pack next to a CAS-bound insert); the insert waits for the rest before
+    // its second phase, through the same hook as the host entry's chunked upload.
+    void pack_overlapped(u32 hint) {
+        PackedText& pt = loc;
+        if (pt.packed) return;
+#ifndef AC_EMU
+        const u64 p_end_all = pt.n_text - (u64)k + 1;
+        const u64 first = std::max<u64>(p_end_all / std::max<u32>(hint, 1), 1u << 16);
+        const u64 H = (first + (u64)k + 8192 + 4095) & ~4095ULL;      // (Impl::insert: a phase that ends at pe reads below pe + k + 8192)
+        // only next to a first phase that claims into a cache-sized table (config C: 5.15 -> 5.08 ms): where the table is far larger
+        // (config D: 4 GB) that phase is bound by HBM lines itself and the pack beside it costs more than it hides (28.96 -> 29.13)
+        const u64 cap_est = next_pow2(std::max<u64>(1024, pt.n_bases / std::max<u32>(hint, 1) * 3 + 4096));
+        if (pack_overlap() && cap_est <= (1ULL << 25) && H + (1u << 22) < pt.n_text) {
+            pt.pack_alloc();
+            launch(H / 32, PackFunctor{pt.d_text, pt.n_text, pt.bits.ptr(), (u32*)pt.mask.ptr(), 0});
+            SideStream& side = SideStream::get();
+            side.after_main();      // (the fills of bits / mask went out with the head's launch)
+            launch((pt.n_text + 31) / 32 - H / 32, PackFunctor{pt.d_text, pt.n_text, pt.bits.ptr(), (u32*)pt.mask.ptr(), H / 32}, side.stream());
+            upload_done = side.mark(); upload_avail = H; upload_pending = true;
+            pt.packed = true;
+            return;
+        }
+#endif
+        pt.pack();
+    }
     Table graph_table() const { return Table{const_cast<u64*>(slots.ptr()), cap - 1, occ.ptr(), nullptr, n_owners, my_owner, nullptr}; }
     template <int W> void fragments();
     template <int W> void table();                      // K2, K3 on G
@@ -881,7 +908,9 @@ template <int W> void GraphBuilder::Impl::walk() {
     maybe_dest_valid = filter;
     if (filter) { maybe_dest.alloc((u64)U * 2); launch((u64)U * 2, MaybeDestFunctor{links.ptr(), maybe_dest.ptr()}); }
     launch((u64)U * 10, WlinkFlagFunctor{filter ? maybe_dest.ptr() : nullptr, wlinks.ptr(), counters.ptr() + 4});
-    launch(n_walkers, PathWalkFunctor<W>{t, g, tb, nv, uc, wlinks.ptr(), PC, stage.ptr(), wcount.ptr(), seq_tid.ptr(), seq_j.ptr(),
+    DBuf<V16> uinfo(U);
+    launch(U, WalkInfoFunctor{uc, filter ? maybe_dest.ptr() : nullptr, uinfo.ptr()});
+    launch(n_walkers, PathWalkFunctor<W>{t, g, tb, nv, uc, uinfo.ptr(), wlinks.ptr(), PC, stage.ptr(), wcount.ptr(), seq_tid.ptr(), seq_j.ptr(),
                                         depth.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), counters.ptr() + 4, filter ? maybe_dest.ptr() : nullptr,
                                         path_diag(), walk_answers, n_walkers});
     exclusive_scan_u64(wcount.ptr(), woff.ptr(), n_walkers + 1);
@@ -1644,7 +1673,7 @@ void GraphBuilder::build(uint32_t assembly_count_hint, FinalGraph* out) {
     m.begin(&tm_);
     m.G = &m.loc;
     m.check_sizes(m.loc);
-    m.loc.pack();
+    m.pack_overlapped(assembly_count_hint);
     m.lap(&tm_.pack);
     AC_DISPATCH_W(table, (*impl_))
     AC_DISPATCH_W(degrees, (*impl_))

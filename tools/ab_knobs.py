@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--host-entry", action="store_true", help="build through ac_compress_build from host views (the T_hot bracket: upload included)")
     ap.add_argument("--workload", type=str, default=None, help="a named workload of autocycler_amd.synth.WORKLOADS (overrides --assemblies/--genome/--kmer)")
+    ap.add_argument("--lib", type=str, default=None, help="another build of the library (e.g. one made with -DAC_MEASUREMENT_KNOBS)")
     ap.add_argument("--emu", action="store_true", help="dry run of this script on the CPU emulation (tests/_emu), small sizes only")
     ap.add_argument("--variants", type=str, default="base;AC_TABLE_SHIFT=0,AC_MINKEY_VARIANT=0;AC_TABLE_SHIFT=2;base")
     args = ap.parse_args()
@@ -39,7 +40,7 @@ def main():
         lib = _capi.load_library(emu_lib.emu_path())
         hip = None
     else:
-        lib = _capi.load_library()
+        lib = _capi.load_library(args.lib)
         hip = C.CDLL("libamdhip64.so.7")
     lib.ac_seqs_views.restype = C.POINTER(_capi.SeqView)
     lib.ac_seqs_count.restype = C.c_uint32

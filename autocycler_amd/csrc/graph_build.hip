@@ -357,7 +357,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 //                     insert phases while the upload's tail is in flight.
 //   AC_NO_MAILBOX     (read once) small read-backs through hipMemcpyAsync + synchronise instead of the mapped mailbox page.
 //   AC_INSERT_PROFILE (read once) per-wavefront cycle split of every insert launch on stderr (measurement).
-[[maybe_unused]] static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : 1; }
+[[maybe_unused]] static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : -1; }      // -1 = automatic
 [[maybe_unused]] static bool path_filter() { const char* e = getenv("AC_PATH_FILTER"); return e ? atoi(e) != 0 : true; }   // smallest positions only for possible expand_repeats destinations
 // AC_PATH_DIAG (skips the walk's depth atomics / position updates to price them: the result is WRONG when set) only exists in
 // builds made with -DAC_MEASUREMENT_KNOBS; the shipped library ignores the variable.
@@ -382,6 +382,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static bool fill_novel_plain() { const char* e = getenv("AC_FILL_NOVEL"); return e && atoi(e) == 0; }      // 0: a thread per bitmap word
 [[maybe_unused]] static u32 seq_bytes_per_thread() { const char* e = getenv("AC_SEQ_BYTES"); int v = e ? atoi(e) : 16; return (u32)(v < 1 ? 1 : (v > 256 ? 256 : v)); }      // plain sequence writers: output bytes per thread
 [[maybe_unused]] static bool pack_overlap() { const char* e = getenv("AC_PACK_OVERLAP"); return e ? atoi(e) != 0 : true; }      // 0: K1 of the device entry in one launch
+[[maybe_unused]] static int minkey_prefix_bases() { const char* e = getenv("AC_MINKEY_PREFIX_BASES"); int v = e ? atoi(e) : 31; return v < 1 ? 1 : (v > 31 ? 31 : v); }      // tests: a shorter prefix takes the full-key path often
 [[maybe_unused]] static int degree_flags() { const char* e = getenv("AC_DEGREE_FLAGS"); return e ? atoi(e) : 1; }      // 0: every degree by probing; 2: sibling bits inside the one-pass kernel; 1: two passes
 [[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); if (!e) return -1; int v = atoi(e); return v < 0 ? 0 : (v > 3 ? 3 : v); }      // -1 = automatic
 [[maybe_unused]] static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
@@ -814,8 +815,26 @@ template <int W> void GraphBuilder::Impl::unitigs() {
 
     // K8 min canonical k-mer per unitig
     DBuf<MinVal<W>> umin(U);
-    if constexpr (W <= 4) {
-        if (minkey_variant() == 1) {      // wavefront form: keys stay in registers
+    // Automatic: the prefix form pays one full key and one join per UNITIG to save a full key per K-MER — it wins with long keys and
+    // long unitigs (config D, k = 101, 128 k-mers per unitig: 2.13 -> 1.62 ms) and loses with short ones (config C, k = 51, 49 per
+    // unitig: 0.105 -> 0.157 ms; E', 5 per unitig: 0.56 -> 0.82 ms); keys wider than four words have no register form at all.
+    const int mk = minkey_variant() >= 0 ? minkey_variant() : ((W > 4 || (W >= 3 && N >= 32 * (u64)U)) ? 2 : 1);
+    if (mk == 2) {      // prefix form: (f, index, mark) per piece, one full key per unitig
+        const u64 n_waves = (N + 63) / 64;
+        DBuf<MinPre> upre(U), wfirst(n_waves), wlast(n_waves);
+        MinPreArgs a{t, npos.ptr(), scan.ptr(), N, upre.ptr(), wfirst.ptr(), wlast.ptr(), minkey_prefix_bases()};
+#ifdef AC_EMU
+        launch(n_waves, MinPreWaveEmuFunctor<W>{a});
+#else
+        const u64 blocks = (N + 255) / 256;
+        if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+        flush_fills();
+        hipLaunchKernelGGL(minpre_wave_kernel<W>, dim3((unsigned)blocks), dim3(256), 0, 0, a);
+        AC_HIP_CHECK(hipGetLastError());
+#endif
+        launch(U, MinFinishFunctor<W>{t, npos.ptr(), ustart.ptr(), U, N, upre.ptr(), wfirst.ptr(), wlast.ptr(), umin.ptr()});
+    } else if constexpr (W <= 4) {
+        if (mk == 1) {      // wavefront form: keys stay in registers
             const u64 n_waves = (N + 63) / 64;
             DBuf<MinVal<W>> wfirst(n_waves), wlast(n_waves);
             MinWaveArgs<W> a{t, npos.ptr(), scan.ptr(), N, umin.ptr(), wfirst.ptr(), wlast.ptr()};

@@ -3,7 +3,7 @@
 values in KiB per build): HBM-side bytes per build of the kernel bench.py prices the roofline on, calibrated on PackFunctor
 whose bytes are known exactly (reads n_text bytes, writes 0.375 n_text).
 
-    python tools/pmc_traffic.py FETCH.csv WRITE.csv N_TEXT TAG > profiles/pmc_traffic.json"""
+    python tools/pmc_traffic.py FETCH.csv WRITE.csv N_TEXT TAG [BUILDS_IN_THE_PASS=7] > profiles/pmc_traffic.json"""
 import csv
 import json
 import sys
@@ -13,29 +13,30 @@ def load(path):
     return {r["Name"]: float(r[[c for c in r if c.endswith("_per_build")][0]]) * 1024 for r in csv.DictReader(open(path))}
 
 
-def per_dispatch(path, pat):
-    """Bytes per dispatch of the kernels matching pat (PackFunctor also runs inside the end repair, so per-build is not per-call)."""
-    tot = n = 0.0
+def per_pack(path, pat, builds):
+    """Bytes per WHOLE-TEXT pack of the kernels matching pat.  The device entry packs the text in two dispatches per build (head on
+    stream 0, tail under the first insert phase) and the driver's end repair packs it once more in one: `builds` builds in the
+    pass => builds + 1 whole-text packs, however many dispatches that took."""
+    tot = 0.0
     for r in csv.DictReader(open(path)):
         if pat in r["Name"]:
             tot += float(r[[c for c in r if c.endswith("_sum")][0]]) * 1024
-            n += float(r["Dispatches"])
-    return tot / n if n else 0.0
+    return tot / (builds + 1)
 
 
-def main(fetch_csv, write_csv, n_text, tag):
+def main(fetch_csv, write_csv, n_text, tag, builds=7):
     f, w = load(fetch_csv), load(write_csv)
     pick = lambda d, pat: sum(v for k, v in d.items() if pat in k)
     n_text = int(n_text)
-    pf, pw = per_dispatch(fetch_csv, "PackFunctor"), per_dispatch(write_csv, "PackFunctor")
+    pf, pw = per_pack(fetch_csv, "PackFunctor", int(builds)), per_pack(write_csv, "PackFunctor", int(builds))
     fcal, wcal = pf / n_text, pw / (0.375 * n_text)
     fcorr = 2.0 if 0.4 < fcal < 0.6 else 1.0     # gfx950: 128-B requests tallied at 64 B (MI355X_MICROARCH.md, HBM section)
     kf, kw = pick(f, "insert_wave_kernel"), pick(w, "insert_wave_kernel")
     table = {k: {"fetch_raw": f.get(k, 0.0), "write_raw": w.get(k, 0.0), "hbm_side_bytes": f.get(k, 0.0) * fcorr + w.get(k, 0.0)}
              for k in sorted(set(f) | set(w), key=lambda k: -(f.get(k, 0.0) * fcorr + w.get(k, 0.0)))[:12]}
     print(json.dumps({
-        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), python bench.py --steps 2 "
-                  f"--warmup 1 --no-cpu-baseline on MI355X; profiles/{tag}_pmc_*_configC.csv",
+        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), tools/pmc_lean.sh (torch-free driver, "
+                  f"{builds} builds of config C per pass) on MI355X; profiles/{tag}_pmc_*_configC.csv",
         "kernel": "insert_wave_kernel<2> (3 phase launches per build, summed)",
         "fetch_size_raw_bytes": kf, "write_size_raw_bytes": kw,
         "calibration": {"kernel": "functor_kernel<PackFunctor>: reads n_text bytes with 16 B/lane loads, writes 0.375*n_text bytes",
@@ -48,4 +49,4 @@ def main(fetch_csv, write_csv, n_text, tag):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])

@@ -342,17 +342,26 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 // profiles/r03*_ab_knobs_configC.jsonl, profiles/r04*_ab_*.jsonl).  None of them changes a result (tests: *_tuning_knobs_*):
 //   AC_TABLE_SHIFT    k-mer table capacity = 2^n x the reference-style sizing.  Unset = automatic: 1 (load ~0.23 on similar
 //                     assemblies: short probe clusters) while the table stays about cache-sized, 0 for tables far beyond it.
-//   AC_MINKEY_VARIANT 1 (default) = wavefront segmented min with the keys in registers, 0 = key records + library reduce-by-key.
+//   AC_MINKEY_VARIANT seed k-mer per unitig: 2 = on a 64-bit key prefix, one full key per unitig; 1 = wavefront segmented min with the full
+//                     keys in registers; 0 = key records + library reduce-by-key.  Unset = automatic (2 for long keys and unitigs, else 1).
+//   AC_MINKEY_PREFIX_BASES   (tests) bases in that prefix, default 31.
 //   AC_SEED_RADIX_LIMIT  unitigs from which the seed order is W radix passes instead of the comparator merge sort (default 2^19).
-//   AC_PATH_CHUNK     text positions per path walker (default 256; 128, 512 and 1024 measured slower).
+//   AC_PATH_CHUNK     text positions per path walker (default: 5 x the mean unitig length, a power of two in [64, 2048]).
 //   AC_PATH_FILTER    1 (default): the walk keeps smallest positions only for unitig sides that can become expand_repeats
 //                     destinations.
 //   AC_REMAP_BLOCK    path entries per wavefront in the final renumbering.
 //   AC_INSERT_CHUNK / AC_INSERT_GROWTH / AC_INSERT_WAVES   insert phases: longest wavefront chunk, prefix growth factor, wavefronts per phase;
 //   AC_INSERT_ADAPT (default 1) / AC_INSERT_CHUNK_REST      redundant text: everything after the second phase in one launch, and its longest chunk (16384).
-//   AC_EXPAND_WAVE_LIMIT   junctions per level from which expand_repeats runs a thread instead of a wavefront per junction (65536).
+//   AC_EXPAND_WAVE_LIMIT   junctions per level from which expand_repeats runs a thread per junction (default: never);
+//   AC_EXPAND_GROUP        lanes per junction otherwise: 16 (default), 8, 32 or 64.
 //   AC_EXPAND_REWRITE_ALWAYS  rewrite the sequences contiguously after every host check of the expand passes (tests).
 //   AC_SEQ_WRITER     0 / 1 = always the search-per-thread / the indexed LDS-tiled sequence writers (default: by output size).
+//   AC_DEGREE_FLAGS   1 (default): degrees from the sibling bits the insert collects, probes only where they do not settle it (two
+//                     passes); 2: the same inside the one-pass kernel; 0: every degree by probing (what sharded builds and k < 3 do).
+//   AC_RENUM_TWO_PASS 1: renumber with two sorts (length | 32 bases | depth) instead of one (length | 16 bases); AC_RENUM_MAX_GROUP (tests).
+//   AC_FILL_NOVEL     0: novel list by a thread per bitmap word instead of the wavefront-cooperative kernel.
+//   AC_SEQ_BYTES      output bytes per thread of the plain sequence writers (16).
+//   AC_PACK_OVERLAP   0: K1 of the device entry in one launch (default: its tail under the first insert phase, cache-sized tables only).
 //   AC_UPLOAD_THREADS (16) / AC_HOST_PACK (1) / AC_UPLOAD_OVERLAP (1)   host entry: packing threads, 2-bit pack on the host, first
 //                     insert phases while the upload's tail is in flight.
 //   AC_NO_MAILBOX     (read once) small read-backs through hipMemcpyAsync + synchronise instead of the mapped mailbox page.
@@ -383,6 +392,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static u32 seq_bytes_per_thread() { const char* e = getenv("AC_SEQ_BYTES"); int v = e ? atoi(e) : 16; return (u32)(v < 1 ? 1 : (v > 256 ? 256 : v)); }      // plain sequence writers: output bytes per thread
 [[maybe_unused]] static bool pack_overlap() { const char* e = getenv("AC_PACK_OVERLAP"); return e ? atoi(e) != 0 : true; }      // 0: K1 of the device entry in one launch
 [[maybe_unused]] static int minkey_prefix_bases() { const char* e = getenv("AC_MINKEY_PREFIX_BASES"); int v = e ? atoi(e) : 31; return v < 1 ? 1 : (v > 31 ? 31 : v); }      // tests: a shorter prefix takes the full-key path often
+[[maybe_unused]] static u32 expand_group() { const char* e = getenv("AC_EXPAND_GROUP"); int v = e ? atoi(e) : 16; return (v == 8 || v == 32 || v == 64) ? (u32)v : 16u; }      // lanes per junction in expand_wave_kernel
 [[maybe_unused]] static int degree_flags() { const char* e = getenv("AC_DEGREE_FLAGS"); return e ? atoi(e) : 1; }      // 0: every degree by probing; 2: sibling bits inside the one-pass kernel; 1: two passes
 [[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); if (!e) return -1; int v = atoi(e); return v < 0 ? 0 : (v > 3 ? 3 : v); }      // -1 = automatic
 [[maybe_unused]] static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
@@ -391,7 +401,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static bool host_pack() { const char* e = getenv("AC_HOST_PACK"); return e ? atoi(e) != 0 : true; }      // 0: upload the text as bytes and pack on the device
 [[maybe_unused]] static bool insert_profile() { static const bool v = getenv("AC_INSERT_PROFILE") != nullptr; return v; }      // measurement only
 [[maybe_unused]] static bool expand_rewrite_always() { return getenv("AC_EXPAND_REWRITE_ALWAYS") != nullptr; }      // tests: compact the expand pool after every host check
-[[maybe_unused]] static u64 expand_wave_limit() { const char* e = getenv("AC_EXPAND_WAVE_LIMIT"); return e ? (u64)atoll(e) : 65536; }      // junctions per level from which expand_repeats runs a thread (not a wavefront) per junction
+[[maybe_unused]] static u64 expand_wave_limit() { const char* e = getenv("AC_EXPAND_WAVE_LIMIT"); return e ? (u64)atoll(e) : ~0ULL; }      // junctions per level from which expand_repeats runs a thread (not a wavefront) per junction
 #ifdef AC_EMU
 [[maybe_unused]] static bool seq_writer_plain() { return true; }
 #else
@@ -482,8 +492,7 @@ struct GraphBuilder::Impl {
         counters.alloc(8); counters.fill_bytes(0);
     }
     void check_sizes(const PackedText& t) const {
-        // (2^32 positions short of 2^40: a slot word whose upper half is all ones is then the empty slot and nothing else — MarkFunctor)
-        if (t.n_text >= POS_MASK - (1ULL << 32)) throw DeviceError("input too large for 40-bit text positions");
+        if (t.n_text >= POS_MASK) throw DeviceError("input too large for 40-bit text positions");
         if (t.n_seqs == 0 || t.n_text < (u64)k + 2) throw DeviceError("no sequences");
     }
     template <int W> void insert(const PackedText& t, u32 hint, DBuf<u64>* slots_out, u64* cap_out, u64* n_distinct_out, DBuf<u64>* bm_out, bool want_sib = false);
@@ -1078,17 +1087,22 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
 #ifdef AC_EMU
                         launch_full(cnt, ExpandFunctor{e, clist.ptr(), (u64)hb[lv], (u32)pool.size(), counters.ptr() + 7});
 #else
-                        // a wavefront per junction while a level is small (its time is one junction's dependency chain); a thread per
-                        // junction when a level has so many that the lanes are better spent on different junctions (mixed-species
-                        // inputs: a million short shifts per level)
+                        // sixteen lanes per junction (expand_wave_kernel; AC_EXPAND_GROUP).  The thread-per-junction form
+                        // (ExpandFunctor: the emulation's, and the definition the kernel is read against) used to take over on
+                        // levels of >= 65536 junctions, where a whole wavefront per junction wasted lanes; with four junctions per
+                        // wavefront it no longer wins anywhere (E' expand 4.41 -> 4.19 ms, config D 2.50 -> 2.15): AC_EXPAND_WAVE_LIMIT
                         if (cnt >= expand_wave_limit()) {
                             launch_full(cnt, ExpandFunctor{e, clist.ptr(), (u64)hb[lv], (u32)pool.size(), counters.ptr() + 7});
                             continue;
                         }
-                        const u64 blocks = (cnt + 3) / 4;
+                        const u32 G = expand_group();
+                        const u64 blocks = (cnt * G + 255) / 256;
                         if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
                         flush_fills();
-                        hipLaunchKernelGGL(expand_wave_kernel<W>, dim3((unsigned)blocks), dim3(256), 0, 0, e, clist.ptr(), (u64)hb[lv], cnt, (u32)pool.size(), counters.ptr() + 7);
+                        if (G == 8) hipLaunchKernelGGL((expand_wave_kernel<W, 8>), dim3((unsigned)blocks), dim3(256), 0, 0, e, clist.ptr(), (u64)hb[lv], cnt, (u32)pool.size(), counters.ptr() + 7);
+                        else if (G == 16) hipLaunchKernelGGL((expand_wave_kernel<W, 16>), dim3((unsigned)blocks), dim3(256), 0, 0, e, clist.ptr(), (u64)hb[lv], cnt, (u32)pool.size(), counters.ptr() + 7);
+                        else if (G == 32) hipLaunchKernelGGL((expand_wave_kernel<W, 32>), dim3((unsigned)blocks), dim3(256), 0, 0, e, clist.ptr(), (u64)hb[lv], cnt, (u32)pool.size(), counters.ptr() + 7);
+                        else hipLaunchKernelGGL((expand_wave_kernel<W, 64>), dim3((unsigned)blocks), dim3(256), 0, 0, e, clist.ptr(), (u64)hb[lv], cnt, (u32)pool.size(), counters.ptr() + 7);
                         AC_HIP_CHECK(hipGetLastError());
 #endif
                     }

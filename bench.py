@@ -495,7 +495,7 @@ def main():
             others = []      # stage timers of this run (a stage = the kernel + its small helpers)
             try:
                 pk = pj.get("per_kernel_per_build", {})
-                for pat, st_key, what in (("PathWalkFunctor", "paths", "path walk (K10) + compaction"), ("DegreeFunctor", "degree", "degree kernel (K5) + first flags")):
+                for pat, st_key, what in (("PathWalkFunctor", "paths", "path walk (K10) + compaction"), ("expand_wave_kernel", "expand", "expand_repeats junction kernel (K17) + level scheduling and the rewrite")):
                     b = sum(v["hbm_side_bytes"] for kk, v in pk.items() if pat in kk)
                     if b and stage.get(st_key):
                         others.append({"kernel": pat, "stage": what, "stage_ms": stage[st_key] * 1e3, "traffic": b,

@@ -253,7 +253,7 @@ def test_bench_line_contract_single_rank_dry_run():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in j["cpu_baseline"], key
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 1
-    assert [o["kernel"] for o in j["roofline_other"]] == ["PathWalkFunctor", "DegreeFunctor"]
+    assert [o["kernel"] for o in j["roofline_other"]] == ["PathWalkFunctor", "expand_wave_kernel"]
     assert j["cpu_baseline_full_size"]["gfa_md5"] == "c28d41ea9e4784f5f1dd06da6b3eb587"
     assert "dry run" in j["data"]
     # the host-RAM -> host-RAM bracket of the same region (SURVEY.md 8d T_hot), timed in the same run through ac_compress_build

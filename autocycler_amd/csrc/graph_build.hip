@@ -584,10 +584,10 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
         Table tb{sl.ptr(), c - 1, nullptr, nbm.ptr(), (&pt == &uni) ? n_owners : 1u, (&pt == &uni) ? my_owner : 0u, want_sib ? sflags.ptr() : nullptr};
         stream_sync();
 #ifndef AC_EMU
-        hipEvent_t e0, e1;
-        AC_HIP_CHECK(hipEventCreate(&e0)); AC_HIP_CHECK(hipEventCreate(&e1));
+        // the dominant kernel's duration, live: one event pair around EVERY phase launch, summed (what sits between the launches — the
+        // read-back after the second phase, the wait for the tail of the pack / upload — is not the kernel's time)
+        std::vector<hipEvent_t> evs;
         flush_fills();
-        AC_HIP_CHECK(hipEventRecord(e0, 0));
 #endif
         // Phases over geometrically growing prefixes: [0, n/A), [n/A, 2n/A), [2n/A, 4n/A), ...  (A = assembly
         // count): what a phase streams has, for similar assemblies, mostly been inserted by the earlier ones.
@@ -631,8 +631,13 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
                             (unsigned long long)h[1], h[1] ? (double)h[0] / h[1] : 0.0, (unsigned long long)h[3], h[3] ? (double)h[2] / h[3] : 0.0,
                             (unsigned long long)h[5], h[5] ? (double)h[4] / h[5] : 0.0, h[7] ? (double)h[6] / h[7] : 0.0, (unsigned long long)h[8]);
                 } else {
+                    hipEvent_t ea, eb;
+                    AC_HIP_CHECK(hipEventCreate(&ea)); AC_HIP_CHECK(hipEventCreate(&eb));
+                    evs.push_back(ea); evs.push_back(eb);
+                    AC_HIP_CHECK(hipEventRecord(ea, 0));
                     hipLaunchKernelGGL((insert_wave_kernel<W, false>), dim3((unsigned)blocks), dim3(256), 0, 0, t, tb, pb, pe, chunk, istats.ptr(), ierr, (u64*)nullptr);
                     AC_HIP_CHECK(hipGetLastError());
+                    AC_HIP_CHECK(hipEventRecord(eb, 0));
                 }
 #endif
             }
@@ -647,11 +652,12 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
         }
 #ifndef AC_EMU
         flush_fills();
-        AC_HIP_CHECK(hipEventRecord(e1, 0));
-        AC_HIP_CHECK(hipEventSynchronize(e1));
-        float ms = 0; AC_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-        tm->insert_kernel_ms += ms;
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (!evs.empty()) AC_HIP_CHECK(hipEventSynchronize(evs.back()));
+        for (size_t i = 0; i + 1 < evs.size(); i += 2) {
+            float ms = 0; AC_HIP_CHECK(hipEventElapsedTime(&ms, evs[i], evs[i + 1]));
+            tm->insert_kernel_ms += ms;
+        }
+        for (hipEvent_t e : evs) (void)hipEventDestroy(e);
 #endif
         tm->insert_launches += launches;
         std::vector<InsertStats> st = to_host(istats, 257);

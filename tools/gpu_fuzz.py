@@ -18,4 +18,25 @@ for seed in range(24, 424):
         fails += 1; print("FAIL seed", seed, "k", k, repr(e)[:300])
         if fails > 5: break
     n += 1
-print("gpu fuzz cases", n, "fails", fails, "time %.1f" % (time.time() - t0))
+print("gpu fuzz cases", n, "fails", fails, "time %.1f" % (time.time() - t0), flush=True)
+# random synthetic assembly sets (the CPU sweep's second part, on the device): long novel runs, multi-wavefront unitigs, real
+# expand_repeats levels — what the small adversarial cases do not reach
+from autocycler_amd import synth
+t0 = time.time(); m = 0
+for seed in range(1000, 1400):
+    r = random.Random(seed)
+    k = r.choice([21, 31, 51, 51, 77, 101])
+    na = r.randint(2, 10); genome = r.choice([8000, 20000, 50000, 120000]); plasmid = r.choice([0, 1500, 4000])
+    sub = r.choice([1e-4, 1e-3, 5e-3, 2e-2]); indel = r.choice([0, 1e-5, 1e-4, 1e-3])
+    seqs, fn, hd = [], [], []
+    for i, contigs in enumerate(synth.make_assemblies(na, genome=genome, plasmid=plasmid, sub=sub, indel=indel, seed=seed)):
+        for header, s in contigs:
+            seqs.append(s.tobytes().decode()); fn.append(f"assembly_{i:04d}.fasta"); hd.append(header)
+    try:
+        parity_util.check_case(k, seqs, fn, hd)
+    except Exception as e:
+        fails += 1; print("FAIL synthetic seed", seed, "k", k, repr(e)[:300])
+        if fails > 5: break
+    m += 1
+    if time.time() - t0 > float(sys.argv[1]) if len(sys.argv) > 1 else 240: break
+print("gpu synthetic sets", m, "fails", fails, "time %.1f" % (time.time() - t0))

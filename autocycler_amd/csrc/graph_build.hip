@@ -345,7 +345,9 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 //   AC_MINKEY_VARIANT seed k-mer per unitig: 2 = on a 64-bit key prefix, one full key per unitig; 1 = wavefront segmented min with the full
 //                     keys in registers; 0 = key records + library reduce-by-key.  Unset = automatic (2 for long keys and unitigs, else 1).
 //   AC_MINKEY_PREFIX_BASES   (tests) bases in that prefix, default 31.
-//   AC_SEED_RADIX_LIMIT  unitigs from which the seed order is W radix passes instead of the comparator merge sort (default 2^19).
+//   AC_SEED_PREFIX_SORT  1 (default): seed order by one sort on a 64-bit prefix of the seed keys + full-key ranking inside the groups that
+//                     agree on it (AC_SEED_PREFIX_BITS: tests); 0: the full-key sorts —
+//   AC_SEED_RADIX_LIMIT  unitigs from which those are W radix passes instead of the comparator merge sort (default 2^19).
 //   AC_PATH_CHUNK     text positions per path walker (default: 5 x the mean unitig length, a power of two in [64, 2048]).
 //   AC_PATH_FILTER    1 (default): the walk keeps smallest positions only for unitig sides that can become expand_repeats
 //                     destinations.
@@ -393,6 +395,8 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static bool pack_overlap() { const char* e = getenv("AC_PACK_OVERLAP"); return e ? atoi(e) != 0 : true; }      // 0: K1 of the device entry in one launch
 [[maybe_unused]] static int minkey_prefix_bases() { const char* e = getenv("AC_MINKEY_PREFIX_BASES"); int v = e ? atoi(e) : 31; return v < 1 ? 1 : (v > 31 ? 31 : v); }      // tests: a shorter prefix takes the full-key path often
 [[maybe_unused]] static u32 expand_group() { const char* e = getenv("AC_EXPAND_GROUP"); int v = e ? atoi(e) : 16; return (v == 8 || v == 32 || v == 64) ? (u32)v : 16u; }      // lanes per junction in expand_wave_kernel
+[[maybe_unused]] static bool seed_prefix_sort() { const char* e = getenv("AC_SEED_PREFIX_SORT"); return e ? atoi(e) != 0 : true; }      // 0: seed order by the full-key sorts
+[[maybe_unused]] static int seed_prefix_bits() { const char* e = getenv("AC_SEED_PREFIX_BITS"); int v = e ? atoi(e) : 64; return v < 1 ? 1 : (v > 64 ? 64 : v); }      // tests
 [[maybe_unused]] static int degree_flags() { const char* e = getenv("AC_DEGREE_FLAGS"); return e ? atoi(e) : 1; }      // 0: every degree by probing; 2: sibling bits inside the one-pass kernel; 1: two passes
 [[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); if (!e) return -1; int v = atoi(e); return v < 0 ? 0 : (v > 3 ? 3 : v); }      // -1 = automatic
 [[maybe_unused]] static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
@@ -789,9 +793,11 @@ template <int W> void GraphBuilder::Impl::degrees() {
     }
     if (sib.size() && degree_flags() == 1 && (!g.any_dots || es.keys)) {      // settle what the sibling bits settle, queue the rest, probe the queues
         DegWork wk;
-        wk.rcap = (u32)(N / DEG_REGIONS + N / (4 * DEG_REGIONS) + 64 * DEG_BATCH);
-        wk.ocap = N;
-        DBuf<u64> items((u64)DEG_LISTS * ((u64)DEG_REGIONS * wk.rcap + wk.ocap)); DBuf<u32> counts(DEG_LISTS * (DEG_REGIONS + 1));
+        // a k-mer whose window holds dots starts within k - 1 positions of a sequence end: at most 2 (k - 1) per sequence
+        const u64 max_generic = std::min<u64>(N, 2 * ((u64)k - 1) * g.n_seqs);
+        wk.rcap[0] = (u32)(N / DEG_REGIONS + N / (4 * DEG_REGIONS) + 64 * DEG_BATCH); wk.ocap[0] = N;
+        wk.rcap[1] = (u32)(max_generic / DEG_REGIONS + 64 * DEG_BATCH); wk.ocap[1] = max_generic;
+        DBuf<u64> items(wk.words()); DBuf<u32> counts(DEG_LISTS * (DEG_REGIONS + 1));
         counts.fill_bytes(0);
         wk.items = items.ptr(); wk.counts = counts.ptr();
         const u64 n_thr = (((N + DEG_BATCH - 1) / DEG_BATCH) + 63) & ~63ULL;
@@ -878,7 +884,17 @@ template <int W> void GraphBuilder::Impl::unitigs() {
     // K9 seed order = rank of the smallest k-mer
     order.alloc(U);
     launch(U, IotaFunctor{order.ptr()});
-    if constexpr (W <= 4) {
+    if (seed_prefix_sort()) {      // one sort on a 64-bit prefix of the seed keys, ties on full keys: any key width, any number of unitigs
+        DBuf<u64> wkey(U);
+        launch(U, SeedPrefixFunctor<W>{umin.ptr(), (int)k, wkey.ptr(), seed_prefix_bits()});
+        sort_pairs_u64_u32(wkey, order, U, 64);
+        DBuf<u32> settled(U);
+        launch(U, SeedTieFunctor<W>{order.ptr(), wkey.ptr(), U, umin.ptr(), settled.ptr()});
+        order = std::move(settled);
+        DBuf<MinVal<W>> sorted(U);
+        launch(U, GatherMinFunctor<W>{order.ptr(), umin.ptr(), sorted.ptr()});
+        umin = std::move(sorted);
+    } else if constexpr (W <= 4) {
         if ((u64)U >= seed_radix_limit()) {      // many unitigs (mixed-species graphs: millions): W stable LSD radix passes over the key words
             DBuf<u64> wkey(U);                    // (the comparator merge sort takes 2.4 ms for 3.5 M seeds, 5.3 ms for 6.5 M)
             for (int word = W - 1; word >= 0; word--) {

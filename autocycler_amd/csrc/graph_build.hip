@@ -1065,7 +1065,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             }
             DBuf<u64> lkey(C);
             launch(C, LevelKeyFunctor{level.ptr(), lkey.ptr()});
-            sort_pairs_u64_u32(lkey, clist, C, 64);
+            sort_pairs_u64_u32(lkey, clist, C, 32);      // (a radix sort of many candidates does four passes instead of eight)
             // first index of every level; [0] = number of levels (levels beyond the table: a second, exact read)
             const u32 LV_TABLE = 1024;
             DBuf<u32> bstart((u64)LV_TABLE + 2);

@@ -397,6 +397,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static u32 expand_group() { const char* e = getenv("AC_EXPAND_GROUP"); int v = e ? atoi(e) : 16; return (v == 8 || v == 32 || v == 64) ? (u32)v : 16u; }      // lanes per junction in expand_wave_kernel
 [[maybe_unused]] static bool seed_prefix_sort() { const char* e = getenv("AC_SEED_PREFIX_SORT"); return e ? atoi(e) != 0 : true; }      // 0: seed order by the full-key sorts
 [[maybe_unused]] static int seed_prefix_bits() { const char* e = getenv("AC_SEED_PREFIX_BITS"); int v = e ? atoi(e) : 64; return v < 1 ? 1 : (v > 64 ? 64 : v); }      // tests
+[[maybe_unused]] static u32 degree_region_cap() { const char* e = getenv("AC_DEGREE_REGION_CAP"); int v = e ? atoi(e) : 0; return (u32)(v < 0 ? 0 : v); }      // tests: entries per queue region (0 = sized from N)
 [[maybe_unused]] static int degree_flags() { const char* e = getenv("AC_DEGREE_FLAGS"); return e ? atoi(e) : 1; }      // 0: every degree by probing; 2: sibling bits inside the one-pass kernel; 1: two passes
 [[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); if (!e) return -1; int v = atoi(e); return v < 0 ? 0 : (v > 3 ? 3 : v); }      // -1 = automatic
 [[maybe_unused]] static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
@@ -797,6 +798,7 @@ template <int W> void GraphBuilder::Impl::degrees() {
         const u64 max_generic = std::min<u64>(N, 2 * ((u64)k - 1) * g.n_seqs);
         wk.rcap[0] = (u32)(N / DEG_REGIONS + N / (4 * DEG_REGIONS) + 64 * DEG_BATCH); wk.ocap[0] = N;
         wk.rcap[1] = (u32)(max_generic / DEG_REGIONS + 64 * DEG_BATCH); wk.ocap[1] = max_generic;
+        if (degree_region_cap()) { wk.rcap[0] = std::min(wk.rcap[0], degree_region_cap()); wk.rcap[1] = std::min(wk.rcap[1], degree_region_cap()); }      // tests: regions spill
         DBuf<u64> items(wk.words()); DBuf<u32> counts(DEG_LISTS * (DEG_REGIONS + 1));
         counts.fill_bytes(0);
         wk.items = items.ptr(); wk.counts = counts.ptr();

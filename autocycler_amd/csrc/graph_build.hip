@@ -364,8 +364,9 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 //   AC_FILL_NOVEL     0: novel list by a thread per bitmap word instead of the wavefront-cooperative kernel.
 //   AC_SEQ_BYTES      output bytes per thread of the plain sequence writers (16).
 //   AC_PACK_OVERLAP   0: K1 of the device entry in one launch (default: its tail under the first insert phase, cache-sized tables only).
-//   AC_UPLOAD_THREADS (16) / AC_HOST_PACK (1) / AC_UPLOAD_OVERLAP (1)   host entry: packing threads, 2-bit pack on the host, first
-//                     insert phases while the upload's tail is in flight.
+//   AC_UPLOAD_THREADS (16) / AC_HOST_PACK (1) / AC_UPLOAD_OVERLAP (1)   host entry: packing threads, 2-bit pack on the host, the
+//                     insert issued chunk by chunk while background threads still pack and send the rest (0: everything is sent
+//                     before anything else is issued); AC_UPLOAD_CHUNK_MB (64; 16, 32, 128), AC_UPLOAD_SLOTS (tests: staging slots).
 //   AC_NO_MAILBOX     (read once) small read-backs through hipMemcpyAsync + synchronise instead of the mapped mailbox page.
 //   AC_INSERT_PROFILE (read once) per-wavefront cycle split of every insert launch on stderr (measurement).
 [[maybe_unused]] static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : -1; }      // -1 = automatic
@@ -398,6 +399,8 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static bool seed_prefix_sort() { const char* e = getenv("AC_SEED_PREFIX_SORT"); return e ? atoi(e) != 0 : true; }      // 0: seed order by the full-key sorts
 [[maybe_unused]] static int seed_prefix_bits() { const char* e = getenv("AC_SEED_PREFIX_BITS"); int v = e ? atoi(e) : 64; return v < 1 ? 1 : (v > 64 ? 64 : v); }      // tests
 [[maybe_unused]] static u32 degree_region_cap() { const char* e = getenv("AC_DEGREE_REGION_CAP"); int v = e ? atoi(e) : 0; return (u32)(v < 0 ? 0 : v); }      // tests: entries per queue region (0 = sized from N)
+[[maybe_unused]] static u64 upload_chunk_bytes() { const char* e = getenv("AC_UPLOAD_CHUNK_MB"); int v = e ? atoi(e) : 64; return (u64)((v == 16 || v == 32 || v == 128) ? v : 64) << 20; }      // text bytes per upload chunk
+[[maybe_unused]] static int upload_slots() { const char* e = getenv("AC_UPLOAD_SLOTS"); int v = e ? atoi(e) : 1 << 20; return v < 1 ? 1 : v; }      // tests: fewer staging slots, so that chunks wait for one
 [[maybe_unused]] static int degree_flags() { const char* e = getenv("AC_DEGREE_FLAGS"); return e ? atoi(e) : 1; }      // 0: every degree by probing; 2: sibling bits inside the one-pass kernel; 1: two passes
 [[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); if (!e) return -1; int v = atoi(e); return v < 0 ? 0 : (v > 3 ? 3 : v); }      // -1 = automatic
 [[maybe_unused]] static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
@@ -510,6 +513,29 @@ struct GraphBuilder::Impl {
     // host entry: stream 0 only waited for the FIRST chunk of the packed upload; positions below upload_avail are on the device, the
     // rest arrives while the first insert phases run (upload_done = the event behind the last chunk)
     void* upload_done = nullptr; u64 upload_avail = 0; bool upload_pending = false;
+    // host entry, packed upload: the chunks are packed and sent by background threads while this thread already issues the insert
+    // phases — each phase first waits (host: until the copy of the chunks it reads has been ISSUED; stream 0: until it has LANDED).
+    struct UploadJob {
+#ifndef AC_EMU
+        const std::vector<SeqView>* seqs = nullptr;      // the caller's views: valid until the build has taken the last chunk
+        std::vector<uint64_t> off;
+        uint32_t k = 0; u64 n = 0, CH = 0, SUB = 0, n_chunks = 0, slot_bytes = 0; int NSLOT = 0, dev = 0;
+        hipStream_t up = nullptr, pk = nullptr;
+        u64* d_bits = nullptr; u32* d_mask = nullptr;
+        std::atomic<u64> next{0};
+        std::vector<std::atomic<u32>> done, slot_state, issued;      // slot_state: 0 untouched, 1 someone is waiting for the slot, 2 free
+        std::vector<hipEvent_t> landed;                               // per chunk: both of its copies are on the device
+        std::mutex hip_mu; std::string fail; std::atomic<bool> stop{false};
+        std::vector<std::thread> pool;
+        u64 next_wait = 0;                                            // chunks stream 0 already waits for
+        void run();
+#endif
+    };
+    UploadJob* job = nullptr;
+    u64 upload_rest_limit(u64 pb) const;      // where a piece of the one-launch rest that starts at pb may end so that one more chunk suffices
+    void need_text(u64 upto);      // everything below text position `upto` is on the device before whatever stream 0 gets next
+    void finish_upload();          // joins the uploaders (idempotent); throws what they threw
+    ~Impl();
     // K1 of the device entry in two launches: the head of the text — what the first insert phase reads — on stream 0, the rest on the
     // side stream, under that first phase (a bandwidth-bound pack next to a CAS-bound insert); the insert waits for the rest before
     // its second phase, through the same hook as the host entry's chunked upload.
@@ -607,14 +633,20 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
         while (pb < p_end_all) {
             u64 pe = (pb == 0) ? first : pb * insert_growth();
             if (rest_at_once || pe > p_end_all || p_end_all - pe < (1u << 16)) pe = p_end_all;
-            u64 len = pe - pb;
 #ifndef AC_EMU
             if (upload_pending && &pt == &loc && pe + (u64)k + 8192 > upload_avail) {      // this phase reads beyond the first uploaded chunk
                 flush_fills();
                 AC_HIP_CHECK(hipStreamWaitEvent(0, (hipEvent_t)upload_done, 0));
                 upload_pending = false;
             }
+            if (job && &pt == &loc) {
+                // the one-launch rest of a redundant text goes out chunk by chunk while the upload is still running: each piece as
+                // soon as the chunk it ends in has been sent
+                if (rest_at_once) pe = std::min<u64>(pe, upload_rest_limit(pb));
+                need_text(pe + (u64)k + 8192);
+            }
 #endif
+            const u64 len = pe - pb;
             {      // one wavefront per chunk: >= ~16 K wavefronts when the phase is long
                 u64 c = (len / insert_waves_target() + 63) & ~63ULL;
                 u32 chunk = (u32)std::min<u64>(std::max<u64>(c, 256), rest_at_once ? wave_chunk_rest() : wave_chunk_max());
@@ -1492,9 +1524,9 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
     const u64 n = loc.n_text;
     HostStager& st = HostStager::get();
     st.ensure();
-    const u64 CH = (u64)64 << 20, SUB = (u64)1 << 20;      // text bytes per chunk (one pair of copies) / per work item
+    const u64 CH = upload_chunk_bytes(), SUB = (u64)1 << 20;      // text bytes per chunk (one pair of copies) / per work item
     const u64 SLOT_BYTES = CH / 4 + CH / 8;                // codes + mask bits of one chunk
-    [[maybe_unused]] const int NSLOT = (int)((HostStager::SLOT * HostStager::NS) / SLOT_BYTES);
+    [[maybe_unused]] const int NSLOT = std::max(1, std::min((int)((HostStager::SLOT * HostStager::NS) / SLOT_BYTES), upload_slots()));
     [[maybe_unused]] const u64 n_chunks = (n + CH - 1) / CH, subs = CH / SUB;
     [[maybe_unused]] auto chunk_len = [&](u64 c) { return std::min(n, (c + 1) * CH) - c * CH; };
     [[maybe_unused]] auto slot_bits = [&](int sl) { return (u64*)(st.slot(0) + (u64)sl * SLOT_BYTES); };
@@ -1506,86 +1538,125 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
         pack_text_groups(seqs, off, k, n, b / 32, (e + 31) / 32, loc.bits.ptr() + b / 32, (u32*)loc.mask.ptr() + b / 32);
     }
 #else
-    int dev = 0;
-    AC_HIP_CHECK(hipGetDevice(&dev));
-    hipStream_t up = st.stream(), pk = st.pack_stream();
+    Impl::UploadJob* job = new Impl::UploadJob();
+    impl_->job = job;
+    job->seqs = &seqs; job->off = off; job->k = k; job->n = n; job->CH = CH; job->SUB = SUB; job->NSLOT = NSLOT; job->n_chunks = n_chunks;
+    job->slot_bytes = SLOT_BYTES;
+    AC_HIP_CHECK(hipGetDevice(&job->dev));
+    job->up = st.stream(); job->pk = st.pack_stream();
     flush_fills();
     AC_HIP_CHECK(hipEventRecord(st.begin(), 0));
-    AC_HIP_CHECK(hipStreamWaitEvent(pk, st.begin(), 0));
-    loc.pack_alloc(pk);                                    // zero codes / all-ones mask beyond the text (and under it, until the copies land)
-    AC_HIP_CHECK(hipEventRecord(st.copied(), pk));
-    AC_HIP_CHECK(hipStreamWaitEvent(up, st.copied(), 0));
-    std::atomic<u64> next{0};
-    std::vector<std::atomic<u32>> done(n_chunks), slot_state(n_chunks);      // slot_state: 0 untouched, 1 someone is waiting for the slot, 2 free
-    for (auto& x : done) x.store(0);
-    for (auto& x : slot_state) x.store(0);
-    std::vector<std::atomic<u32>> issued(n_chunks);
-    for (auto& x : issued) x.store(0);
-    std::mutex hip_mu;
-    std::string fail;
-    std::atomic<bool> stop{false};
-    u64* const d_bits = loc.bits.ptr();
-    u32* const d_mask = (u32*)loc.mask.ptr();
-    auto worker = [&] {
-        try {
-            AC_HIP_CHECK(hipSetDevice(dev));
-            for (u64 item; (item = next.fetch_add(1)) < n_chunks * subs && !stop.load();) {
-                const u64 c = item / subs, sub = item % subs;
-                const u64 clen = chunk_len(c);
-                if (sub * SUB >= clen) continue;
-                const int sl = (int)(c % (u64)NSLOT);
-                if (c >= (u64)NSLOT) {      // the chunk that used this slot before must have left it: one thread waits, the others watch it
-                    u32 expect = 0;
-                    if (slot_state[c].compare_exchange_strong(expect, 1)) {
-                        while (!issued[c - NSLOT].load(std::memory_order_acquire) && !stop.load()) std::this_thread::yield();
-                        if (!stop.load()) AC_HIP_CHECK(hipEventSynchronize(st.event(sl)));
-                        slot_state[c].store(2, std::memory_order_release);
-                    } else {
-                        while (slot_state[c].load(std::memory_order_acquire) != 2 && !stop.load()) std::this_thread::yield();
-                    }
-                    if (stop.load()) break;
-                }
-                const u64 b = c * CH + sub * SUB, e = std::min(c * CH + clen, b + SUB);
-                pack_text_groups(seqs, off, k, n, b / 32, (e + 31) / 32, slot_bits(sl) + sub * SUB / 32, slot_mask(sl) + sub * SUB / 32);
-                const u32 n_sub = (u32)((clen + SUB - 1) / SUB);
-                if (done[c].fetch_add(1, std::memory_order_acq_rel) + 1 == n_sub) {      // the chunk is complete: send it
-                    const u64 g0 = c * CH / 32, ng = (clen + 31) / 32;
-                    std::lock_guard<std::mutex> lock(hip_mu);
-                    // codes and mask bits of a chunk travel on two streams (two copy engines): the smaller copy no longer sits
-                    // between two big ones on one queue.  The slot is free again when both have left it.
-                    AC_HIP_CHECK(hipMemcpyAsync(d_mask + g0, slot_mask(sl), ng * 4, hipMemcpyHostToDevice, pk));
-                    AC_HIP_CHECK(hipEventRecord(st.copied(), pk));
-                    AC_HIP_CHECK(hipMemcpyAsync(d_bits + g0, slot_bits(sl), ng * 8, hipMemcpyHostToDevice, up));
-                    AC_HIP_CHECK(hipStreamWaitEvent(up, st.copied(), 0));
-                    AC_HIP_CHECK(hipEventRecord(st.event(sl), up));
-                    if (c == 0) AC_HIP_CHECK(hipEventRecord(st.first(), up));
-                    issued[c].store(1, std::memory_order_release);
-                }
-            }
-        } catch (const std::exception& ex) {
-            std::lock_guard<std::mutex> lock(hip_mu);
-            if (fail.empty()) fail = ex.what();
-            stop.store(true);
-        }
-    };
+    AC_HIP_CHECK(hipStreamWaitEvent(job->pk, st.begin(), 0));
+    loc.pack_alloc(job->pk);                               // zero codes / all-ones mask beyond the text (and under it, until the copies land)
+    AC_HIP_CHECK(hipEventRecord(st.copied(), job->pk));
+    AC_HIP_CHECK(hipStreamWaitEvent(job->up, st.copied(), 0));
+    job->d_bits = loc.bits.ptr(); job->d_mask = (u32*)loc.mask.ptr();
+    job->done = std::vector<std::atomic<u32>>(n_chunks); job->slot_state = std::vector<std::atomic<u32>>(n_chunks);
+    job->issued = std::vector<std::atomic<u32>>(n_chunks);
+    for (u64 c = 0; c < n_chunks; c++) { job->done[c].store(0); job->slot_state[c].store(0); job->issued[c].store(0); }
+    job->landed.resize(n_chunks);
+    for (auto& e : job->landed) AC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const int T = (int)std::max<u64>(1, std::min<u64>({(n + SUB - 1) / SUB, upload_threads(), (u64)std::max(1u, std::thread::hardware_concurrency())}));
-    std::vector<std::thread> pool;
-    for (int i = 1; i < T; i++) pool.emplace_back(worker);
-    worker();
-    for (auto& t : pool) t.join();
-    if (!fail.empty()) { (void)hipStreamSynchronize(up); (void)hipStreamSynchronize(pk); throw DeviceError(fail); }
-    AC_HIP_CHECK(hipEventRecord(st.done(), up));
-    // stream 0 goes ahead as soon as the FIRST chunk is there: the first insert phases only read the head of the text, and the
-    // insert waits for `done` before it launches anything that reads further (Impl::insert)
-    const bool overlap = upload_overlap() && n > CH;
-    AC_HIP_CHECK(hipStreamWaitEvent(0, overlap ? st.first() : st.done(), 0));
-    impl_->upload_done = (void*)st.done();
-    impl_->upload_avail = std::min(n, CH);
-    impl_->upload_pending = overlap;
-    st.timed = true;
+    for (int i = 0; i < T; i++) job->pool.emplace_back([job] { job->run(); });
+    // This thread goes on to the build: the insert waits for the chunks as it gets to them (Impl::need_text).  Without the overlap
+    // (AC_UPLOAD_OVERLAP=0) everything is on the device before anything else is issued.
+    if (!upload_overlap()) { impl_->need_text(n); impl_->finish_upload(); }
 #endif
     loc.packed = true;
 }
+
+#ifndef AC_EMU
+void GraphBuilder::Impl::UploadJob::run() {
+    HostStager& st = HostStager::get();
+    const u64 subs = CH / SUB;
+    auto chunk_len = [&](u64 c) { return std::min(n, (c + 1) * CH) - c * CH; };
+    auto slot_bits = [&](int sl) { return (u64*)(st.slot(0) + (u64)sl * slot_bytes); };
+    auto slot_mask = [&](int sl) { return (u32*)(st.slot(0) + (u64)sl * slot_bytes + CH / 4); };
+    try {
+        AC_HIP_CHECK(hipSetDevice(dev));
+        for (u64 item; (item = next.fetch_add(1)) < n_chunks * subs && !stop.load();) {
+            const u64 c = item / subs, sub = item % subs;
+            const u64 clen = chunk_len(c);
+            if (sub * SUB >= clen) continue;
+            const int sl = (int)(c % (u64)NSLOT);
+            if (c >= (u64)NSLOT) {      // the chunk that used this slot before must have left it: one thread waits, the others watch it
+                u32 expect = 0;
+                if (slot_state[c].compare_exchange_strong(expect, 1)) {
+                    while (!issued[c - NSLOT].load(std::memory_order_acquire) && !stop.load()) std::this_thread::yield();
+                    if (!stop.load()) AC_HIP_CHECK(hipEventSynchronize(landed[c - NSLOT]));
+                    slot_state[c].store(2, std::memory_order_release);
+                } else {
+                    while (slot_state[c].load(std::memory_order_acquire) != 2 && !stop.load()) std::this_thread::yield();
+                }
+                if (stop.load()) break;
+            }
+            const u64 b = c * CH + sub * SUB, e = std::min(c * CH + clen, b + SUB);
+            pack_text_groups(*seqs, off, k, n, b / 32, (e + 31) / 32, slot_bits(sl) + sub * SUB / 32, slot_mask(sl) + sub * SUB / 32);
+            const u32 n_sub = (u32)((clen + SUB - 1) / SUB);
+            if (done[c].fetch_add(1, std::memory_order_acq_rel) + 1 == n_sub) {      // the chunk is complete: send it
+                const u64 g0 = c * CH / 32, ng = (clen + 31) / 32;
+                std::lock_guard<std::mutex> lock(hip_mu);
+                // codes and mask bits of a chunk travel on two streams (two copy engines): the smaller copy no longer sits
+                // between two big ones on one queue.  The chunk has landed (and its slot is free again) when both have.
+                AC_HIP_CHECK(hipMemcpyAsync(d_mask + g0, slot_mask(sl), ng * 4, hipMemcpyHostToDevice, pk));
+                AC_HIP_CHECK(hipEventRecord(st.copied(), pk));
+                AC_HIP_CHECK(hipMemcpyAsync(d_bits + g0, slot_bits(sl), ng * 8, hipMemcpyHostToDevice, up));
+                AC_HIP_CHECK(hipStreamWaitEvent(up, st.copied(), 0));
+                AC_HIP_CHECK(hipEventRecord(landed[c], up));
+                issued[c].store(1, std::memory_order_release);
+            }
+        }
+    } catch (const std::exception& ex) {
+        std::lock_guard<std::mutex> lock(hip_mu);
+        if (fail.empty()) fail = ex.what();
+        stop.store(true);
+    }
+}
+void GraphBuilder::Impl::need_text(u64 upto) {
+    if (!job) return;
+    while (job->next_wait < job->n_chunks && job->next_wait * job->CH < upto) {
+        const u64 c = job->next_wait;
+        while (!job->issued[c].load(std::memory_order_acquire) && !job->stop.load()) std::this_thread::yield();
+        if (job->stop.load()) finish_upload();      // throws
+        flush_fills();
+        AC_HIP_CHECK(hipStreamWaitEvent(0, job->landed[c], 0));
+        job->next_wait++;
+    }
+    if (job->next_wait == job->n_chunks) finish_upload();
+}
+u64 GraphBuilder::Impl::upload_rest_limit(u64 pb) const {
+    if (!job) return ~0ULL;
+    for (u64 c = job->next_wait; c < job->n_chunks; c++) {      // the end of the first chunk that gives this launch something to do
+        const u64 end = std::min(job->n, (c + 1) * job->CH);
+        if (c + 1 == job->n_chunks) break;
+        if (end > pb + (u64)k + 8192 + (1u << 20)) return end - (u64)k - 8192;
+    }
+    return ~0ULL;
+}
+void GraphBuilder::Impl::finish_upload() {
+    if (!job) return;
+    UploadJob* j = job;
+    job = nullptr;
+    for (auto& t : j->pool) t.join();
+    HostStager& st = HostStager::get();
+    std::string fail = j->fail;
+    if (fail.empty()) {
+        if (hipEventRecord(st.done(), j->up) != hipSuccess) fail = "hipEventRecord failed";
+        st.timed = true;
+    } else { (void)hipStreamSynchronize(j->up); (void)hipStreamSynchronize(j->pk); }
+    for (auto& e : j->landed) (void)hipEventDestroy(e);      // (a destroyed event that a stream still waits for stays valid until then)
+    delete j;
+    if (!fail.empty()) throw DeviceError(fail);
+}
+GraphBuilder::Impl::~Impl() {
+    if (job) { job->stop.store(true); try { finish_upload(); } catch (...) {} }
+}
+#else
+void GraphBuilder::Impl::need_text(u64) {}
+u64 GraphBuilder::Impl::upload_rest_limit(u64) const { return ~0ULL; }
+void GraphBuilder::Impl::finish_upload() {}
+GraphBuilder::Impl::~Impl() {}
+#endif
 
 void GraphBuilder::set_sequences_host(const std::vector<SeqView>& seqs, bool pack_now) {
     const double t0 = now_s();

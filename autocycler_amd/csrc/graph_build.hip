@@ -1463,10 +1463,38 @@ __attribute__((target("avx2,bmi2"))) static void pack_groups_avx2(const u8* t, u
                   (_pext_u64(__builtin_bswap64(q[2]), M) << 16) | _pext_u64(__builtin_bswap64(q[3]), M);
     }
 }
+// Two groups (64 bytes) per step with AVX-512: codes ((ch >> 1) ^ (ch >> 2)) & 3 under the "is a base" mask, four of them folded into
+// a byte by two multiply-adds (4 a + b per byte pair, then 16 x + y per pair of those), sixteen bytes narrowed out of the dwords and
+// reversed inside each half so that the first base ends up most significant; the mask bits are the compare masks as they come.
+__attribute__((target("avx512f,avx512bw,avx512vl,ssse3"))) static void pack_groups_avx512(const u8* t, u64 n_groups, u64* bits, u32* mask) {
+    const __m512i vA = _mm512_set1_epi8('A'), vC = _mm512_set1_epi8('C'), vG = _mm512_set1_epi8('G'), vT = _mm512_set1_epi8('T');
+    const __m512i three = _mm512_set1_epi8(3);
+    const __m512i w1 = _mm512_set1_epi16(0x0104);      // per byte pair (first, second): 4 * first + second   (low byte = first in memory)
+    const __m512i w2 = _mm512_set1_epi32(0x00010010);  // per word pair: 16 * first + second
+    const __m128i rev = _mm_set_epi8(8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7);
+    u64 g = 0;
+    for (; g + 2 <= n_groups; g += 2) {
+        const __m512i v = _mm512_loadu_si512((const void*)(t + g * 32));
+        const __mmask64 good = _mm512_cmpeq_epi8_mask(v, vA) | _mm512_cmpeq_epi8_mask(v, vC) | _mm512_cmpeq_epi8_mask(v, vG) | _mm512_cmpeq_epi8_mask(v, vT);
+        __m512i c = _mm512_and_si512(_mm512_xor_si512(_mm512_srli_epi16(v, 1), _mm512_srli_epi16(v, 2)), three);
+        c = _mm512_maskz_mov_epi8(good, c);
+        const __m512i n16 = _mm512_maddubs_epi16(c, w1);        // 16-bit lanes: 4 * b0 + b1
+        const __m512i n32 = _mm512_madd_epi16(n16, w2);         // 32-bit lanes: 16 * (4 b0 + b1) + (4 b2 + b3) = four bases, first most significant
+        const __m128i by = _mm_shuffle_epi8(_mm512_cvtepi32_epi8(n32), rev);
+        _mm_storeu_si128((__m128i*)(bits + g), by);
+        const u64 bad = ~(u64)good;
+        mask[g] = (u32)bad; mask[g + 1] = (u32)(bad >> 32);
+    }
+    if (g < n_groups) pack_groups_avx2(t + g * 32, n_groups - g, bits + g, mask + g);
+}
 #endif
 static void pack_groups(const u8* t, u64 n_groups, u64* bits, u32* mask) {
 #if defined(__x86_64__)
-    static const bool fast = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && getenv("AC_PACK_SCALAR") == nullptr;
+    static const bool simd_off = getenv("AC_PACK_SCALAR") != nullptr;
+    static const bool fast = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !simd_off;
+    static const bool wide = fast && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") &&
+                             getenv("AC_PACK_AVX2") == nullptr;
+    if (wide) { pack_groups_avx512(t, n_groups, bits, mask); return; }
     if (fast) { pack_groups_avx2(t, n_groups, bits, mask); return; }
 #endif
     pack_groups_scalar(t, n_groups, bits, mask);

@@ -129,3 +129,30 @@ def c_client_matches_the_oracle(tmp_path, k, seqs, assembly_count):
     assert pr.returncode == 0, pr.stderr[-2000:]
     assert pr.stdout == gfa_o
     assert f"kmers {st['kmers']} pre {st['unitigs_pre']} {st['links_pre']} {st['length_pre']} post {st['unitigs_post']} {st['links_post']} {st['length_post']}" in pr.stderr
+
+
+def host_pack_simd_equals_scalar(lib_path):
+    """K1 on the host (the packed upload of ac_compress_build): the AVX2 / BMI2 loop == the portable loop == the definition, on
+    bytes of every kind (bases, dots, separators, lower case, arbitrary), at lengths around the 32-byte groups."""
+    import ctypes as C
+    import numpy as np
+    from autocycler_amd import _capi
+    lib = _capi.load_library(lib_path)
+    rng = np.random.default_rng(5)
+    for n in (1, 31, 32, 33, 64, 1000, 4096 + 17, 100_003):
+        pool = np.frombuffer(b"ACGTACGTACGTACGT.$acgtN\x00\xff", dtype=np.uint8)
+        text = pool[rng.integers(0, len(pool), size=n)].copy()
+        g = (n + 31) // 32
+        outs = []
+        for scalar in (0, 1):
+            bits = np.zeros(g, dtype=np.uint64); mask = np.zeros(g, dtype=np.uint32)
+            assert lib.ac_pack_text(text.ctypes.data_as(C.c_void_p), C.c_uint64(n), bits.ctypes.data_as(C.c_void_p), mask.ctypes.data_as(C.c_void_p),
+                                    C.c_int(scalar)) == 0
+            outs.append((bits, mask))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        padded = np.concatenate([text, np.full(g * 32 - n, ord("$"), dtype=np.uint8)]).reshape(g, 32)
+        good = np.isin(padded, np.frombuffer(b"ACGT", dtype=np.uint8))
+        code = np.where(good, ((padded >> 1) ^ (padded >> 2)) & 3, 0).astype(np.uint64)
+        want_bits = (code << (62 - 2 * np.arange(32, dtype=np.uint64))).sum(axis=1, dtype=np.uint64)
+        want_mask = ((~good).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(axis=1).astype(np.uint32)
+        assert np.array_equal(outs[0][0], want_bits) and np.array_equal(outs[0][1], want_mask)

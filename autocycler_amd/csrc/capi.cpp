@@ -20,6 +20,8 @@
 #include <filesystem>
 #include <fstream>
 #include <chrono>
+#include <fcntl.h>
+#include <unistd.h>
 #include "device_rt.hpp"
 
 using namespace ac;
@@ -112,6 +114,34 @@ static void validate_layout(uint32_t k, uint64_t n_text, const uint64_t* off, co
 static void build_graph(GraphBuilder& b, uint32_t assembly_count, ac_graph* h) {
     b.build(assembly_count, &h->g);
     h->tm = b.timings();
+}
+
+// Writes the pieces one behind the other into `path`, each at its own offset by its own thread (pwrite): the GFA of config C is
+// 95 MB.  With the S and L lines formatted by several threads too (gfa_chunks) the write stage of the whole command went from 48 to
+// 26 ms (profiles/r07l_e2e_configC.log).
+static void write_pieces(const std::string& path, const std::vector<std::string>& pieces, int threads) {
+    int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) throw UserError("failed to write " + path);
+    std::vector<uint64_t> at(pieces.size() + 1, 0);
+    for (size_t i = 0; i < pieces.size(); i++) at[i + 1] = at[i] + pieces[i].size();
+    std::atomic<size_t> next{0};
+    std::atomic<bool> bad{false};
+    auto worker = [&] {
+        for (size_t i; (i = next.fetch_add(1)) < pieces.size();) {
+            const char* p = pieces[i].data(); uint64_t left = pieces[i].size(), off = at[i];
+            while (left) {
+                ssize_t w = ::pwrite(fd, p, left, (off_t)off);
+                if (w <= 0) { bad.store(true); return; }
+                p += w; left -= (uint64_t)w; off += (uint64_t)w;
+            }
+        }
+    };
+    const int T = std::max(1, std::min<int>({threads, 16, (int)pieces.size()}));
+    std::vector<std::thread> pool;
+    for (int i = 1; i < T; i++) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+    if (::close(fd) != 0 || bad.load()) throw UserError("failed to write " + path);
 }
 
 extern "C" {
@@ -773,11 +803,7 @@ int ac_compress_dir(const char* assemblies_dir, const char* autocycler_dir, uint
         double t1 = now();
         std::vector<SeqMeta> meta(s.lr.seqs.size());
         for (size_t i = 0; i < meta.size(); i++) meta[i] = SeqMeta{s.lr.seqs[i].id, s.lr.seqs[i].length, s.lr.seqs[i].filename, s.lr.seqs[i].contig_header};
-        {
-            std::ofstream f(fs::path(autocycler_dir) / "input_assemblies.gfa", std::ios::binary);
-            for (const std::string& piece : gfa_chunks(g->g, meta, threads)) f.write(piece.data(), (std::streamsize)piece.size());
-            if (!f) throw UserError("failed to write input_assemblies.gfa");
-        }
+        write_pieces((fs::path(autocycler_dir) / "input_assemblies.gfa").string(), gfa_chunks(g->g, meta, threads), threads);
         {
             std::string y = metrics_yaml(s.lr, g->g.post.unitigs, g->g.post.total_length);
             std::ofstream f(fs::path(autocycler_dir) / "input_assemblies.yaml", std::ios::binary);

@@ -13,6 +13,26 @@ static inline void put_u64(std::string& s, uint64_t v) {
     while (n) s.push_back(buf[--n]);
 }
 
+// Rust's {:.2} of a depth.  Depths of a compress graph are whole numbers (occurrence counts): those skip snprintf.
+static inline void put_depth(std::string& s, double d) {
+    if (d >= 0 && d < 9e15 && d == (double)(uint64_t)d) { put_u64(s, (uint64_t)d); s += ".00"; return; }
+    char buf[64]; snprintf(buf, sizeof buf, "%.2f", d);
+    s += buf;
+}
+static void s_lines(const FinalGraph& g, uint32_t a, uint32_t b, std::string& out) {      // S lines of unitigs [a, b)
+    for (uint32_t i = a; i < b; i++) {
+        out += "S\t"; put_u64(out, (uint64_t)i + 1); out.push_back('\t'); out.append(g.seq(i), g.seq_len[i]); out += "\tDP:f:";
+        put_depth(out, g.depth[i]); out.push_back('\n');
+    }
+}
+static void l_lines(const FinalGraph& g, uint64_t a, uint64_t b, std::string& out) {      // L lines [a, b)
+    for (uint64_t li = a; li < b; li++) {
+        const Link& l = g.links[li];
+        out += "L\t"; put_u64(out, l.a); out += l.a_fwd ? "\t+\t" : "\t-\t"; put_u64(out, l.b);
+        out += l.b_fwd ? "\t+\t0M\n" : "\t-\t0M\n";
+    }
+}
+
 std::string gfa_string(const FinalGraph& g, const std::vector<SeqMeta>& seqs, int parts) {
     std::string out;
     size_t est = 64;
@@ -21,16 +41,8 @@ std::string gfa_string(const FinalGraph& g, const std::vector<SeqMeta>& seqs, in
     out.reserve(est);
     if (parts & 1) {
     out += "H\tVN:Z:1.0\tKM:i:"; put_u64(out, g.k); out.push_back('\n');
-    for (uint32_t i = 0; i < g.n_unitigs; i++) {
-        out += "S\t"; put_u64(out, (uint64_t)i + 1); out.push_back('\t'); out.append(g.seq(i), g.seq_len[i]); out += "\tDP:f:";
-        char buf[64]; snprintf(buf, sizeof buf, "%.2f", g.depth[i]);   // Rust {:.2}
-        out += buf; out.push_back('\n');
-    }
-    for (uint64_t li = 0; li < g.n_links; li++) {
-        const Link& l = g.links[li];
-        out += "L\t"; put_u64(out, l.a); out += l.a_fwd ? "\t+\t" : "\t-\t"; put_u64(out, l.b);
-        out += l.b_fwd ? "\t+\t0M\n" : "\t-\t0M\n";
-    }
+    s_lines(g, 0, g.n_unitigs, out);
+    l_lines(g, 0, g.n_links, out);
     }
     if (parts & 2)
     for (size_t s = 0; s < seqs.size(); s++) {
@@ -48,8 +60,8 @@ std::string gfa_string(const FinalGraph& g, const std::vector<SeqMeta>& seqs, in
     return out;
 }
 
-// The same text in pieces built by several threads (H/S/L in one piece, the P lines split by path entries): concatenated in
-// order they are exactly gfa_string().  Used by the whole-command driver, which writes the pieces one after the other.
+// The same text in pieces built by several threads — the header, the S lines split by sequence bytes, the L lines, the P lines
+// split by path entries: concatenated in order they are exactly gfa_string().  Used by the whole-command driver.
 std::vector<std::string> gfa_chunks(const FinalGraph& g, const std::vector<SeqMeta>& seqs, int threads) {
     size_t S = seqs.size();
     int T = std::max(1, std::min<int>(threads, 64));
@@ -58,7 +70,17 @@ std::vector<std::string> gfa_chunks(const FinalGraph& g, const std::vector<SeqMe
     for (size_t s = 0; s < S; s++)
         if (g.path_off[s + 1] >= per * cut.size() && s + 1 < S) cut.push_back(s + 1);
     cut.push_back(S);
-    std::vector<std::string> out(cut.size());          // out[0] = H, S, L; out[i] = P lines of sequences [cut[i-1], cut[i])
+    std::vector<uint32_t> ucut{0};       // unitig ranges with about equal S-line bytes (the unitigs come longest first)
+    {
+        uint64_t bytes = 0, all = (uint64_t)g.post.total_length + (uint64_t)g.n_unitigs * 24, per_s = all / (uint64_t)T + 1;
+        for (uint32_t i = 0; i < g.n_unitigs; i++) {
+            bytes += (uint64_t)g.seq_len[i] + 24;
+            if (bytes >= per_s * ucut.size() && i + 1 < g.n_unitigs) ucut.push_back(i + 1);
+        }
+        ucut.push_back(g.n_unitigs);
+    }
+    const size_t n_s = ucut.size() - 1, n_l = g.n_links ? (size_t)std::min<uint64_t>((uint64_t)T, g.n_links / 65536 + 1) : 0, n_p = cut.size() - 1;
+    std::vector<std::string> out(1 + n_s + n_l + n_p);      // header | S pieces | L pieces | P pieces
     auto p_lines = [&](size_t a, size_t b, std::string* dst) {
         FinalGraph view;       // a shallow view restricted to [a, b): same arrays, shifted offsets
         std::vector<SeqMeta> sub(seqs.begin() + (long)a, seqs.begin() + (long)b);
@@ -67,8 +89,23 @@ std::vector<std::string> gfa_chunks(const FinalGraph& g, const std::vector<SeqMe
         *dst = gfa_string(view, sub, 2);
     };
     std::vector<std::thread> pool;
-    for (size_t i = 1; i < cut.size(); i++) pool.emplace_back(p_lines, cut[i - 1], cut[i], &out[i]);
-    out[0] = gfa_string(g, seqs, 1);
+    for (size_t i = 0; i < n_p; i++) pool.emplace_back(p_lines, cut[i], cut[i + 1], &out[1 + n_s + n_l + i]);
+    for (size_t i = 0; i < n_s; i++)
+        pool.emplace_back([&g, &ucut, &out, i] {
+            std::string& d = out[1 + i];
+            uint64_t est = 0;
+            for (uint32_t u = ucut[i]; u < ucut[i + 1]; u++) est += (uint64_t)g.seq_len[u] + 32;
+            d.reserve(est);
+            s_lines(g, ucut[i], ucut[i + 1], d);
+        });
+    for (size_t i = 0; i < n_l; i++)
+        pool.emplace_back([&g, &out, n_s, n_l, i] {
+            const uint64_t a = g.n_links * i / n_l, b = g.n_links * (i + 1) / n_l;
+            std::string& d = out[1 + n_s + i];
+            d.reserve((b - a) * 28);
+            l_lines(g, a, b, d);
+        });
+    out[0] = "H\tVN:Z:1.0\tKM:i:"; put_u64(out[0], g.k); out[0].push_back('\n');
     for (auto& t : pool) t.join();
     return out;
 }

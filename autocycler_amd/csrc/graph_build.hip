@@ -1582,7 +1582,7 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
     job->done = std::vector<std::atomic<u32>>(n_chunks); job->slot_state = std::vector<std::atomic<u32>>(n_chunks);
     job->issued = std::vector<std::atomic<u32>>(n_chunks);
     for (u64 c = 0; c < n_chunks; c++) { job->done[c].store(0); job->slot_state[c].store(0); job->issued[c].store(0); }
-    job->landed.resize(n_chunks);
+    job->landed.assign(n_chunks, nullptr);
     for (auto& e : job->landed) AC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const int T = (int)std::max<u64>(1, std::min<u64>({(n + SUB - 1) / SUB, upload_threads(), (u64)std::max(1u, std::thread::hardware_concurrency())}));
     for (int i = 0; i < T; i++) job->pool.emplace_back([job] { job->run(); });
@@ -1672,7 +1672,7 @@ void GraphBuilder::Impl::finish_upload() {
         if (hipEventRecord(st.done(), j->up) != hipSuccess) fail = "hipEventRecord failed";
         st.timed = true;
     } else { (void)hipStreamSynchronize(j->up); (void)hipStreamSynchronize(j->pk); }
-    for (auto& e : j->landed) (void)hipEventDestroy(e);      // (a destroyed event that a stream still waits for stays valid until then)
+    for (auto& e : j->landed) if (e) (void)hipEventDestroy(e);      // (a destroyed event that a stream still waits for stays valid until then)
     delete j;
     if (!fail.empty()) throw DeviceError(fail);
 }

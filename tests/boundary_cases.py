@@ -66,6 +66,23 @@ def compress_dir_matches_the_oracle(lib, tmp_path, k, device=0):
     return out_o
 
 
+def compress_dir_many_pieces(lib, tmp_path, k=31, device=0, threads=48):
+    """The whole command on a synthetic directory whose graph has hundreds of unitigs and links, written with many threads: the
+    GFA is formatted in pieces (header, S lines by sequence bytes, L lines, P lines by path entries: gfa_chunks) that land in the
+    file through parallel pwrite — byte for byte the oracle's file."""
+    from autocycler_amd import synth
+    src = tmp_path / "asm_many"
+    synth.write_fasta_dir(synth.make_assemblies(5, genome=30_000, plasmid=2_000, sub=2e-3, indel=2e-4, seed=4242), str(src))
+    out_o, out_p = tmp_path / "o_many", tmp_path / "p_many"
+    O.compress_dir(src, out_o, k=k)
+    rc = lib.ac_compress_dir(str(src).encode(), str(out_p).encode(), C.c_uint32(k), C.c_uint32(25), C.c_int(threads), C.c_int(device), None, None)
+    assert rc == 0, lib.ac_last_error()
+    want = (out_o / "input_assemblies.gfa").read_bytes()
+    assert want.count(b"\nS\t") > 200 and want.count(b"\nL\t") > 200      # (enough lines for several S and L pieces)
+    assert (out_p / "input_assemblies.gfa").read_bytes() == want
+    assert (out_p / "input_assemblies.yaml").read_text() == (out_o / "input_assemblies.yaml").read_text()
+
+
 def cli_matches_the_oracle(tmp_path, k):
     """The `autocycler-compress` binary (flag surface of main.rs:140-160) on the same fixture, as a fresh process."""
     cli = ROOT / "autocycler_amd" / "autocycler-compress"

@@ -30,6 +30,10 @@ def test_compress_dir_five_file_fixture(emu, tmp_path, k):
     B.compress_dir_matches_the_oracle(_capi.load_library(emu), tmp_path, k)
 
 
+def test_compress_dir_written_in_many_pieces(emu, tmp_path):
+    B.compress_dir_many_pieces(_capi.load_library(emu), tmp_path)
+
+
 def test_two_device_ordinals(emu):
     B.two_device_ordinals(emu)
 

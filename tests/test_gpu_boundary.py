@@ -34,6 +34,10 @@ def test_compress_dir_five_file_fixture(lib, tmp_path, k):
     B.compress_dir_matches_the_oracle(lib, tmp_path, k)
 
 
+def test_compress_dir_written_in_many_pieces(lib, tmp_path):
+    B.compress_dir_many_pieces(lib, tmp_path)
+
+
 @pytest.mark.parametrize("k", [13, 51])
 def test_cli_five_file_fixture(lib, tmp_path, k):
     B.cli_matches_the_oracle(tmp_path, k)

@@ -51,7 +51,7 @@ class Timings(C.Structure):
 
 
 EXPORTS = ["ac_compress_build", "ac_compress_build_device", "ac_pack_text", "ac_text_size", "ac_layout_text", "ac_kmer_count",
-           "ac_stats_pre", "ac_stats_post", "ac_unitig_count", "ac_unitig", "ac_unitig_positions", "ac_links",
+           "ac_stats_pre", "ac_stats_post", "ac_unitig_count", "ac_unitig", "ac_unitigs_bulk", "ac_paths_bulk", "ac_unitig_positions", "ac_links",
            "ac_path", "ac_timings_get", "ac_free", "ac_gfa_string", "ac_string_free", "ac_last_error",
            "ac_device_count", "ac_max_kmer", "ac_version", "ac_set_stage_timing", "ac_random_access_ceilings", "ac_release_memory", "ac_end_repair_device", "ac_pairwise_distances", "ac_graph_from_gfa", "ac_graph_kmer_size", "ac_graph_seq_info", "ac_decompress_seq", "ac_decompress",
            "ac_shard_begin", "ac_shard_fragment_sizes", "ac_shard_fragments_export", "ac_shard_build_union",
@@ -183,6 +183,28 @@ class Graph:
         p, n = C.POINTER(C.c_int32)(), C.c_uint32()
         _check(self._lib, self._lib.ac_path(self._h, seq_index, C.byref(p), C.byref(n)))
         return p[:n.value]
+
+    def bulk(self):
+        """Zero-copy numpy views (valid while this handle lives): seq_bytes, seq_begin, seq_len, depth, links (structured: a, a_fwd, b,
+        b_fwd), path_entries, path_off."""
+        import numpy as np
+        U = self.unitig_count
+        sb, bg, ln, dp = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(self._lib, self._lib.ac_unitigs_bulk(self._h, C.byref(sb), C.byref(bg), C.byref(ln), C.byref(dp)))
+        view = lambda ptr, n, ct: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n,)) if n else np.zeros(0, dtype=ct)
+        seq_begin = view(bg, U, C.c_uint64); seq_len = view(ln, U, C.c_uint32); depth = view(dp, U, C.c_double)
+        total = int((seq_begin + seq_len).max()) if U else 0
+        seq_bytes = view(sb, total, C.c_uint8)
+        lp, n = C.POINTER(Link)(), C.c_uint64()
+        _check(self._lib, self._lib.ac_links(self._h, C.byref(lp), C.byref(n)))
+        ldt = np.dtype([("a", "<u4"), ("a_fwd", "u1"), ("_p0", "u1", (3,)), ("b", "<u4"), ("b_fwd", "u1"), ("_p1", "u1", (3,))])
+        assert ldt.itemsize == C.sizeof(Link)
+        links = np.frombuffer((C.c_uint8 * (n.value * C.sizeof(Link))).from_address(C.addressof(lp.contents)), dtype=ldt) if n.value else np.zeros(0, dtype=ldt)
+        pe, po, ne = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        _check(self._lib, self._lib.ac_paths_bulk(self._h, C.byref(pe), C.byref(po), C.byref(ne)))
+        S = self._lib.ac_graph_seq_count(self._h)
+        return dict(seq_bytes=seq_bytes, seq_begin=seq_begin, seq_len=seq_len, depth=depth, links=links,
+                    path_entries=view(pe, ne.value, C.c_int32), path_off=view(po, S + 1, C.c_uint64))
 
     def path_counts(self):
         n = self._lib.ac_graph_seq_count(self._h)

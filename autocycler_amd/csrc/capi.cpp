@@ -103,11 +103,12 @@ static void validate_layout(uint32_t k, uint64_t n_text, const uint64_t* off, co
     for (uint32_t i = 0; i < n_seqs; i++) {
         if (len[i] < k) throw DeviceError("sequence " + std::to_string(i + 1) + " is shorter than k");
         const uint64_t plen = (uint64_t)len[i] + k - 1;
-        if (off[i] < prev_end + 1) throw DeviceError("sequence table: offset of sequence " + std::to_string(i + 1) + " overlaps the previous sequence or its separator");
+        if (off[i] != prev_end + 1) throw DeviceError("sequence table: sequence " + std::to_string(i + 1) + " does not start right behind the separator of the previous one");
         if (off[i] + plen + 1 > n_text) throw DeviceError("sequence table: sequence " + std::to_string(i + 1) + " runs past the end of the text");
         if (d1[i] > k - 1 || d2[i] > k - 1 || (uint32_t)d1[i] + d2[i] > k - 1) throw DeviceError("sequence table: more padding dots than k - 1 on sequence " + std::to_string(i + 1));
         prev_end = off[i] + plen;
     }
+    if (n_seqs && prev_end + 1 != n_text) throw DeviceError("sequence table: the text does not end with the separator of the last sequence");
 }
 
 // compress.rs:42-44 behind the ABI: one device pipeline from the packed text to the final UnitigGraph.
@@ -488,13 +489,17 @@ int ac_end_repair_device(uint32_t k, void* d_text, uint64_t n_text, const uint64
                          uint16_t* seq_d1, uint16_t* seq_d2, uint32_t n_seqs, int device, double* seconds, uint64_t* n_matches) {
     return guarded([&] {
         if (!d_text || n_seqs == 0) throw DeviceError("no sequences found in input assemblies");
-        validate_layout(k, n_text, seq_off, seq_len, seq_d1, seq_d2, n_seqs);
+        if (!seq_d1 || !seq_d2) throw DeviceError("null sequence table");
+        {   // seq_d1 / seq_d2 are outputs here (the repair counts the surviving dots itself): only the layout is checked
+            std::vector<uint16_t> zero(n_seqs, 0);
+            validate_layout(k, n_text, seq_off, seq_len, zero.data(), zero.data(), n_seqs);
+        }
         std::lock_guard<std::mutex> lock(g_build_mutex);
         if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
         select_device(device);
         std::vector<uint64_t> off(seq_off, seq_off + n_seqs);
         std::vector<uint32_t> len(seq_len, seq_len + n_seqs);
-        std::vector<uint16_t> d1(seq_d1, seq_d1 + n_seqs), d2(seq_d2, seq_d2 + n_seqs);
+        std::vector<uint16_t> d1(n_seqs, 0), d2(n_seqs, 0);
         RepairTimings tm;
         end_repair_device(k, (uint8_t*)d_text, n_text, off, len, &d1, &d2, &tm);
         for (uint32_t i = 0; i < n_seqs; i++) { seq_d1[i] = d1[i]; seq_d2[i] = d2[i]; }
@@ -652,6 +657,21 @@ int ac_path(const ac_graph* g, uint32_t seq_index, const int32_t** signed_unitig
     uint64_t b = g->g.path_off[seq_index], e = g->g.path_off[seq_index + 1];
     *signed_unitigs = g->g.path + b;
     *n = (uint32_t)(e - b);
+    return 0;
+}
+int ac_unitigs_bulk(const ac_graph* g, const uint8_t** seq_bytes, const uint64_t** seq_begin, const uint32_t** seq_len, const double** depth) {
+    if (!g->host_arrays) { g_err = "this rank kept no host arrays (sharded build, not the writing rank)"; return 1; }
+    if (seq_bytes) *seq_bytes = (const uint8_t*)g->g.seq_block.p;
+    if (seq_begin) *seq_begin = g->g.seq_begin;
+    if (seq_len) *seq_len = g->g.seq_len;
+    if (depth) *depth = g->g.depth;
+    return 0;
+}
+int ac_paths_bulk(const ac_graph* g, const int32_t** path_entries, const uint64_t** path_off, uint64_t* n_entries) {
+    if (!g->host_paths) { g_err = "this rank kept no paths on the host (sharded build)"; return 1; }
+    if (path_entries) *path_entries = g->g.path;
+    if (path_off) *path_off = g->g.path_off.data();
+    if (n_entries) *n_entries = g->g.n_path;
     return 0;
 }
 int ac_timings_get(const ac_graph* g, ac_timings* o) {

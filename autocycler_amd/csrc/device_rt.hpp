@@ -214,8 +214,9 @@ class PinnedPool {
 #ifndef AC_EMU
 static const int FILL_MAX = 16;
 struct FillArgs { void* p[FILL_MAX]; u64 bytes[FILL_MAX]; u64 tile0[FILL_MAX + 1]; u32 word[FILL_MAX]; int n; };
-template <int UNUSED> __global__ void __launch_bounds__(256) fill_many_kernel(FillArgs a) {      // a tile = 16 KB of one region
-    const u64 tile = blockIdx.x;
+static const u64 FILL_MAX_TILES = (u64)1 << 23;
+template <int UNUSED> __global__ void __launch_bounds__(256) fill_many_kernel(FillArgs a, u64 tile0) {      // a tile = 16 KB of one region
+    const u64 tile = tile0 + blockIdx.x;
     int r = 0;
     while (r + 1 < a.n && a.tile0[r + 1] <= tile) r++;
     const u64 base = (tile - a.tile0[r]) * 16384;
@@ -246,9 +247,10 @@ class FillQueue {
         a_.tile0[n_] = tiles;
         a_.n = n_;
         n_ = 0;
-        if (tiles > 0x7FFFFFFFULL) throw DeviceError("grid too large");
-        hipLaunchKernelGGL(fill_many_kernel<0>, dim3((unsigned)tiles), dim3(256), 0, 0, a_);
-        AC_HIP_CHECK(hipGetLastError());
+        for (u64 t0 = 0; t0 < tiles; t0 += FILL_MAX_TILES) {      // (2^32 threads per launch at most: 64 GB of fills)
+            hipLaunchKernelGGL(fill_many_kernel<0>, dim3((unsigned)std::min(FILL_MAX_TILES, tiles - t0)), dim3(256), 0, 0, a_, t0);
+            AC_HIP_CHECK(hipGetLastError());
+        }
     }
     void drop() { n_ = 0; }      // the arena was reset: whatever was queued points at dead buffers
   private:
@@ -561,10 +563,13 @@ class SideStream {
 // has >> 256 workgroups at the benchmark sizes, so the 256 CUs / 8 XCDs fill from the grid alone.
 #ifndef AC_EMU
 template <class F>
-__global__ void __launch_bounds__(256) functor_kernel(u64 n, F f) {
-    u64 tid = (u64)blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(256) functor_kernel(u64 n, F f, u64 base = 0) {
+    u64 tid = base + (u64)blockIdx.x * 256 + threadIdx.x;
     if (tid < n) f(tid);
 }
+// A launch may not hold more than 2^32 - 1 threads (hipErrorInvalidConfiguration beyond that): a text of more than 4 G positions
+// (BASELINE configs[4]: 5 G bp) takes several launches of at most this many 256-thread workgroups.
+static const u64 MAX_LAUNCH_BLOCKS = (u64)1 << 23;
 #endif
 #ifdef AC_EMU
 inline int emu_order() { const char* e = getenv("AC_EMU_ORDER"); return e ? atoi(e) : 0; }
@@ -584,11 +589,12 @@ template <class F> void launch(u64 n, const F& f, stream_t s = 0) {
         for (u64 i = 0; i < n; i++) f(perm[i]);
     } else { for (u64 i = 0; i < n; i++) f(i); }
 #else
-    u64 blocks = (n + 255) / 256;
-    if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+    const u64 blocks = (n + 255) / 256;
     if (s == 0) flush_fills();
-    hipLaunchKernelGGL(functor_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, s, n, f);
-    AC_HIP_CHECK(hipGetLastError());
+    for (u64 b0 = 0; b0 < blocks; b0 += MAX_LAUNCH_BLOCKS) {
+        hipLaunchKernelGGL(functor_kernel<F>, dim3((unsigned)std::min(MAX_LAUNCH_BLOCKS, blocks - b0)), dim3(256), 0, s, n, f, b0 * 256);
+        AC_HIP_CHECK(hipGetLastError());
+    }
 #endif
 }
 
@@ -596,8 +602,8 @@ template <class F> void launch(u64 n, const F& f, stream_t s = 0) {
 // may use the wavefront-wide helpers below, which need all 64 lanes to arrive together.
 #ifndef AC_EMU
 template <class F>
-__global__ void __launch_bounds__(256) functor_kernel_full(u64 n, F f) {
-    u64 tid = (u64)blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(256) functor_kernel_full(u64 n, F f, u64 base = 0) {
+    u64 tid = base + (u64)blockIdx.x * 256 + threadIdx.x;
     f(tid, tid < n);
 }
 #endif
@@ -608,11 +614,12 @@ template <class F> void launch_full(u64 n, const F& f, stream_t s = 0) {
     if (order == 1) { for (u64 i = n; i-- > 0;) f(i, true); }
     else { for (u64 i = 0; i < n; i++) f(i, true); }
 #else
-    u64 blocks = (n + 255) / 256;
-    if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+    const u64 blocks = (n + 255) / 256;
     if (s == 0) flush_fills();
-    hipLaunchKernelGGL(functor_kernel_full<F>, dim3((unsigned)blocks), dim3(256), 0, s, n, f);
-    AC_HIP_CHECK(hipGetLastError());
+    for (u64 b0 = 0; b0 < blocks; b0 += MAX_LAUNCH_BLOCKS) {
+        hipLaunchKernelGGL(functor_kernel_full<F>, dim3((unsigned)std::min(MAX_LAUNCH_BLOCKS, blocks - b0)), dim3(256), 0, s, n, f, b0 * 256);
+        AC_HIP_CHECK(hipGetLastError());
+    }
 #endif
 }
 // Bump allocation from a device counter with ONE atomic per wavefront (a counter hit by every lane serialises in L2).

@@ -431,6 +431,10 @@ struct PackedText {
     DBuf<u64> seq_off; DBuf<u32> seq_len; DBuf<u16> seq_d1, seq_d2; DBuf<u8> seq_flags;
     bool has_flags = false;
     DBuf<u64> bits, mask;
+    // alphabet check of K1 (pack_check, sequence.rs:39-41): [0] = smallest (sequence index + 1) holding an illegal byte, [1] = number of
+    // non-base bytes - 1 (both start as all-ones); expected_nonbase = padding dots + separators the sequence table promises
+    DBuf<u32> pack_bad; bool check_alphabet = false; int k = 0; u64 expected_nonbase = 0;
+    PackCheck chk() const { return PackCheck{seq_off.ptr(), seq_len.ptr(), seq_d1.ptr(), seq_d2.ptr(), n_seqs, k, check_alphabet ? const_cast<u32*>(pack_bad.ptr()) : nullptr}; }
     std::vector<u64> h_off; std::vector<u32> h_len;
     void set_table(const std::vector<uint64_t>& off, const std::vector<uint32_t>& len, const std::vector<uint16_t>& d1,
                    const std::vector<uint16_t>& d2, const std::vector<uint8_t>* flags = nullptr) {
@@ -443,8 +447,8 @@ struct PackedText {
         copy_h2d(seq_d2.ptr(), d2.data(), (size_t)n_seqs * 2);
         has_flags = flags != nullptr;
         if (flags) { seq_flags.alloc(n_seqs); copy_h2d(seq_flags.ptr(), flags->data(), n_seqs); }
-        n_bases = 0; any_dots = 0;
-        for (u32 i = 0; i < n_seqs; i++) { n_bases += len[i]; if (d1[i] || d2[i]) any_dots = 1; }
+        n_bases = 0; any_dots = 0; expected_nonbase = (u64)n_seqs + 1;
+        for (u32 i = 0; i < n_seqs; i++) { n_bases += len[i]; if (d1[i] || d2[i]) any_dots = 1; expected_nonbase += (u64)d1[i] + d2[i]; }
         stream_sync();
     }
     TextCtx ctx(int k) const { return TextCtx{bits.ptr(), mask.ptr(), n_text, k, seq_off.ptr(), seq_len.ptr(), seq_d1.ptr(), seq_d2.ptr(), n_seqs}; }
@@ -454,11 +458,22 @@ struct PackedText {
         bits.alloc(n_bits_words); mask.alloc(n_mask_words);
         bits.fill_bytes(0, s);
         mask.fill_bytes(0xFF, s);
+        if (check_alphabet) { pack_bad.alloc(2); pack_bad.fill_bytes(0xFF, s); }
+    }
+    // What pack_check found (read back with the build's last read-back): throws the reference's message for a text that holds
+    // anything but A, C, G, T between its padding dots (sequence.rs:39-41).
+    void verify_alphabet(const u32* bad) const {
+        if (!check_alphabet) return;
+        if (bad[0] != 0xFFFFFFFFu) throw DeviceError("input sequence " + std::to_string(bad[0]) + " contains non-ACGT characters");
+        const u64 found = (u64)(u32)(bad[1] + 1u);
+        if (found != (expected_nonbase & 0xFFFFFFFFULL))
+            throw DeviceError("the text does not match its sequence table: " + std::to_string(expected_nonbase) + " padding dots and separators expected, " +
+                              std::to_string(found) + " non-ACGT characters found");
     }
     void pack() {   // K1
         if (packed) return;
         pack_alloc();
-        launch((n_text + 31) / 32, PackFunctor{d_text, n_text, bits.ptr(), (u32*)mask.ptr(), 0});
+        launch((n_text + 31) / 32, PackFunctor{d_text, n_text, bits.ptr(), (u32*)mask.ptr(), 0, chk()});
         packed = true;
     }
 };
@@ -522,7 +537,7 @@ struct GraphBuilder::Impl {
         uint32_t k = 0; u64 n = 0, CH = 0, SUB = 0, n_chunks = 0, slot_bytes = 0; int NSLOT = 0, dev = 0;
         hipStream_t up = nullptr, pk = nullptr;
         u64* d_bits = nullptr; u32* d_mask = nullptr;
-        std::atomic<u64> next{0};
+        std::atomic<u64> next{0}, nonbase{0}; u64 expected_nonbase = 0;      // alphabet check: non-base bytes the packers met / the sequence table promises
         std::vector<std::atomic<u32>> done, slot_state, issued;      // slot_state: 0 untouched, 1 someone is waiting for the slot, 2 free
         std::vector<hipEvent_t> landed;                               // per chunk: both of its copies are on the device
         std::mutex hip_mu; std::string fail; std::atomic<bool> stop{false};
@@ -551,10 +566,10 @@ struct GraphBuilder::Impl {
         const u64 cap_est = next_pow2(std::max<u64>(1024, pt.n_bases / std::max<u32>(hint, 1) * 3 + 4096));
         if (pack_overlap() && cap_est <= (1ULL << 25) && H + (1u << 22) < pt.n_text) {
             pt.pack_alloc();
-            launch(H / 32, PackFunctor{pt.d_text, pt.n_text, pt.bits.ptr(), (u32*)pt.mask.ptr(), 0});
+            launch(H / 32, PackFunctor{pt.d_text, pt.n_text, pt.bits.ptr(), (u32*)pt.mask.ptr(), 0, pt.chk()});
             SideStream& side = SideStream::get();
             side.after_main();      // (the fills of bits / mask went out with the head's launch)
-            launch((pt.n_text + 31) / 32 - H / 32, PackFunctor{pt.d_text, pt.n_text, pt.bits.ptr(), (u32*)pt.mask.ptr(), H / 32}, side.stream());
+            launch((pt.n_text + 31) / 32 - H / 32, PackFunctor{pt.d_text, pt.n_text, pt.bits.ptr(), (u32*)pt.mask.ptr(), H / 32, pt.chk()}, side.stream());
             upload_done = side.mark(); upload_avail = H; upload_pending = true;
             pt.packed = true;
             return;
@@ -655,7 +670,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
                 launch(n_waves, InsertWaveEmuFunctor<W>{t, tb, pb, pe, chunk, istats.ptr(), ierr});
 #else
                 u64 blocks = (n_waves + 3) / 4;
-                if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+                if (blocks > 0xFFFFFFULL) throw DeviceError("grid too large");
                 flush_fills();
                 if (insert_profile()) {      // measurement only: per-wavefront cycle split of this launch on stderr
                     DBuf<u64> prof(16);
@@ -751,7 +766,15 @@ template <int W> void GraphBuilder::Impl::fragments() {
     frag_bytes = read_scalar(boff.ptr() + n_frags);
     frag_text.alloc(frag_bytes);
     launch((frag_bytes + 63) / 64, FragCopyFunctor{loc.d_text, fpos.ptr(), boff.ptr(), n_frags, frag_bytes, frag_text.ptr()});
-    if (read_scalar(counters.ptr() + 6)) throw DeviceError("internal error: novel run outside a sequence");
+    {
+        u32 frag_err = 0, pack_bad[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+        ReadBatch rb;
+        rb.add(&frag_err, counters.ptr() + 6, 4);
+        if (loc.check_alphabet && loc.pack_bad.size()) rb.add(pack_bad, loc.pack_bad.ptr(), 8);
+        rb.run();
+        if (loc.pack_bad.size()) loc.verify_alphabet(pack_bad);
+        if (frag_err) throw DeviceError("internal error: novel run outside a sequence");
+    }
     tm->n_fragments = n_frags; tm->fragment_bytes = frag_bytes;
     lap(&tm->fragments);
 }
@@ -798,7 +821,7 @@ inline void GraphBuilder::Impl::novel_list(u64 known_n) {
     if (fill_novel_plain()) launch(n_bm_words, FillNovelFunctor{bm.ptr(), wprefix.ptr(), npos.ptr()});
     else {
         const u64 blocks = (n_bm_words + 255) / 256;
-        if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+        if (blocks > 0xFFFFFFULL) throw DeviceError("grid too large");
         flush_fills();
         hipLaunchKernelGGL(fill_novel_wave_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, 0, bm.ptr(), wprefix.ptr(), npos.ptr(), n_bm_words);
         AC_HIP_CHECK(hipGetLastError());
@@ -882,7 +905,7 @@ template <int W> void GraphBuilder::Impl::unitigs() {
         launch(n_waves, MinPreWaveEmuFunctor<W>{a});
 #else
         const u64 blocks = (N + 255) / 256;
-        if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+        if (blocks > 0xFFFFFFULL) throw DeviceError("grid too large");
         flush_fills();
         hipLaunchKernelGGL(minpre_wave_kernel<W>, dim3((unsigned)blocks), dim3(256), 0, 0, a);
         AC_HIP_CHECK(hipGetLastError());
@@ -897,7 +920,7 @@ template <int W> void GraphBuilder::Impl::unitigs() {
             launch(n_waves, MinWaveEmuFunctor<W>{a});
 #else
             const u64 blocks = (N + 255) / 256;
-            if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+            if (blocks > 0xFFFFFFULL) throw DeviceError("grid too large");
             flush_fills();
             hipLaunchKernelGGL(minkey_wave_kernel<W>, dim3((unsigned)blocks), dim3(256), 0, 0, a);
             AC_HIP_CHECK(hipGetLastError());
@@ -1035,7 +1058,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         launch(U, BlockMaxFunctor{off, U, n_blocks, bmax.ptr()});
         inclusive_max_scan_u32(bmax.ptr(), first.ptr(), n_blocks);
         const u64 grid = (n_blocks + 255) / 256;
-        if (grid > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+        if (grid > 0xFFFFFFULL) throw DeviceError("grid too large");
         SeqSrc q{g.bits.ptr(), ustartpos.ptr(), ulen.ptr(), uorient.ptr(), (int)(k / 2)};
         ExpState e0{};
         flush_fills();
@@ -1153,7 +1176,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                         }
                         const u32 G = expand_group();
                         const u64 blocks = (cnt * G + 255) / 256;
-                        if (blocks > 0x7FFFFFFFULL) throw DeviceError("grid too large");
+                        if (blocks > 0xFFFFFFULL) throw DeviceError("grid too large");
                         flush_fills();
                         if (G == 8) hipLaunchKernelGGL((expand_wave_kernel<W, 8>), dim3((unsigned)blocks), dim3(256), 0, 0, e, clist.ptr(), (u64)hb[lv], cnt, (u32)pool.size(), counters.ptr() + 7);
                         else if (G == 16) hipLaunchKernelGGL((expand_wave_kernel<W, 16>), dim3((unsigned)blocks), dim3(256), 0, 0, e, clist.ptr(), (u64)hb[lv], cnt, (u32)pool.size(), counters.ptr() + 7);
@@ -1247,14 +1270,17 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     std::vector<u64> h_sums(n_seqs);
     out->path_off.resize((size_t)n_seqs + 1);
     std::vector<u32> errs(8);
+    u32 pack_bad[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
     {
         ReadBatch rb;
         rb.add(h_sums.data(), sums.ptr(), (size_t)n_seqs * 8);
         rb.add(out->path_off.data(), path_off.ptr(), ((size_t)n_seqs + 1) * 8);
         rb.add(errs.data(), counters.ptr(), 8 * 4);
+        if (loc.check_alphabet && loc.pack_bad.size()) rb.add(pack_bad, loc.pack_bad.ptr(), 8);
         rb.run();                                   // synchronises stream 0 (once)
     }
     side.sync();                                    // ... and the copies: everything above has landed
+    if (loc.pack_bad.size()) loc.verify_alphabet(pack_bad);      // before any internal check: a text with foreign bytes explains them all
     if (errs[7]) throw DeviceError("internal error: expand_repeats pool overflow");
     if (errs[3] || errs[4])
         throw DeviceError("internal error: inconsistent unitig ends (codes " + std::to_string(errs[3]) + "/" + std::to_string(errs[4]) + ")");
@@ -1315,7 +1341,7 @@ void device_warmup(int device) {
     AC_HIP_CHECK(hipSetDevice(device));
     void* p = nullptr;
     AC_HIP_CHECK(hipMalloc(&p, 4096));
-    hipLaunchKernelGGL(functor_kernel<PackFunctor>, dim3(1), dim3(256), 0, 0, (u64)1, PackFunctor{(const u8*)p, 32, (u64*)((u8*)p + 1024), (u32*)((u8*)p + 2048), 0});
+    hipLaunchKernelGGL(functor_kernel<PackFunctor>, dim3(1), dim3(256), 0, 0, (u64)1, PackFunctor{(const u8*)p, 32, (u64*)((u8*)p + 1024), (u32*)((u8*)p + 2048), 0, PackCheck{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr}});
     (void)hipDeviceSynchronize();
     (void)hipFree(p);
 #else
@@ -1329,6 +1355,8 @@ GraphBuilder::GraphBuilder(uint32_t k) : impl_(new Impl) {
     // dead.  Nothing a caller can reach lives in it: every array of an ac_graph is a pinned block of its own (PinnedPool) or host heap.
     Arena::device().reset();
     impl_->k = k;
+    impl_->loc.k = impl_->uni.k = (int)k;
+    impl_->loc.check_alphabet = true;      // the caller's text; the union text of a sharded build is cut out of texts that were checked
     if (k < 1 || (k % 2) == 0) throw DeviceError("k must be odd");
     if ((int)k > max_supported_k())
         throw DeviceError("k-mer sizes above " + std::to_string(max_supported_k()) + " are not supported by this build of the HIP backend");
@@ -1513,8 +1541,10 @@ void pack_text_host(const uint8_t* text, uint64_t n_text, uint64_t* bits, uint32
 // Packs the groups [g0, g1) of the text layout of `seqs` (group g = text bytes 32 g .. 32 g + 31; bytes beyond the text read as
 // separators).  Groups that lie inside one padded sequence — all but two or three per sequence — are packed straight from the
 // caller's buffer; only the groups that touch a separator are assembled in a 32-byte scratch first.
-static void pack_text_groups(const std::vector<SeqView>& seqs, const std::vector<uint64_t>& off, uint32_t k, u64 n_text, u64 g0, u64 g1,
-                             u64* bits, u32* mask) {
+// Returns the number of non-base bytes it met (mask bits set, the separators beyond the text's end included): the host entry's
+// alphabet check (sequence.rs:39-41) compares their total with what the sequence table promises.
+static u64 pack_text_groups(const std::vector<SeqView>& seqs, const std::vector<uint64_t>& off, uint32_t k, u64 n_text, u64 g0, u64 g1,
+                            u64* bits, u32* mask) {
     const u64 b = g0 * 32;
     // first sequence whose span [off, off + plen] (the '$' after it included) ends after b
     size_t lo = 0, hi = seqs.size();
@@ -1541,6 +1571,23 @@ static void pack_text_groups(const std::vector<SeqView>& seqs, const std::vector
             slow(g++);
         }
     }
+    u64 nonbase = 0;
+    for (u64 q = 0; q < g1 - g0; q++) nonbase += (u64)__builtin_popcount(mask[q]);
+    return nonbase;
+}
+// The host entry's alphabet check failed: name the first sequence that holds anything but A, C, G, T between its padding dots.
+[[maybe_unused]] static void throw_bad_alphabet(const std::vector<SeqView>& seqs, uint32_t k, u64 expected, u64 found) {
+    for (size_t i = 0; i < seqs.size(); i++) {
+        const u64 plen = (u64)seqs[i].length + k - 1;
+        u64 a = 0, b = 0;
+        while (a < plen && seqs[i].fwd[a] == '.') a++;
+        while (b < plen - a && seqs[i].fwd[plen - 1 - b] == '.') b++;
+        for (u64 j = a; j < plen - b; j++) {
+            const u8 c = seqs[i].fwd[j];
+            if (c != 'A' && c != 'C' && c != 'G' && c != 'T') throw DeviceError("input sequence " + std::to_string(i + 1) + " contains non-ACGT characters");
+        }
+    }
+    throw DeviceError("internal error: the packed text holds " + std::to_string(found) + " non-base positions, " + std::to_string(expected) + " expected");
 }
 
 // Final (end-repaired) sequences: the text never reaches the device as bytes.  Host threads lay a piece of the text out in a
@@ -1561,15 +1608,19 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
     [[maybe_unused]] auto slot_mask = [&](int sl) { return (u32*)(st.slot(0) + (u64)sl * SLOT_BYTES + CH / 4); };
 #ifdef AC_EMU
     loc.pack_alloc();
+    u64 nonbase = 0;
     for (u64 b = 0; b < n; b += SUB) {
         const u64 e = std::min(n, b + SUB);
-        pack_text_groups(seqs, off, k, n, b / 32, (e + 31) / 32, loc.bits.ptr() + b / 32, (u32*)loc.mask.ptr() + b / 32);
+        nonbase += pack_text_groups(seqs, off, k, n, b / 32, (e + 31) / 32, loc.bits.ptr() + b / 32, (u32*)loc.mask.ptr() + b / 32);
     }
+    const u64 expected = loc.expected_nonbase + ((n + 31) / 32 * 32 - n);
+    if (nonbase != expected) throw_bad_alphabet(seqs, k, expected, nonbase);
 #else
     Impl::UploadJob* job = new Impl::UploadJob();
     impl_->job = job;
     job->seqs = &seqs; job->off = off; job->k = k; job->n = n; job->CH = CH; job->SUB = SUB; job->NSLOT = NSLOT; job->n_chunks = n_chunks;
     job->slot_bytes = SLOT_BYTES;
+    job->expected_nonbase = loc.expected_nonbase + ((n + 31) / 32 * 32 - n);
     AC_HIP_CHECK(hipGetDevice(&job->dev));
     job->up = st.stream(); job->pk = st.pack_stream();
     flush_fills();
@@ -1619,7 +1670,8 @@ void GraphBuilder::Impl::UploadJob::run() {
                 if (stop.load()) break;
             }
             const u64 b = c * CH + sub * SUB, e = std::min(c * CH + clen, b + SUB);
-            pack_text_groups(*seqs, off, k, n, b / 32, (e + 31) / 32, slot_bits(sl) + sub * SUB / 32, slot_mask(sl) + sub * SUB / 32);
+            nonbase.fetch_add(pack_text_groups(*seqs, off, k, n, b / 32, (e + 31) / 32, slot_bits(sl) + sub * SUB / 32, slot_mask(sl) + sub * SUB / 32),
+                              std::memory_order_relaxed);
             const u32 n_sub = (u32)((clen + SUB - 1) / SUB);
             if (done[c].fetch_add(1, std::memory_order_acq_rel) + 1 == n_sub) {      // the chunk is complete: send it
                 const u64 g0 = c * CH / 32, ng = (clen + 31) / 32;
@@ -1672,6 +1724,9 @@ void GraphBuilder::Impl::finish_upload() {
         if (hipEventRecord(st.done(), j->up) != hipSuccess) fail = "hipEventRecord failed";
         st.timed = true;
     } else { (void)hipStreamSynchronize(j->up); (void)hipStreamSynchronize(j->pk); }
+    if (fail.empty() && !j->stop.load() && j->nonbase.load() != j->expected_nonbase) {      // sequence.rs:39-41 (every chunk was packed: nobody stopped)
+        try { throw_bad_alphabet(*j->seqs, j->k, j->expected_nonbase, j->nonbase.load()); } catch (const std::exception& ex) { fail = ex.what(); }
+    }
     for (auto& e : j->landed) if (e) (void)hipEventDestroy(e);      // (a destroyed event that a stream still waits for stays valid until then)
     delete j;
     if (!fail.empty()) throw DeviceError(fail);
@@ -1706,6 +1761,7 @@ void GraphBuilder::set_sequences_host(const std::vector<SeqView>& seqs, bool pac
     if (pack_now && host_pack()) {      // the sequences are final: pack on the host, upload 0.375 B per base
         Arena::device().reserve(arena_estimate(n, false));
         loc.d_text = nullptr;
+        loc.check_alphabet = false;      // K1 runs on the host here: its packers count the non-base bytes (finish_upload)
         loc.set_table(off, len, d1, d2);
         upload_packed(seqs, off);
         tm_.h2d = now_s() - t0;
@@ -1726,7 +1782,7 @@ void GraphBuilder::set_sequences_host(const std::vector<SeqView>& seqs, bool pac
         const u64 b = c * C, e = std::min(n, b + C);
         fill_text_range(seqs, off, k, b, e, st.slot(0));
         memcpy(d_text + b, st.slot(0), e - b);
-        if (pack_now) launch((e - b + 31) / 32, PackFunctor{d_text, n, loc.bits.ptr(), (u32*)loc.mask.ptr(), b / 32});
+        if (pack_now) launch((e - b + 31) / 32, PackFunctor{d_text, n, loc.bits.ptr(), (u32*)loc.mask.ptr(), b / 32, loc.chk()});
     }
 #else
     int dev = 0;
@@ -1763,7 +1819,7 @@ void GraphBuilder::set_sequences_host(const std::vector<SeqView>& seqs, bool pac
                     AC_HIP_CHECK(hipEventRecord(st.event(sl), up));
                     if (pack_now) {
                         AC_HIP_CHECK(hipStreamWaitEvent(pk, st.event(sl), 0));
-                        launch((e - b + 31) / 32, PackFunctor{d_text, n, loc.bits.ptr(), (u32*)loc.mask.ptr(), b / 32}, pk);
+                        launch((e - b + 31) / 32, PackFunctor{d_text, n, loc.bits.ptr(), (u32*)loc.mask.ptr(), b / 32, loc.chk()}, pk);
                     }
                 }
                 issued[sl].store(c + 1, std::memory_order_release);

@@ -199,6 +199,15 @@ int ac_unitig_positions(ac_graph*, uint32_t idx, int forward, const ac_position*
 int ac_links(const ac_graph*, const ac_link** links, uint64_t* n);   /* get_links_for_gfa order (unitig_graph.rs:333-350) */
 /* get_unitig_path_for_sequence_i32 (unitig_graph.rs:467-472) of the seq_index-th input sequence. */
 int ac_path(const ac_graph*, uint32_t seq_index, const int32_t** signed_unitigs, uint32_t* n);
+/* Bulk views of the finished graph, zero-copy and valid until ac_free(): everything save_gfa (unitig_graph.rs:317-331) reads, in
+ * five arrays instead of one call per unitig / sequence — what a caller that rebuilds its own UnitigGraph, or checks a graph of
+ * 10^8 unitigs, wants.  seq_bytes + seq_begin[i] .. + seq_len[i] = Unitig::forward_seq of unitig i (number i + 1); depth[i] =
+ * Unitig::depth; path_entries[path_off[s] .. path_off[s + 1]) = get_unitig_path_for_sequence_i32 of the s-th input sequence.
+ * Any out pointer may be NULL. */
+int ac_unitigs_bulk(const ac_graph*, const uint8_t** seq_bytes, const uint64_t** seq_begin, const uint32_t** seq_len,
+                    const double** depth);
+int ac_paths_bulk(const ac_graph*, const int32_t** path_entries, const uint64_t** path_off /* ac_graph_seq_count() + 1 */,
+                  uint64_t* n_entries);
 int ac_timings_get(const ac_graph*, ac_timings* out);
 void ac_free(ac_graph*);
 

@@ -173,3 +173,67 @@ def host_pack_simd_equals_scalar(lib_path):
         want_bits = (code << (62 - 2 * np.arange(32, dtype=np.uint64))).sum(axis=1, dtype=np.uint64)
         want_mask = ((~good).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(axis=1).astype(np.uint32)
         assert np.array_equal(outs[0][0], want_bits) and np.array_equal(outs[0][1], want_mask)
+
+
+def foreign_bytes_are_rejected(lib_path, device=0):
+    """sequence.rs:39-41: a Sequence holds A, C, G, T only (quit_with_error "... contains non-ACGT characters"), and its padding dots
+    sit at its two ends (sequence.rs:44-46).  Every entry that takes sequences or a text from the caller must refuse anything else —
+    an N, a lower-case base, a dot or a separator inside a sequence, a sequence table whose dot counts do not match the text — with
+    that message instead of building a graph from it: the host entry (its packers classify every byte), the device entry and the first
+    phase of a sharded build (K1 checks every non-base byte against the sequence table)."""
+    import numpy as np
+    lib = _capi.load_library(lib_path)
+    k = 11
+    rng = np.random.default_rng(5)
+    base = ["".join("ACGT"[c] for c in rng.integers(0, 4, size=n)) for n in (700, 333, 90)]
+
+    def host(seqs):
+        views = (_capi.SeqView * len(seqs))()
+        keep = [("." * 5 + s + "." * 5).encode() for s in seqs]
+        for i, b in enumerate(keep):
+            views[i].fwd, views[i].length, views[i].id = b, len(seqs[i]), i + 1
+        g = C.c_void_p()
+        rc = lib.ac_compress_build(C.c_uint32(k), C.c_uint32(len(seqs)), views, C.c_uint32(len(seqs)), C.c_int(device), C.byref(g))
+        if rc == 0:
+            lib.ac_free(g)
+        return rc, lib.ac_last_error().decode()
+
+    def dev(seqs, d1=None, d2=None, shard=False):
+        text = ("$" + "$".join("." * 5 + s + "." * 5 for s in seqs) + "$").encode()
+        n = len(seqs)
+        off, p = [], 1
+        for s in seqs:
+            off.append(p); p += len(s) + 10 + 1
+        if str(lib_path).endswith("libautocycler_emu.so"):
+            buf = np.frombuffer(text, dtype=np.uint8).copy(); ptr = buf.ctypes.data
+        else:
+            import torch
+            buf = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(f"cuda:{device}"); ptr = buf.data_ptr()
+        args = [C.c_uint32(k), C.c_uint32(n), C.c_void_p(ptr), C.c_uint64(len(text)), (C.c_uint64 * n)(*off), (C.c_uint32 * n)(*[len(s) for s in seqs]),
+                (C.c_uint16 * n)(*range(1, n + 1)), (C.c_uint16 * n)(*(d1 or [5] * n)), (C.c_uint16 * n)(*(d2 or [5] * n)), C.c_uint32(n), C.c_int(device)]
+        g = C.c_void_p()
+        if shard:
+            rc = lib.ac_shard_begin(*args, C.byref(g))
+            if rc == 0:
+                lib.ac_shard_free(g)
+        else:
+            rc = lib.ac_compress_build_device(*args, C.byref(g))
+            if rc == 0:
+                lib.ac_free(g)
+        return rc, lib.ac_last_error().decode()
+
+    assert host(base)[0] == 0 and dev(base)[0] == 0 and dev(base, shard=True)[0] == 0
+    for which, at, ch in ((0, 350, "N"), (1, 0, "N"), (2, 89, "n"), (1, 100, "a"), (0, 5, "."), (2, 40, "$"), (1, 332, "-"), (0, 699, "\x00")):
+        bad = list(base)
+        bad[which] = bad[which][:at] + ch + bad[which][at + 1:]
+        want = f"input sequence {which + 1} contains non-ACGT characters"
+        for rc, msg in (host(bad), dev(bad), dev(bad, shard=True)):
+            assert rc != 0 and msg == want, (which, at, ch, msg)
+    # a table that claims fewer / more padding dots than the text holds
+    for d1, d2 in (([4, 5, 5], None), (None, [5, 5, 3])):
+        rc, msg = dev(base, d1=d1, d2=d2)
+        assert rc != 0 and "non-ACGT" in msg, msg
+    # end-repaired sequences (bases where padding was) are fine when the table says so
+    rep = list(base)
+    text_ok = dev(rep)[0]
+    assert text_ok == 0

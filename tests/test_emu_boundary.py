@@ -81,8 +81,55 @@ def test_device_entry_rejects_a_bad_sequence_table(emu):
         return rc, lib.ac_last_error().decode()
     assert run(good_off, lens)[0] == 0
     assert "shorter than k" in run(good_off, [5, lens[1]])[1]
-    assert "overlaps" in run([1, 20], lens)[1]
-    assert "overlaps" in run([0, good_off[1]], lens)[1]
+    assert "right behind the separator" in run([1, 20], lens)[1]
+    assert "right behind the separator" in run([0, good_off[1]], lens)[1]
+    assert "right behind the separator" in run([1, good_off[1] + 1], lens)[1]      # a gap between two sequences
+    assert "does not end with the separator" in run(good_off, lens, n_text=len(text) + 1)[1]
     assert "past the end" in run(good_off, [lens[0], lens[1] + 3])[1]
     assert "past the end" in run(good_off, lens, n_text=len(text) - 2)[1]
     assert "padding dots" in run(good_off, lens, d1=(11, 5))[1]
+
+
+def test_foreign_bytes_are_rejected(emu):
+    B.foreign_bytes_are_rejected(emu)
+
+
+def test_bulk_accessors_equal_the_per_item_ones(emu):
+    import parity_util
+    k, (seqs, fn, hd) = 21, seqgen.make_case(5, 21)
+    g, gfa, _ = parity_util.check_case(k, seqs, fn, hd, lib_path=emu)
+    b = g.bulk()
+    for i in range(g.unitig_count):
+        s, d = g.unitig(i)
+        assert b["seq_bytes"][int(b["seq_begin"][i]):int(b["seq_begin"][i]) + int(b["seq_len"][i])].tobytes() == s and b["depth"][i] == d
+    assert [(int(l["a"]), bool(l["a_fwd"]), int(l["b"]), bool(l["b_fwd"])) for l in b["links"]] == g.links()
+    for sidx in range(len(seqs)):
+        assert b["path_entries"][int(b["path_off"][sidx]):int(b["path_off"][sidx + 1])].tolist() == list(g.path(sidx))
+
+
+def test_config_e_checker_on_a_small_mixed_species_job(emu):
+    """tests/fullsize_e.py (the property checker of test_gpu_fullsize.py::test_config_e_full_size_k51, torch on the device there) on a
+    12-assembly mixed-species job built by the emulation: it passes on the real graph and it FAILS on a flipped path entry, a changed
+    unitig base and a changed depth."""
+    import torch
+    import fullsize_e
+    lib = _capi.load_library(emu)
+    job = fullsize_e.make_job(3, 4, genome=20_000, plasmid=1_500, workers=1)
+    text = job["text"]
+    g, _, _ = fullsize_e.build_device(lib, job, text.ctypes.data)
+    t = torch.from_numpy(text)
+    r = fullsize_e.check_on_device(g, job, t, chunk=70_000)
+    assert r["unitigs"] == g.unitig_count and r["path_entries"] > 0
+    b = g.bulk()
+    def broken(arr, i, v):
+        old = arr[i]; arr[i] = v
+        try:
+            fullsize_e.check_on_device(g, job, t, chunk=70_000)
+        except AssertionError:
+            return True
+        finally:
+            arr[i] = old
+        return False
+    assert broken(b["path_entries"], 5, -b["path_entries"][5])
+    assert broken(b["seq_bytes"], 100, ord("A") if b["seq_bytes"][100] != ord("A") else ord("C"))
+    assert broken(b["depth"], 3, b["depth"][3] + 1)

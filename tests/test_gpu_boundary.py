@@ -76,3 +76,24 @@ def test_c_client(lib, tmp_path, k):
     if k == 51:
         seqs, fn, hd = _synth_case(4, 30_000, 2_000, 1e-3, 1e-4, 5)
         B.c_client_matches_the_oracle(tmp_path, k, seqs, 4)
+
+
+def test_foreign_bytes_are_rejected(lib):
+    import autocycler_amd
+    B.foreign_bytes_are_rejected(autocycler_amd.LIB_PATH)
+
+
+def test_bulk_accessors_equal_the_per_item_ones(lib):
+    """ac_unitigs_bulk / ac_paths_bulk (zero-copy views for graphs of 10^8 unitigs) hold what ac_unitig / ac_path / ac_links return."""
+    import numpy as np
+    import parity_util
+    from test_gpu_parity import _synth_case
+    seqs, fn, hd = _synth_case(6, 60_000, 3_000, 1e-3, 1e-4, 99)
+    g, gfa, _ = parity_util.check_case(51, seqs, fn, hd)
+    b = g.bulk()
+    for i in range(g.unitig_count):
+        s, d = g.unitig(i)
+        assert b["seq_bytes"][int(b["seq_begin"][i]):int(b["seq_begin"][i]) + int(b["seq_len"][i])].tobytes() == s and b["depth"][i] == d
+    assert [(int(l["a"]), bool(l["a_fwd"]), int(l["b"]), bool(l["b_fwd"])) for l in b["links"]] == g.links()
+    for sidx in range(len(seqs)):
+        assert b["path_entries"][int(b["path_off"][sidx]):int(b["path_off"][sidx + 1])].tolist() == list(g.path(sidx))

@@ -163,6 +163,30 @@ def test_config_d_full_size_k101():
     assert g.kmer_count > 240_000_000
 
 
+def test_config_e_full_size_k51():
+    """BASELINE configs[4] at FULL size on one MI355X: 25 species x 40 strains (1 % apart) x ~5 Mbp = 1000 assemblies, 5.08 G bp, k = 51
+    (`synth.make_mixed_species(25, 40)`): ~2.1 G distinct canonical k-mers, ~8 x 10^7 unitigs, > 10^9 path entries — more text
+    positions than a 32-bit index holds and more threads than one launch may have.  Neither the oracle nor the reference can hold
+    it (8 KB of heap per distinct k-mer at N = 1000), so the device result is checked through the size-independent
+    properties, evaluated chunk by chunk on the device (tests/fullsize_e.py; the E' and E2 replicas of the same generator are compared
+    with the oracle's md5 below)."""
+    import torch
+    import fullsize_e
+    from autocycler_amd import _capi
+    lib = _capi.load_library()
+    job = fullsize_e.make_job(25, 40)
+    assert job["bases"] > 5_000_000_000 and job["n_assemblies"] == 1000
+    d_text = torch.from_numpy(job["text"]).to("cuda:0")
+    g, times, _ = fullsize_e.build_device(lib, job, d_text.data_ptr(), repair=True, builds=1)
+    lib.ac_release_memory()
+    r = fullsize_e.check_on_device(g, job, d_text, log=print)
+    print("config E full size:", times, g.stats_post, "kmers", g.kmer_count, r)
+    assert r["unitigs"] > 50_000_000 and r["path_entries"] > 1_000_000_000
+    assert g.kmer_count > 4_000_000_000
+    g.close()
+    lib.ac_release_memory()
+
+
 @pytest.mark.parametrize("golden_name", ["configC_k51", "configDprime_k101", "configB_k51", "configEprime_k51", "configE2_k51"])
 def test_gfa_digest_equals_the_oracle(golden_name):
     """Bit-exact parity at full size: the GFA built on the device (end repair on the device text, build, GFA text — the flow of

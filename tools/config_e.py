@@ -1,63 +1,69 @@
 #!/usr/bin/env python3
-"""BASELINE config E in miniature on one MI355X: SPECIES species x STRAINS assemblies of ~5 Mbp (strains 1 % diverged from their
-species root), one compress job, k = 51: end repair on the device, graph build, internal consistency checks, timing.
-    python tools/config_e.py [SPECIES=5] [STRAINS=40]"""
+"""BASELINE.json configs[4] on one MI355X: SPECIES species x STRAINS strains (1 % apart) x ~GENOME bp, one compress job, k = 51
+(`synth.make_mixed_species`): end repair on the device, BUILDS builds, one more with the stage table, and (--check) the
+size-independent properties of tests/fullsize_e.py evaluated on the device.  One JSON line on stdout.
+    python tools/config_e.py [--species 25] [--strains 40] [--genome 5000000] [--builds 2] [--check]"""
+import argparse
 import ctypes as C
 import json
+import os
 import sys
 import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-import numpy as np
-import torch
+sys.path.insert(0, str(ROOT / "tests"))
 
-import bench
-from autocycler_amd import _capi, synth
 
-species = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-strains = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-k = 51
-lib = _capi.load_library()
-lib.ac_seqs_views.restype = C.POINTER(_capi.SeqView)
-lib.ac_seqs_count.restype = C.c_uint32
-lib.ac_seqs_free.argtypes = [C.c_void_p]
-t0 = time.time()
-seqs, fn, hd = [], [], []
-for sp in range(species):
-    for i, contigs in enumerate(synth.make_assemblies(strains, sub=1e-2, indel=1e-4, seed=900_000 + 1000 * sp)):
-        for header, s in contigs:
-            seqs.append(np.ascontiguousarray(s)); fn.append(f"species{sp:02d}_strain{i:03d}.fasta"); hd.append(header)
-t_gen = time.time() - t0
-n_asm = species * strains
-h = bench.prepare(lib, k, seqs, fn, hd, n_asm, threads=32, repair=0)
-n = lib.ac_seqs_count(h)
-views = lib.ac_seqs_views(h)
-n_text = lib.ac_text_size(C.c_uint32(k), views, C.c_uint32(n))
-text = np.empty(n_text, dtype=np.uint8)
-off = (C.c_uint64 * n)(); d1 = (C.c_uint16 * n)(); d2 = (C.c_uint16 * n)()
-assert lib.ac_layout_text(C.c_uint32(k), views, C.c_uint32(n), text.ctypes.data_as(C.c_void_p), off, d1, d2) == 0
-lens = (C.c_uint32 * n)(*[views[i].length for i in range(n)])
-ids = (C.c_uint16 * n)(*[views[i].id for i in range(n)])
-bases = sum(lens)
-d_text = torch.from_numpy(text).to("cuda:0")
-secs = C.c_double()
-assert lib.ac_end_repair_device(C.c_uint32(k), C.c_void_p(d_text.data_ptr()), C.c_uint64(n_text), off, lens, d1, d2, C.c_uint32(n), C.c_int(0),
-                                C.byref(secs), None) == 0, lib.ac_last_error()
-times = []
-g = None
-for it in range(3):
-    if g is not None:
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--species", type=int, default=25)
+    ap.add_argument("--strains", type=int, default=40)
+    ap.add_argument("--genome", type=int, default=5_000_000)
+    ap.add_argument("--builds", type=int, default=2)
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--no-stages", action="store_true")
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    import fullsize_e
+    from autocycler_amd import _capi
+    log = lambda *a: print(*a, file=sys.stderr, flush=True)
+    lib = _capi.load_library()
+    mem_gb = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 2**30
+    log(f"host: {os.cpu_count()} cpus, {mem_gb:.0f} GB")
+    job = fullsize_e.make_job(args.species, args.strains, genome=args.genome, plasmid=args.genome // 50)
+    log(f"job: {job['n']} sequences, {job['bases']} bases, generate {job['generate_s']:.1f}s layout {job['layout_s']:.1f}s")
+    t0 = time.time()
+    d_text = torch.from_numpy(job["text"]).to("cuda:0")
+    torch.cuda.synchronize()
+    log(f"text on the device {time.time() - t0:.1f}s")
+    g, times, repair_s = fullsize_e.build_device(lib, job, d_text.data_ptr(), repair=True, builds=args.builds)
+    log(f"builds: {times}")
+    tm = g.timings()
+    stages = None
+    if not args.no_stages:
+        lib.ac_set_stage_timing(1)
         g.close()
-    hg = C.c_void_p()
-    t1 = time.perf_counter()
-    rc = lib.ac_compress_build_device(C.c_uint32(k), C.c_uint32(n_asm), C.c_void_p(d_text.data_ptr()), C.c_uint64(n_text), off, lens, ids, d1, d2,
-                                      C.c_uint32(n), C.c_int(0), C.byref(hg))
-    assert rc == 0, lib.ac_last_error()
-    times.append(time.perf_counter() - t1)
-    g = _capi.Graph(lib, hg, n)
-tm = g.timings()
-print(json.dumps({"workload": f"{species} species x {strains} strains x ~5 Mbp, 1 % strain divergence, k={k}, one MI355X", "bases": bases,
-                  "sequences": n, "generate_s": t_gen, "end_repair_device_s": secs.value, "build_s": times, "Mbp_per_s": bases / 1e6 / min(times),
-                  "graph": {**g.stats_post, "kmers": g.kmer_count, "path_entries": tm["n_path_entries"], "table_capacity": tm["table_capacity"]}}))
+        g, t_st, _ = fullsize_e.build_device(lib, job, d_text.data_ptr(), repair=False, builds=1)
+        lib.ac_set_stage_timing(0)
+        tm = g.timings()
+        stages = {kk: round(v * 1e3, 3) for kk, v in tm.items() if isinstance(v, float) and kk not in ("insert_kernel_ms", "upload_device_ms") and v}
+        log(f"stage build: {t_st[0]:.4f}s {stages}")
+    out = {"workload": f"{args.species} species x {args.strains} strains x ~{args.genome} bp (1 % strain divergence), k=51, one MI355X",
+           "bases": job["bases"], "sequences": job["n"], "host_cpus": os.cpu_count(), "host_mem_gb": round(mem_gb),
+           "generate_s": job["generate_s"], "end_repair_device_s": repair_s, "build_s": times,
+           "Mbp_per_s": job["bases"] / 1e6 / min(times), "stages_ms": stages,
+           "graph": {**g.stats_post, "pre_total_length": g.stats_pre["total_length"], "kmers": g.kmer_count, "path_entries": tm["n_path_entries"],
+                     "table_capacity": tm["table_capacity"], "n_distinct": tm["n_distinct"], "passes": tm["simplify_passes"],
+                     "levels": tm["n_levels"], "candidates": tm["n_candidates"], "insert_kernel_ms": tm["insert_kernel_ms"],
+                     "insert_real": tm["insert_real"], "insert_launches": tm["insert_launches"]}}
+    if args.check:
+        lib.ac_release_memory()
+        out["check"] = fullsize_e.check_on_device(g, job, d_text, log=log)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

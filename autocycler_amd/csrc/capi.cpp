@@ -21,6 +21,7 @@
 #include <fstream>
 #include <chrono>
 #include <fcntl.h>
+#include <cerrno>
 #include <unistd.h>
 #include "device_rt.hpp"
 
@@ -78,6 +79,9 @@ static void select_device(int device) {
         if (arena_device >= 0) {
             if (g_live_shards) throw DeviceError("a sharded build is in flight on device " + std::to_string(arena_device) + ": this process cannot use device " + std::to_string(device) + " until it is freed");
             Arena::device().release_all();
+#ifndef AC_EMU
+            Mailbox::get().release();      // the read-back page is mapped into the previous device's address space
+#endif
         }
         arena_device = device;
     }
@@ -121,7 +125,10 @@ static void build_graph(GraphBuilder& b, uint32_t assembly_count, ac_graph* h) {
 // 95 MB.  With the S and L lines formatted by several threads too (gfa_chunks) the write stage of the whole command went from 48 to
 // 26 ms (profiles/r07l_e2e_configC.log).
 static void write_pieces(const std::string& path, const std::vector<std::string>& pieces, int threads) {
-    int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    // into a temporary file next to the target, renamed over it when every piece is down: a failed write never leaves a truncated
+    // input_assemblies.gfa behind
+    const std::string tmp = path + ".tmp." + std::to_string((long)::getpid());
+    int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) throw UserError("failed to write " + path);
     std::vector<uint64_t> at(pieces.size() + 1, 0);
     for (size_t i = 0; i < pieces.size(); i++) at[i + 1] = at[i] + pieces[i].size();
@@ -132,6 +139,7 @@ static void write_pieces(const std::string& path, const std::vector<std::string>
             const char* p = pieces[i].data(); uint64_t left = pieces[i].size(), off = at[i];
             while (left) {
                 ssize_t w = ::pwrite(fd, p, left, (off_t)off);
+                if (w < 0 && errno == EINTR) continue;
                 if (w <= 0) { bad.store(true); return; }
                 p += w; left -= (uint64_t)w; off += (uint64_t)w;
             }
@@ -142,7 +150,8 @@ static void write_pieces(const std::string& path, const std::vector<std::string>
     for (int i = 1; i < T; i++) pool.emplace_back(worker);
     worker();
     for (auto& t : pool) t.join();
-    if (::close(fd) != 0 || bad.load()) throw UserError("failed to write " + path);
+    const bool closed = ::close(fd) == 0;
+    if (!closed || bad.load() || ::rename(tmp.c_str(), path.c_str()) != 0) { ::unlink(tmp.c_str()); throw UserError("failed to write " + path); }
 }
 
 extern "C" {
@@ -688,6 +697,15 @@ int ac_timings_get(const ac_graph* g, ac_timings* o) {
     o->n_local_distinct = t.n_local_distinct; o->n_fragments = t.n_fragments; o->fragment_bytes = t.fragment_bytes;
     o->upload_device_ms = t.upload_device_ms;
     return 0;
+}
+// The same for a caller that was compiled against another version of the header: at most out_size bytes are written (the struct only
+// ever grows at its end), the library's own size is returned.
+size_t ac_timings_get_sized(const ac_graph* g, ac_timings* out, size_t out_size) {
+    ac_timings t;
+    memset(&t, 0, sizeof t);
+    ac_timings_get(g, &t);
+    if (out) memcpy(out, &t, std::min(out_size, sizeof t));
+    return sizeof t;
 }
 void ac_free(ac_graph* g) { delete g; }
 

@@ -12,6 +12,8 @@
 #include <algorithm>
 
 #include <mutex>
+#include <time.h>
+#include <unistd.h>
 
 #include "kmer_ops.hpp"
 #include "graph_types.hpp"
@@ -42,6 +44,7 @@ typedef int stream_t;
 #ifdef AC_EMU
 inline u64 atomic_cas64(u64* p, u64 expected, u64 desired) { u64 old = *p; if (old == expected) *p = desired; return old; }
 inline u64 atomic_min64(u64* p, u64 v) { u64 o = *p; if (v < o) *p = v; return o; }
+inline void atomic_max64(u64* p, u64 v) { if (v > *p) *p = v; }
 inline void atomic_xor64(u64* p, u64 v) { *p ^= v; }
 inline u32 atomic_add32(u32* p, u32 v) { u32 o = *p; *p += v; return o; }
 inline u64 atomic_add64(u64* p, u64 v) { u64 o = *p; *p += v; return o; }
@@ -54,6 +57,7 @@ __device__ inline u64 atomic_cas64(u64* p, u64 expected, u64 desired) {
     return (u64)atomicCAS((unsigned long long*)p, (unsigned long long)expected, (unsigned long long)desired);
 }
 __device__ inline u64 atomic_min64(u64* p, u64 v) { return (u64)atomicMin((unsigned long long*)p, (unsigned long long)v); }
+__device__ inline void atomic_max64(u64* p, u64 v) { atomicMax((unsigned long long*)p, (unsigned long long)v); }
 __device__ inline void atomic_xor64(u64* p, u64 v) { atomicXor((unsigned long long*)p, (unsigned long long)v); }
 __device__ inline u32 atomic_add32(u32* p, u32 v) { return atomicAdd(p, v); }
 __device__ inline u64 atomic_add64(u64* p, u64 v) { return (u64)atomicAdd((unsigned long long*)p, (unsigned long long)v); }
@@ -72,15 +76,19 @@ __device__ inline void atomic_max32(u32* p, u32 v) { atomicMax(p, v); }
 class Arena {
   public:
     static Arena& device() { static Arena a(false); return a; }
+    static const size_t COALESCE_LIMIT = (size_t)16 << 30;
     void* alloc(size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255;
         if (bytes == 0) bytes = 256;
-        if (blocks_.empty() || blocks_.back().used + bytes > blocks_.back().cap) {
-            size_t cap = std::max(bytes, grow_);
-            Block b; b.cap = cap; b.used = 0; b.p = raw_alloc(cap);
+        // first fit, forwards only: blocks behind the current one are empty (a rewind emptied them) or do not exist yet
+        size_t i = cur_;
+        while (i < blocks_.size() && blocks_[i].used + bytes > blocks_[i].cap) i++;
+        if (i == blocks_.size()) {
+            Block b; b.cap = std::max(bytes, grow_); b.used = 0; b.p = raw_alloc(b.cap);
             blocks_.push_back(b);
         }
-        Block& b = blocks_.back();
+        cur_ = i;
+        Block& b = blocks_[i];
         void* r = (char*)b.p + b.used;
         b.used += bytes;
         peak_ = std::max(peak_, total_used());
@@ -89,14 +97,18 @@ class Arena {
     // Start of a build: everything handed out so far is dead.
     void reset() {
         on_reset();
-        if (blocks_.size() > 1) {   // coalesce: next build gets one block big enough for the last one
-            size_t total = 0;
-            for (auto& b : blocks_) { total += b.cap; raw_free(b.p); }
+        const size_t last_peak = peak_;
+        peak_ = 0; cur_ = 0;
+        size_t total = 0;
+        for (auto& b : blocks_) total += b.cap;
+        if (blocks_.size() > 1 && total <= COALESCE_LIMIT) {   // coalesce: next build gets one block big enough for the last one (what it used
+            for (auto& b : blocks_) raw_free(b.p);              // at its peak plus an eighth; the capacities add up to more: tails a large request skipped)
+            if (last_peak) total = std::min(total, last_peak + last_peak / 8 + ((size_t)256 << 20));
             blocks_.clear();
             Block b; b.cap = total; b.used = 0; b.p = raw_alloc(total);
             blocks_.push_back(b);
-        } else if (!blocks_.empty()) {
-            blocks_.back().used = 0;
+        } else {   // a large arena keeps its blocks: the next build of the same job makes the same requests in the same order and fits them the same
+            for (auto& b : blocks_) b.used = 0;      // way, and giving 150 GB back and asking for it again costs seconds (configs[4]: 8 s)
         }
     }
     // First build of a process: one block of about the size the build will need, so that neither this build grows the
@@ -110,8 +122,23 @@ class Arena {
     void release_all() {
         on_reset();
         for (auto& b : blocks_) raw_free(b.p);
-        blocks_.clear();
+        blocks_.clear(); cur_ = 0;
     }
+    // Stage-local temporaries of a build that is larger than usual (BASELINE configs[4]: 270 GB without this): take a mark, allocate, and
+    // rewind when the stage is done — everything allocated since the mark is dead.  All work runs in order on stream 0, so memory
+    // handed out again after a rewind cannot be touched by what used it before; blocks that were added since the mark go back to the
+    // arena's later allocations.
+    struct Mark { size_t block, used; bool empty; };
+    Mark mark() const { return blocks_.empty() ? Mark{0, 0, true} : Mark{cur_, blocks_[cur_].used, false}; }
+    void rewind(const Mark& m) {
+        on_rewind();
+        if (blocks_.empty()) return;
+        cur_ = m.empty ? 0 : m.block;
+        blocks_[cur_].used = m.empty ? 0 : m.used;
+        for (size_t i = cur_ + 1; i < blocks_.size(); i++) blocks_[i].used = 0;      // kept for the allocations to come (no hipFree: it waits for the device)
+    }
+    size_t peak() const { return peak_; }
+    double alloc_seconds() const { return alloc_s_; }
     size_t total_used() const { size_t t = 0; for (auto& b : blocks_) t += b.used; return t; }
     size_t capacity() const { size_t t = 0; for (auto& b : blocks_) t += b.cap; return t; }
     void set_grow(size_t g) { grow_ = g; }
@@ -120,7 +147,11 @@ class Arena {
     struct Block { void* p; size_t cap, used; };
     explicit Arena(bool host) : host_(host) {}
     void on_reset();      // (defined after FillQueue)
+    void on_rewind();
+    static double wall() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
     void* raw_alloc(size_t bytes) {
+        const double t0 = wall();
+        struct Acc { double& a; double t0; ~Acc() { a += wall() - t0; } } acc{alloc_s_, t0};
 #ifdef AC_EMU
         void* p = malloc(bytes);
         if (!p) throw DeviceError("emu malloc failed");
@@ -133,16 +164,19 @@ class Arena {
 #endif
     }
     void raw_free(void* p) {
+        const double t0 = wall();
 #ifdef AC_EMU
         free(p);
 #else
         if (host_) (void)hipHostFree(p); else (void)hipFree(p);
 #endif
+        alloc_s_ += wall() - t0;
     }
+    double alloc_s_ = 0;      // seconds spent in the runtime's allocator so far (AC_DEBUG_ARENA)
     bool host_;
     std::vector<Block> blocks_;
     size_t grow_ = (size_t)64 << 20;
-    size_t peak_ = 0;
+    size_t peak_ = 0, cur_ = 0;
 };
 
 // Recycling pool of pinned host blocks for results that outlive a build (they are owned by the caller's graph
@@ -197,9 +231,23 @@ class PinnedPool {
     static void give_back(void* p, size_t cap) {
         PinnedPool& self = get();
         std::lock_guard<std::mutex> lock(self.mu_);
-        if (self.free_.size() >= 32 || self.held_ + cap > ((size_t)8 << 30)) { raw_free(p); return; }
+        if (self.free_.size() >= 32 || self.held_ + cap > keep_limit()) { raw_free(p); return; }
         self.free_.push_back(Entry{p, cap});
         self.held_ += cap;
+    }
+    // Pinned bytes kept for the next build: 8 GB, or a sixteenth of the host's memory up to 64 GB (the results of a BASELINE configs[4]
+    // job are 14 GB, and pinning that much anew costs seconds per build); AC_PINNED_POOL_GB overrides.
+    static size_t keep_limit() {
+        static const size_t v = [] {
+            if (const char* e = getenv("AC_PINNED_POOL_GB")) return (size_t)std::max(0, atoi(e)) << 30;
+            size_t phys = 0;
+#if defined(_SC_PHYS_PAGES) && defined(_SC_PAGE_SIZE)
+            const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+            if (pages > 0 && psz > 0) phys = (size_t)pages * (size_t)psz;
+#endif
+            return std::min<size_t>(std::max<size_t>((size_t)8 << 30, phys / 16), (size_t)64 << 30);
+        }();
+        return v;
     }
     std::mutex mu_;
     std::vector<Entry> free_;
@@ -260,9 +308,11 @@ class FillQueue {
 };
 inline void flush_fills() { FillQueue::get().flush(); }
 inline void Arena::on_reset() { if (!host_) FillQueue::get().drop(); }
+inline void Arena::on_rewind() { if (!host_) FillQueue::get().flush(); }      // queued fills of buffers that stay alive must not be lost
 #else
 inline void flush_fills() {}
 inline void Arena::on_reset() {}
+inline void Arena::on_rewind() {}
 #endif
 
 template <class T>
@@ -393,14 +443,19 @@ class Mailbox {
     }
   private:
     Mailbox() {}
-    void ensure() {
-        if (h_) return;
+    void ensure() {      // the page and its device-side address belong to the device that was current when it was mapped
+        int dev = 0;
+        AC_HIP_CHECK(hipGetDevice(&dev));
+        if (h_ && dev == dev_) return;
+        release();
         AC_HIP_CHECK(hipHostMalloc((void**)&h_, CAP + 64, hipHostMallocMapped | hipHostMallocCoherent));
         memset(h_, 0, CAP + 64);
         AC_HIP_CHECK(hipHostGetDevicePointer((void**)&d_, h_, 0));
+        dev_ = dev; seq_ = 0;
     }
     u8* h_ = nullptr; u8* d_ = nullptr;
     u64 seq_ = 0;
+    int dev_ = -1;
 };
 inline bool use_mailbox() { static const bool v = getenv("AC_NO_MAILBOX") == nullptr; return v; }
 #endif

@@ -76,6 +76,7 @@ struct Table {
     u32 n_owners;     // > 1: one job over several devices (§7) — this table only holds the k-mers whose home hash maps to `my_owner`;
     u32 my_owner;     // inserts of other keys are skipped, lookups of other keys answer "not here" (their owner answers)
     u64* sflags;      // during the insert only (optional): two SIBLING bits per slot (sib_note); MarkFunctor moves them to text positions
+    u64* full_at;     // during the insert only (optional): ~(smallest text position whose insert found the table full), by atomic max
 };
 // Sibling bits.  Two k-mers of one middle are siblings in x (same first base, read in the orientation in which the middle is
 // canonical: key_place) or in y (same last base); a k-mer WITHOUT a sibling in x / y is the only successor / predecessor its text
@@ -252,6 +253,7 @@ template <int W> AC_D u64 table_insert(const TextCtx& t, const Table& tb, const 
         s = (s + 1) & tb.cap_mask;
     }
     atomic_or32(err, 1u);
+    if (tb.full_at) atomic_max64(tb.full_at, ~p);
     return NOREF;
 }
 
@@ -346,7 +348,8 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 //                     keys in registers; 0 = key records + library reduce-by-key.  Unset = automatic (2 for long keys and unitigs, else 1).
 //   AC_MINKEY_PREFIX_BASES   (tests) bases in that prefix, default 31.
 //   AC_SEED_PREFIX_SORT  1 (default): seed order by one sort on a 64-bit prefix of the seed keys + full-key ranking inside the groups that
-//                     agree on it (AC_SEED_PREFIX_BITS: tests); 0: the full-key sorts —
+//                     agree on it (AC_SEED_PREFIX_BITS: tests; a group of more than AC_SEED_MAX_GROUP = 1024 members sends the build to the
+//                     full-key sorts); 0: the full-key sorts —
 //   AC_SEED_RADIX_LIMIT  unitigs from which those are W radix passes instead of the comparator merge sort (default 2^19).
 //   AC_PATH_CHUNK     text positions per path walker (default: 5 x the mean unitig length, a power of two in [64, 2048]).
 //   AC_PATH_FILTER    1 (default): the walk keeps smallest positions only for unitig sides that can become expand_repeats
@@ -397,6 +400,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static int minkey_prefix_bases() { const char* e = getenv("AC_MINKEY_PREFIX_BASES"); int v = e ? atoi(e) : 31; return v < 1 ? 1 : (v > 31 ? 31 : v); }      // tests: a shorter prefix takes the full-key path often
 [[maybe_unused]] static u32 expand_group() { const char* e = getenv("AC_EXPAND_GROUP"); int v = e ? atoi(e) : 16; return (v == 8 || v == 32 || v == 64) ? (u32)v : 16u; }      // lanes per junction in expand_wave_kernel
 [[maybe_unused]] static bool seed_prefix_sort() { const char* e = getenv("AC_SEED_PREFIX_SORT"); return e ? atoi(e) != 0 : true; }      // 0: seed order by the full-key sorts
+[[maybe_unused]] static u32 seed_max_group() { const char* e = getenv("AC_SEED_MAX_GROUP"); int v = e ? atoi(e) : 1024; return (u32)(v < 1 ? 1 : v); }      // tests: smaller groups take the fallback
 [[maybe_unused]] static int seed_prefix_bits() { const char* e = getenv("AC_SEED_PREFIX_BITS"); int v = e ? atoi(e) : 64; return v < 1 ? 1 : (v > 64 ? 64 : v); }      // tests
 [[maybe_unused]] static u32 degree_region_cap() { const char* e = getenv("AC_DEGREE_REGION_CAP"); int v = e ? atoi(e) : 0; return (u32)(v < 0 ? 0 : v); }      // tests: entries per queue region (0 = sized from N)
 [[maybe_unused]] static u64 upload_chunk_bytes() { const char* e = getenv("AC_UPLOAD_CHUNK_MB"); int v = e ? atoi(e) : 64; return (u64)((v == 16 || v == 32 || v == 128) ? v : 64) << 20; }      // text bytes per upload chunk
@@ -577,7 +581,7 @@ struct GraphBuilder::Impl {
 #endif
         pt.pack();
     }
-    Table graph_table() const { return Table{const_cast<u64*>(slots.ptr()), cap - 1, occ.ptr(), nullptr, n_owners, my_owner, nullptr}; }
+    Table graph_table() const { return Table{const_cast<u64*>(slots.ptr()), cap - 1, occ.ptr(), nullptr, n_owners, my_owner, nullptr, nullptr}; }
     template <int W> void fragments();
     template <int W> void table();                      // K2, K3 on G
     void novel_list(u64 known_n);
@@ -618,6 +622,8 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
     DBuf<u64> sl;
     DBuf<u64> nbm(pt.n_text / 64 + 2);   // K3a falls out of the insert: bit p set <=> p is the smallest occurrence of its canonical k-mer
     u64 n_distinct = 0;
+    const Arena::Mark retry_mark = Arena::device().mark();      // a retry gives the table it outgrew back (configs[4]: 21 GB of them)
+    std::vector<u64> phase_end;
     for (;;) {
         sl.alloc(c);
         sl.fill_bytes(0xFF);
@@ -627,7 +633,9 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
         if (want_sib) { sflags.alloc(c / 32 + 1); sflags.fill_bytes(0); }
         else sflags = DBuf<u64>();
         u32* ierr = (u32*)&istats.ptr()[256].real;
-        Table tb{sl.ptr(), c - 1, nullptr, nbm.ptr(), (&pt == &uni) ? n_owners : 1u, (&pt == &uni) ? my_owner : 0u, want_sib ? sflags.ptr() : nullptr};
+        Table tb{sl.ptr(), c - 1, nullptr, nbm.ptr(), (&pt == &uni) ? n_owners : 1u, (&pt == &uni) ? my_owner : 0u, want_sib ? sflags.ptr() : nullptr,
+                 &istats.ptr()[256].claimed};
+        phase_end.clear();
         stream_sync();
 #ifndef AC_EMU
         // the dominant kernel's duration, live: one event pair around EVERY phase launch, summed (what sits between the launches — the
@@ -675,6 +683,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
                 if (insert_profile()) {      // measurement only: per-wavefront cycle split of this launch on stderr
                     DBuf<u64> prof(16);
                     prof.fill_bytes(0);
+                    flush_fills();
                     hipLaunchKernelGGL((insert_wave_kernel<W, true>), dim3((unsigned)blocks), dim3(256), 0, 0, t, tb, pb, pe, chunk, istats.ptr(), ierr, prof.ptr());
                     AC_HIP_CHECK(hipGetLastError());
                     std::vector<u64> h = to_host(prof, 16);
@@ -695,6 +704,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
             }
             launches++;
             pb = pe;
+            phase_end.push_back(pe);
             if (launches == 2 && insert_adaptive() && pb < p_end_all && (p_end_all - pb) > 4 * first) {
                 std::vector<InsertStats> st2 = to_host(istats, 257);
                 u64 claimed = 0;
@@ -714,15 +724,32 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
         tm->insert_launches += launches;
         std::vector<InsertStats> st = to_host(istats, 257);
         const bool ins_err = st[256].real != 0;
+        const u64 full_at = ~st[256].claimed;      // smallest position that found the table full (valid with ins_err)
         st.pop_back();
         n_distinct = 0;
         u64 real = 0;
         for (auto& x : st) { n_distinct += x.claimed; real += x.real; }
         bool overflow = ins_err || (n_distinct * 10 > c * 7);
         if (!overflow) { tm->insert_real += real; tm->insert_positions += pt.n_text; break; }
-        if (c >= next_pow2(pt.n_bases * 4 + 1024)) throw DeviceError("k-mer table overflow");
-        c *= 4;
+        const u64 c_max = next_pow2(pt.n_bases * 4 + 1024);
+        if (c >= c_max) throw DeviceError("k-mer table overflow");
+        // How much larger?  At least four times.  A run that got through knows its k-mer count (target load 0.5); one that filled the
+        // table after a fraction of the text extrapolates from the end of the phase it filled it in (the phases run one after the
+        // other) — a mixed-species job (configs[4]: 2.1 G distinct k-mers behind a capacity hint of 1000 assemblies) otherwise climbs
+        // 32 M -> 128 M -> 512 M -> 2 G -> 8 G slots, re-inserting everything each time.
+        u64 want = c * 4;
+        if (!ins_err) want = std::max(want, next_pow2(n_distinct * 2));
+        else {
+            u64 pe_full = p_end_all;
+            for (u64 e : phase_end) if (full_at < e) { pe_full = e; break; }
+            const double need = (double)c * 0.7 * (double)p_end_all / (double)std::max<u64>(pe_full, 1);
+            want = std::max(want, next_pow2((u64)std::min(need * 2.0, 9.0e18)));
+        }
+        c = std::min(want, c_max);
         tm->insert_kernel_ms = 0; tm->insert_launches = 0;
+        stream_sync();
+        sl = DBuf<u64>(); sflags = DBuf<u64>();
+        Arena::device().rewind(retry_mark);
     }
     if (n_distinct >= 0xFFFFFFF0ULL) throw DeviceError("too many distinct k-mers for 32-bit novel indices");
     memo_n_text = pt.n_text; memo_k = k; memo_cap = c; memo_shift = table_shift();
@@ -848,6 +875,7 @@ template <int W> void GraphBuilder::Impl::degrees() {
         launch(2 * (u64)g.n_seqs, EndSetFunctor<W>{g.ctx((int)k), es});
     }
     if (sib.size() && degree_flags() == 1 && (!g.any_dots || es.keys)) {      // settle what the sibling bits settle, queue the rest, probe the queues
+        const Arena::Mark deg_mark = Arena::device().mark();      // the queues below are the stage's own (8 B per distinct k-mer)
         DegWork wk;
         // a k-mer whose window holds dots starts within k - 1 positions of a sequence end: at most 2 (k - 1) per sequence
         const u64 max_generic = std::min<u64>(N, 2 * ((u64)k - 1) * g.n_seqs);
@@ -869,6 +897,8 @@ template <int W> void GraphBuilder::Impl::degrees() {
                     (unsigned long long)c0, (unsigned long long)c1, (unsigned long long)sx, (int)g.any_dots);
         }
 #endif
+        items = DBuf<u64>(); counts = DBuf<u32>();
+        Arena::device().rewind(deg_mark);
     } else
         launch(N, DegreeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kinfo.ptr(), g.any_dots, 0, bm.ptr(), sib.size() ? sib.ptr() : nullptr, es});
     Novel nv{bm.ptr(), wprefix.ptr()};
@@ -941,18 +971,26 @@ template <int W> void GraphBuilder::Impl::unitigs() {
     // K9 seed order = rank of the smallest k-mer
     order.alloc(U);
     launch(U, IotaFunctor{order.ptr()});
+    bool seeds_ordered = false;
     if (seed_prefix_sort()) {      // one sort on a 64-bit prefix of the seed keys, ties on full keys: any key width, any number of unitigs
         DBuf<u64> wkey(U);
         launch(U, SeedPrefixFunctor<W>{umin.ptr(), (int)k, wkey.ptr(), seed_prefix_bits()});
-        sort_pairs_u64_u32(wkey, order, U, 64);
-        DBuf<u32> settled(U);
-        launch(U, SeedTieFunctor<W>{order.ptr(), wkey.ptr(), U, umin.ptr(), settled.ptr()});
-        order = std::move(settled);
-        DBuf<MinVal<W>> sorted(U);
-        launch(U, GatherMinFunctor<W>{order.ptr(), umin.ptr(), sorted.ptr()});
-        umin = std::move(sorted);
+        DBuf<u32> by_prefix(U);
+        copy_d2d(by_prefix.ptr(), order.ptr(), (size_t)U * 4);
+        sort_pairs_u64_u32(wkey, by_prefix, U, 64);
+        DBuf<u32> settled(U), big(1, true);
+        launch(U, SeedTieFunctor<W>{by_prefix.ptr(), wkey.ptr(), U, umin.ptr(), settled.ptr(), seed_max_group(), big.ptr()});
+        if (read_scalar(big.ptr()) == 0) {
+            order = std::move(settled);
+            DBuf<MinVal<W>> sorted(U);
+            launch(U, GatherMinFunctor<W>{order.ptr(), umin.ptr(), sorted.ptr()});
+            umin = std::move(sorted);
+            seeds_ordered = true;
+        }      // else: a huge group of equal prefixes — `order` is still the identity: the full-key sorts below
+    }
+    if (seeds_ordered) {
     } else if constexpr (W <= 4) {
-        if ((u64)U >= seed_radix_limit()) {      // many unitigs (mixed-species graphs: millions): W stable LSD radix passes over the key words
+        if ((u64)U >= seed_radix_limit() || seed_prefix_sort()) {      // many unitigs (or the prefix sort's fallback) (mixed-species graphs: millions): W stable LSD radix passes over the key words
             DBuf<u64> wkey(U);                    // (the comparator merge sort takes 2.4 ms for 3.5 M seeds, 5.3 ms for 6.5 M)
             for (int word = W - 1; word >= 0; word--) {
                 launch(U, MinWordFunctor<W>{order.ptr(), umin.ptr(), word, wkey.ptr()});
@@ -1006,14 +1044,18 @@ template <int W> void GraphBuilder::Impl::walk() {
     u64 n_walkers = (loc.n_text + PC - 1) / PC;
     depth.alloc(U, true); minpos_fwd.alloc(U); minpos_rev.alloc(U);
     minpos_fwd.fill_bytes(0xFF); minpos_rev.fill_bytes(0xFF);
-    DBuf<u64> wcount(n_walkers + 1), woff(n_walkers + 1);
-    DBuf<int32_t> stage(((n_walkers + 63) / 64) * 64 * PC);
-    DBuf<u32> seq_tid(loc.n_seqs), seq_j(loc.n_seqs);
     path_off.alloc((u64)loc.n_seqs + 1);
-    wcount.fill_bytes(0);
     const bool filter = path_filter();
     maybe_dest_valid = filter;
     if (filter) { maybe_dest.alloc((u64)U * 2); launch((u64)U * 2, MaybeDestFunctor{links.ptr(), maybe_dest.ptr()}); }
+    fs0.alloc(U, true); fe0.alloc(U, true);
+    // everything from here to the compaction is the walk's own: 4 bytes of staging per text position (configs[4]: 20 GB) go back to
+    // the arena once the entries are compacted — they are compacted into the staging area's own first bytes
+    const Arena::Mark walk_mark = Arena::device().mark();
+    DBuf<int32_t> stage(((n_walkers + 63) / 64) * 64 * PC);
+    DBuf<u64> wcount(n_walkers + 1), woff(n_walkers + 1);
+    DBuf<u32> seq_tid(loc.n_seqs), seq_j(loc.n_seqs);
+    wcount.fill_bytes(0);
     launch((u64)U * 10, WlinkFlagFunctor{filter ? maybe_dest.ptr() : nullptr, wlinks.ptr(), counters.ptr() + 4});
     DBuf<V16> uinfo(U);
     launch(U, WalkInfoFunctor{uc, filter ? maybe_dest.ptr() : nullptr, uinfo.ptr()});
@@ -1022,12 +1064,17 @@ template <int W> void GraphBuilder::Impl::walk() {
                                         path_diag(), walk_answers, n_walkers});
     exclusive_scan_u64(wcount.ptr(), woff.ptr(), n_walkers + 1);
     n_ent = read_scalar(woff.ptr() + n_walkers);
-    ent_val.alloc(n_ent);
-    launch_full(((n_walkers + 63) / 64) * 64, PathCompactFunctor{stage.ptr(), wcount.ptr(), woff.ptr(), PC, n_walkers, ent_val.ptr()});
     launch(loc.n_seqs, PathOffFunctor{seq_tid.ptr(), seq_j.ptr(), woff.ptr(), path_off.ptr()});
     tm->n_path_entries = n_ent;
     copy_h2d(path_off.ptr() + loc.n_seqs, &n_ent, 8);
-    fs0.alloc(U, true); fe0.alloc(U, true);
+    {
+        DBuf<int32_t> packed(n_ent);      // (beyond the staging area: the compaction reads rows that later wavefronts' outputs would overwrite)
+        launch_full(((n_walkers + 63) / 64) * 64, PathCompactFunctor{stage.ptr(), wcount.ptr(), woff.ptr(), PC, n_walkers, packed.ptr()});
+        stage = DBuf<int32_t>(); wcount = DBuf<u64>(); woff = DBuf<u64>(); seq_tid = DBuf<u32>(); seq_j = DBuf<u32>(); uinfo = DBuf<V16>();
+        Arena::device().rewind(walk_mark);
+        ent_val.alloc(n_ent);             // where the staging area began; `packed` lies behind the staging area's end (n_ent <= its size)
+        if (ent_val.ptr() != packed.ptr()) copy_d2d(ent_val.ptr(), packed.ptr(), n_ent * 4);
+    }
     launch(loc.n_seqs, PathEndsFunctor{ent_val.ptr(), path_off.ptr(), fs0.ptr(), fe0.ptr()});
     lap(&tm->paths);
 }
@@ -1306,7 +1353,8 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     lap(&tm->d2h);
     tm->total_device = now_s() - t_begin;
     if (getenv("AC_DEBUG_ARENA"))
-        fprintf(stderr, "arena: used %.1f MB of %.1f MB (n_text %.1f MB)\n", Arena::device().total_used() / 1e6, Arena::device().capacity() / 1e6, loc.n_text / 1e6);
+        fprintf(stderr, "arena: used %.1f MB (peak %.1f) of %.1f MB (n_text %.1f MB), %.3f s in hipMalloc / hipFree so far\n", Arena::device().total_used() / 1e6,
+                Arena::device().peak() / 1e6, Arena::device().capacity() / 1e6, loc.n_text / 1e6, Arena::device().alloc_seconds());
 }
 
 // The width-dependent stages behind one explicitly instantiated type per width.  The main unit only sees declarations, so it

@@ -209,6 +209,9 @@ int ac_unitigs_bulk(const ac_graph*, const uint8_t** seq_bytes, const uint64_t**
 int ac_paths_bulk(const ac_graph*, const int32_t** path_entries, const uint64_t** path_off /* ac_graph_seq_count() + 1 */,
                   uint64_t* n_entries);
 int ac_timings_get(const ac_graph*, ac_timings* out);
+/* ac_timings only ever grows at its end.  A client that may meet a newer or older library passes sizeof its own ac_timings: at most
+ * that many bytes are written, the library's sizeof(ac_timings) is returned. */
+size_t ac_timings_get_sized(const ac_graph*, ac_timings* out, size_t out_size);
 void ac_free(ac_graph*);
 
 /* The GFA text save_gfa would write (unitig_graph.rs:317-331): H, S*, L*, P* lines.  filenames/headers:

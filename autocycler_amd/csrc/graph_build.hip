@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <functional>
+#include <condition_variable>
 
 #include "device_rt.hpp"
 
@@ -367,9 +369,10 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 //   AC_FILL_NOVEL     0: novel list by a thread per bitmap word instead of the wavefront-cooperative kernel.
 //   AC_SEQ_BYTES      output bytes per thread of the plain sequence writers (16).
 //   AC_PACK_OVERLAP   0: K1 of the device entry in one launch (default: its tail under the first insert phase, cache-sized tables only).
-//   AC_UPLOAD_THREADS (16) / AC_HOST_PACK (1) / AC_UPLOAD_OVERLAP (1)   host entry: packing threads, 2-bit pack on the host, the
+//   AC_UPLOAD_THREADS (32) / AC_HOST_PACK (1) / AC_UPLOAD_OVERLAP (1)   host entry: packing threads, 2-bit pack on the host, the
 //                     insert issued chunk by chunk while background threads still pack and send the rest (0: everything is sent
 //                     before anything else is issued); AC_UPLOAD_CHUNK_MB (64; 16, 32, 128), AC_UPLOAD_SLOTS (tests: staging slots).
+//   AC_UPLOAD_MASK    1: the packed upload also sends the 1-bit mask plane (0.375 B per base instead of 0.25; default: MaskTableFunctor).
 //   AC_NO_MAILBOX     (read once) small read-backs through hipMemcpyAsync + synchronise instead of the mapped mailbox page.
 //   AC_INSERT_PROFILE (read once) per-wavefront cycle split of every insert launch on stderr (measurement).
 [[maybe_unused]] static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : -1; }      // -1 = automatic
@@ -409,7 +412,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); if (!e) return -1; int v = atoi(e); return v < 0 ? 0 : (v > 3 ? 3 : v); }      // -1 = automatic
 [[maybe_unused]] static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
 [[maybe_unused]] static u64 wave_chunk_rest() { const char* e = getenv("AC_INSERT_CHUNK_REST"); u64 x = e ? (u64)atoll(e) : 16384; return (std::max<u64>(x, 256) + 63) & ~63ULL; }   // longest chunk of the one-launch rest (r04c: 4096 / 8192 / 16384 = 0.90 / 0.84 / 0.82 ms)
-[[maybe_unused]] static u64 upload_threads() { const char* e = getenv("AC_UPLOAD_THREADS"); long x = e ? atol(e) : 16; return (u64)(x < 1 ? 1 : (x > 128 ? 128 : x)); }   // host threads laying out / packing the text (the byte upload uses at most 8)
+[[maybe_unused]] static u64 upload_threads() { const char* e = getenv("AC_UPLOAD_THREADS"); long x = e ? atol(e) : 32; return (u64)(x < 1 ? 1 : (x > 128 ? 128 : x)); }   // host threads laying out / packing the text (the byte upload uses at most 8)
 [[maybe_unused]] static bool host_pack() { const char* e = getenv("AC_HOST_PACK"); return e ? atoi(e) != 0 : true; }      // 0: upload the text as bytes and pack on the device
 [[maybe_unused]] static bool insert_profile() { static const bool v = getenv("AC_INSERT_PROFILE") != nullptr; return v; }      // measurement only
 [[maybe_unused]] static bool expand_rewrite_always() { return getenv("AC_EXPAND_REWRITE_ALWAYS") != nullptr; }      // tests: compact the expand pool after every host check
@@ -421,6 +424,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 #endif
 [[maybe_unused]] static bool seq_writer_forced() { const char* e = getenv("AC_SEQ_WRITER"); return e && atoi(e) == 1; }    // 1 = always the indexed / LDS-tiled writers
 [[maybe_unused]] static u64 seed_radix_limit() { const char* e = getenv("AC_SEED_RADIX_LIMIT"); return e ? (u64)atoll(e) : (1u << 19); }      // unitigs from which the seed order is a radix sort
+[[maybe_unused]] static bool upload_mask() { const char* e = getenv("AC_UPLOAD_MASK"); return e && atoi(e) != 0; }      // 1: the host entry sends the mask plane too (default: the device derives it from the sequence table)
 [[maybe_unused]] static bool upload_overlap() { const char* e = getenv("AC_UPLOAD_OVERLAP"); return e ? atoi(e) != 0 : true; }      // host entry: first insert phases while the upload's tail is in flight
 [[maybe_unused]] static bool insert_adaptive() { const char* e = getenv("AC_INSERT_ADAPT"); return e ? atoi(e) != 0 : true; }
 [[maybe_unused]] static u64 insert_growth() { const char* e = getenv("AC_INSERT_GROWTH"); long x = e ? atol(e) : 2; return (u64)(x < 2 ? 2 : x); }      // phase i+1 ends at growth x the end of phase i
@@ -540,12 +544,12 @@ struct GraphBuilder::Impl {
         std::vector<uint64_t> off;
         uint32_t k = 0; u64 n = 0, CH = 0, SUB = 0, n_chunks = 0, slot_bytes = 0; int NSLOT = 0, dev = 0;
         hipStream_t up = nullptr, pk = nullptr;
-        u64* d_bits = nullptr; u32* d_mask = nullptr;
+        u64* d_bits = nullptr; u32* d_mask = nullptr; bool send_mask = false;
         std::atomic<u64> next{0}, nonbase{0}; u64 expected_nonbase = 0;      // alphabet check: non-base bytes the packers met / the sequence table promises
         std::vector<std::atomic<u32>> done, slot_state, issued;      // slot_state: 0 untouched, 1 someone is waiting for the slot, 2 free
         std::vector<hipEvent_t> landed;                               // per chunk: both of its copies are on the device
         std::mutex hip_mu; std::string fail; std::atomic<bool> stop{false};
-        std::vector<std::thread> pool;
+        u64 ticket = 0;                                               // UploadPool: which run of the pool this job is
         u64 next_wait = 0;                                            // chunks stream 0 already waits for
         void run();
 #endif
@@ -1420,6 +1424,52 @@ uint64_t GraphBuilder::n_bases() const { return impl_->loc.n_bases; }
 // is written chunk by chunk into a persistent ring of pinned staging slots by a few host threads (memcpy: 25 GB/s per thread,
 // 126 GB/s with eight), every filled slot goes out with one asynchronous copy on an upload stream, and K1 packs that chunk on the
 // same stream right behind its copy — the PCIe link never waits, and the build that follows finds bits / mask ready.
+// The packing threads of the host entry, kept between builds: starting 16-32 threads costs 0.5-0.9 ms per build (measured: the
+// calling thread only gets to the build when the last one is up), waking parked ones a few microseconds.
+#ifndef AC_EMU
+class UploadPool {
+  public:
+    static UploadPool& get() { static UploadPool p; return p; }
+    // Runs fn() on n threads; returns at once.  One run at a time (the C ABI serialises builds).
+    u64 start(int n, std::function<void()> fn) {
+        std::unique_lock<std::mutex> lock(mu_);
+        while ((int)threads_.size() < n) { const int idx = (int)threads_.size(); threads_.emplace_back([this, idx] { loop(idx); }); }
+        fn_ = std::move(fn); want_ = n; active_ = n; gen_++;
+        cv_.notify_all();
+        return gen_;
+    }
+    void wait(u64 ticket) {
+        std::unique_lock<std::mutex> lock(mu_);
+        done_cv_.wait(lock, [&] { return gen_ != ticket || active_ == 0; });
+    }
+    ~UploadPool() {
+        { std::unique_lock<std::mutex> lock(mu_); stop_ = true; cv_.notify_all(); }
+        for (auto& t : threads_) t.join();
+    }
+  private:
+    void loop(int idx) {
+        u64 seen = 0;
+        for (;;) {
+            std::function<void()> fn;
+            {
+                std::unique_lock<std::mutex> lock(mu_);
+                cv_.wait(lock, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                if (idx >= want_) continue;
+                fn = fn_;
+            }
+            fn();
+            std::unique_lock<std::mutex> lock(mu_);
+            if (--active_ == 0) done_cv_.notify_all();
+        }
+    }
+    std::mutex mu_; std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> threads_;
+    std::function<void()> fn_;
+    u64 gen_ = 0; int want_ = 0, active_ = 0; bool stop_ = false;
+};
+#endif
 class HostStager {
   public:
     static const size_t SLOT = (size_t)16 << 20;     // 16 MB per copy: the SDMA path reaches 55 GB/s from 16 MB up (1-4 MB: 25-37 GB/s)
@@ -1663,6 +1713,13 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
     }
     const u64 expected = loc.expected_nonbase + ((n + 31) / 32 * 32 - n);
     if (nonbase != expected) throw_bad_alphabet(seqs, k, expected, nonbase);
+    if (!upload_mask()) {      // what the device does instead of receiving the mask plane (MaskTableFunctor) must give the packed one
+        DBuf<u64> derived(loc.mask.size());
+        derived.fill_bytes(0xFF);
+        memset(derived.ptr(), 0, (size_t)((n + 63) / 64) * 8);
+        launch((u64)loc.n_seqs + 1, MaskTableFunctor{loc.seq_off.ptr(), loc.seq_len.ptr(), loc.seq_d1.ptr(), loc.seq_d2.ptr(), loc.n_seqs, (int)k, n, derived.ptr()});
+        if (memcmp(derived.ptr(), loc.mask.ptr(), loc.mask.size() * 8) != 0) throw DeviceError("internal error: the mask plane derived from the sequence table differs from the packed one");
+    }
 #else
     Impl::UploadJob* job = new Impl::UploadJob();
     impl_->job = job;
@@ -1675,6 +1732,11 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
     AC_HIP_CHECK(hipEventRecord(st.begin(), 0));
     AC_HIP_CHECK(hipStreamWaitEvent(job->pk, st.begin(), 0));
     loc.pack_alloc(job->pk);                               // zero codes / all-ones mask beyond the text (and under it, until the copies land)
+    job->send_mask = upload_mask();
+    if (!job->send_mask) {      // the mask plane from the sequence table, on the device (MaskTableFunctor): 0.25 instead of 0.375 bytes per base cross PCIe
+        AC_HIP_CHECK(hipMemsetAsync(loc.mask.ptr(), 0, (size_t)((n + 63) / 64) * 8, job->pk));
+        launch((u64)loc.n_seqs + 1, MaskTableFunctor{loc.seq_off.ptr(), loc.seq_len.ptr(), loc.seq_d1.ptr(), loc.seq_d2.ptr(), loc.n_seqs, (int)k, n, loc.mask.ptr()}, job->pk);
+    }
     AC_HIP_CHECK(hipEventRecord(st.copied(), job->pk));
     AC_HIP_CHECK(hipStreamWaitEvent(job->up, st.copied(), 0));
     job->d_bits = loc.bits.ptr(); job->d_mask = (u32*)loc.mask.ptr();
@@ -1684,7 +1746,7 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
     job->landed.assign(n_chunks, nullptr);
     for (auto& e : job->landed) AC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const int T = (int)std::max<u64>(1, std::min<u64>({(n + SUB - 1) / SUB, upload_threads(), (u64)std::max(1u, std::thread::hardware_concurrency())}));
-    for (int i = 0; i < T; i++) job->pool.emplace_back([job] { job->run(); });
+    job->ticket = UploadPool::get().start(T, [job] { job->run(); });
     // This thread goes on to the build: the insert waits for the chunks as it gets to them (Impl::need_text).  Without the overlap
     // (AC_UPLOAD_OVERLAP=0) everything is on the device before anything else is issued.
     if (!upload_overlap()) { impl_->need_text(n); impl_->finish_upload(); }
@@ -1726,10 +1788,12 @@ void GraphBuilder::Impl::UploadJob::run() {
                 std::lock_guard<std::mutex> lock(hip_mu);
                 // codes and mask bits of a chunk travel on two streams (two copy engines): the smaller copy no longer sits
                 // between two big ones on one queue.  The chunk has landed (and its slot is free again) when both have.
-                AC_HIP_CHECK(hipMemcpyAsync(d_mask + g0, slot_mask(sl), ng * 4, hipMemcpyHostToDevice, pk));
-                AC_HIP_CHECK(hipEventRecord(st.copied(), pk));
+                if (send_mask) {
+                    AC_HIP_CHECK(hipMemcpyAsync(d_mask + g0, slot_mask(sl), ng * 4, hipMemcpyHostToDevice, pk));
+                    AC_HIP_CHECK(hipEventRecord(st.copied(), pk));
+                }
                 AC_HIP_CHECK(hipMemcpyAsync(d_bits + g0, slot_bits(sl), ng * 8, hipMemcpyHostToDevice, up));
-                AC_HIP_CHECK(hipStreamWaitEvent(up, st.copied(), 0));
+                if (send_mask) AC_HIP_CHECK(hipStreamWaitEvent(up, st.copied(), 0));
                 AC_HIP_CHECK(hipEventRecord(landed[c], up));
                 issued[c].store(1, std::memory_order_release);
             }
@@ -1765,7 +1829,7 @@ void GraphBuilder::Impl::finish_upload() {
     if (!job) return;
     UploadJob* j = job;
     job = nullptr;
-    for (auto& t : j->pool) t.join();
+    UploadPool::get().wait(j->ticket);
     HostStager& st = HostStager::get();
     std::string fail = j->fail;
     if (fail.empty()) {

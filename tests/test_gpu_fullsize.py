@@ -214,7 +214,7 @@ def test_gfa_digest_equals_the_oracle(golden_name):
     assert base[0]["gfa_md5"] == golden["gfa_md5"]
 
 
-@pytest.mark.parametrize("variants", ["base", "AC_UPLOAD_OVERLAP=0", "AC_HOST_PACK=0", "AC_UPLOAD_THREADS=5", "AC_UPLOAD_SLOTS=2", "AC_UPLOAD_CHUNK_MB=16,AC_UPLOAD_SLOTS=3", "AC_UPLOAD_SLOTS=1,AC_UPLOAD_OVERLAP=0"])
+@pytest.mark.parametrize("variants", ["base", "AC_UPLOAD_MASK=1", "AC_UPLOAD_OVERLAP=0", "AC_HOST_PACK=0", "AC_UPLOAD_THREADS=5", "AC_UPLOAD_SLOTS=2", "AC_UPLOAD_CHUNK_MB=16,AC_UPLOAD_SLOTS=3", "AC_UPLOAD_SLOTS=1,AC_UPLOAD_OVERLAP=0"])
 def test_host_entry_full_size_digest(variants):
     """The HOST entry (ac_compress_build from pageable per-sequence buffers: host-side 2-bit pack, chunked upload through the pinned
     ring by background threads, the insert issued chunk by chunk as they land) on the whole config C — 487 MB of text, eight 64 MB

@@ -253,7 +253,15 @@ def test_bench_line_contract_single_rank_dry_run():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in j["cpu_baseline"], key
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 1
-    assert [o["kernel"] for o in j["roofline_other"]] == ["PathWalkFunctor", "expand_wave_kernel"]
+    assert [o["kernel"].split("<")[0] for o in j["roofline_other"]] == ["PathWalkFunctor", "expand_wave_kernel"]
+    # a fraction of the HBM peak from MEASURED bytes, a stated lower-bound model next to it, the binding ceiling by name
+    for r in [j["roofline"]] + j["roofline_other"]:
+        for key in ("needed_bytes", "needed_model", "frac_needed", "waste", "ceiling", "frac_source", "kernel_ms"):
+            assert key in r, key
+        assert r["needed_bytes"] > 0 and r["waste"] > 0 and r["traffic"] > 0 and "PMC" in r["frac_source"]
+        assert abs(r["frac"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 8e12) < 1e-9 * max(1.0, r["frac"])
+    assert j["roofline"]["ceiling"] is None or j["roofline"]["ceiling"]["name"] == "cas"
+    assert j["roofline"]["whole_path_equiv"]["B_per_bp"] == 49
     assert j["cpu_baseline_full_size"]["gfa_md5"] == "c28d41ea9e4784f5f1dd06da6b3eb587"
     assert "dry run" in j["data"]
     # the host-RAM -> host-RAM bracket of the same region (SURVEY.md 8d T_hot), timed in the same run through ac_compress_build

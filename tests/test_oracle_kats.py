@@ -287,3 +287,56 @@ def test_position_reserve_is_only_a_hint():
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip())
     assert outs[0] == outs[1] and len(outs[0]) == 32
+
+
+def test_input_assemblies_yaml_follows_the_struct_declarations(tmp_path):
+    """metrics.rs:65-107: serde_yaml writes a struct's fields in declaration order — InputAssemblyMetrics { input_assemblies_count,
+    input_assemblies_total_contigs, input_assemblies_total_length, compressed_unitig_count, compressed_unitig_total_length,
+    input_assembly_details: Vec<InputAssemblyDetails { filename, contigs: Vec<InputContigDetails { name, description, length }> }> } —
+    as block-style YAML (metrics.rs:256-260, serde_yaml 0.9: `- ` items at the parent key's indentation, nested mappings indented by
+    two).  The oracle's file for the five-file fixture is that, line for line; name / description are the contig header up to / after its
+    first space (sequence.rs:77-83).  Where the reference sources are at hand the field lists are re-read from them."""
+    import re
+    from pathlib import Path
+    import boundary_cases as B
+    src = tmp_path / "asm"
+    B.write_five_file_fixture(src)
+    (src / "f.fasta").write_text(">contig_7 length=75 circular=true\n" + FIXED["a"] + "\n>plain\n" + FIXED["b"] + "\n")
+    out = tmp_path / "o"
+    O.compress_dir(src, out, k=13)
+    lines = (out / "input_assemblies.yaml").read_text().splitlines()
+    top = ["input_assemblies_count", "input_assemblies_total_contigs", "input_assemblies_total_length", "compressed_unitig_count",
+           "compressed_unitig_total_length", "input_assembly_details"]
+    detail, contig = ["filename", "contigs"], ["name", "description", "length"]
+    ref = Path("/root/reference/src/metrics.rs")
+    if ref.exists():      # the declarations themselves (build container only)
+        text = ref.read_text()
+        fields = lambda name: re.findall(r"pub (\w+):", re.search(r"pub struct %s \{(.*?)\n\}" % name, text, re.S).group(1))
+        assert fields("InputAssemblyMetrics") == top and fields("InputAssemblyDetails") == detail and fields("InputContigDetails") == contig
+    assert [l.split(":")[0] for l in lines if not l.startswith((" ", "-"))] == top
+    assert lines[0] == "input_assemblies_count: 6" and lines[1] == "input_assemblies_total_contigs: 7"
+    assert lines[2] == "input_assemblies_total_length: %d" % (75 * 7) and lines[5] == "input_assembly_details:"
+    body = lines[6:]
+    files = [i for i, l in enumerate(body) if l.startswith("- filename: ")]
+    # (the path as find_all_assemblies produced it, misc.rs:65-96 -> InputAssemblyDetails::new, metrics.rs:82-87: directory included)
+    assert [body[i][len("- filename: "):] for i in files] == [str(src / f) for f in sorted(["a.fasta", "b.fna", "c.fa", "d.fasta.gz", "e.fna.gz", "f.fasta"])]
+    for i in files:
+        assert body[i + 1] == "  contigs:"
+        assert body[i + 2].startswith("  - name: ") and body[i + 3].startswith("    description: ") and body[i + 4] == "    length: 75"
+    j = files[-1]
+    assert body[j + 2] == "  - name: contig_7" and body[j + 3] == "    description: length=75 circular=true"
+    assert body[j + 5] == "  - name: plain" and body[j + 6] == "    description: ''"      # serde_yaml writes the empty string quoted
+
+
+def test_reference_binary_hook_skips_cleanly_without_cargo():
+    """tests/golden/check_against_rust.sh: with no Rust toolchain it says so and exits 0; with one it builds the
+    reference and diffs GFA and YAML of oracle and product against it."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    script = Path(__file__).resolve().parent / "golden" / "check_against_rust.sh"
+    out = subprocess.run(["bash", str(script)], capture_output=True, text=True, timeout=600)
+    if shutil.which("cargo") is None:
+        assert out.returncode == 0 and "no cargo" in out.stdout
+    else:
+        assert out.returncode == 0, out.stdout[-2000:]

@@ -50,7 +50,7 @@ class Timings(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
-EXPORTS = ["ac_compress_build", "ac_compress_build_device", "ac_pack_text", "ac_text_size", "ac_layout_text", "ac_kmer_count",
+EXPORTS = ["ac_compress_build", "ac_compress_build_multi", "ac_multi_info_get", "ac_compress_build_device", "ac_pack_text", "ac_text_size", "ac_layout_text", "ac_kmer_count",
            "ac_stats_pre", "ac_stats_post", "ac_unitig_count", "ac_unitig", "ac_unitigs_bulk", "ac_paths_bulk", "ac_unitig_positions", "ac_links",
            "ac_path", "ac_timings_get", "ac_timings_get_sized", "ac_free", "ac_gfa_string", "ac_string_free", "ac_last_error",
            "ac_device_count", "ac_max_kmer", "ac_version", "ac_set_stage_timing", "ac_random_access_ceilings", "ac_release_memory", "ac_end_repair_device", "ac_pairwise_distances", "ac_graph_from_gfa", "ac_graph_kmer_size", "ac_graph_seq_info", "ac_decompress_seq", "ac_decompress",
@@ -257,6 +257,37 @@ def graph_from_gfa(gfa_text, lib_path=None):
         _check(lib, lib.ac_graph_seq_info(h, C.c_uint32(i), None, None, C.byref(fn), C.byref(hd)))
         fns.append(fn.value.decode()); hds.append(hd.value.decode())
     return g, fns, hds
+
+
+class MultiInfo(C.Structure):
+    _fields_ = [("n_ranks", C.c_uint32), ("transport", C.c_int)] + \
+               [(n, C.c_uint64) for n in ("bytes_fragments", "bytes_bitmap", "bytes_degrees", "bytes_links", "bytes_queries", "bytes_answers",
+                                          "bytes_reduce", "queries_total", "queries_sent_away", "table_capacity_max", "table_capacity_sum",
+                                          "union_text_bytes", "fragments", "distinct")] + \
+               [("seconds_total", C.c_double), ("seconds_exchange_max", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def compress_build_multi(k, assembly_count, seqs, devices, lib_path=None):
+    """One job over several devices from this one process (ac_compress_build_multi).  seqs as for compress_build; devices: HIP
+    ordinals, one per rank (repeats allowed: host-staged exchanges).  Returns (Graph, multi-info dict)."""
+    lib = load_library(lib_path)
+    seqs = list(seqs)
+    arr = (SeqView * len(seqs))()
+    keep = []
+    for i, (fwd, length, sid) in enumerate(seqs):
+        b = bytes(fwd)
+        keep.append(b)
+        arr[i].fwd, arr[i].length, arr[i].id = b, length, sid
+    h = C.c_void_p()
+    dv = (C.c_int * len(devices))(*devices)
+    _check(lib, lib.ac_compress_build_multi(C.c_uint32(k), C.c_uint32(assembly_count), arr, C.c_uint32(len(seqs)), dv, C.c_int(len(devices)),
+                                            C.byref(h)))
+    info = MultiInfo()
+    _check(lib, lib.ac_multi_info_get(h, C.byref(info)))
+    return Graph(lib, h, len(seqs)), info.as_dict()
 
 
 def compress_build(k, assembly_count, seqs, device=0, lib_path=None):

@@ -24,6 +24,7 @@
 #include <cerrno>
 #include <unistd.h>
 #include "device_rt.hpp"
+#include "multi_build.hpp"
 
 using namespace ac;
 
@@ -34,6 +35,7 @@ static int g_live_shards = 0;      // a live sharded build owns the arenas betwe
 struct ac_graph {
     FinalGraph g;
     BuildTimings tm;
+    MultiStats multi;          // n_ranks == 0: not built by ac_compress_build_multi
     std::vector<uint16_t> seq_ids;
     std::vector<uint32_t> seq_lens;
     bool positions_built = false;
@@ -74,7 +76,7 @@ static void select_device(int device) {
     // The device arena is one process-wide bump allocator: its blocks live on the device they were allocated on.  A call that
     // names another ordinal gives them back first (a build never runs on HBM of another device), together with everything else
     // that is tied to the previous device's memory.  One build at a time per process (g_build_mutex), so nothing is in flight.
-    static int arena_device = -1;
+    int& arena_device = device_ctx().arena_device;      // (per context: the threads of a multi-device build each have their own)
     if (arena_device != device) {
         if (arena_device >= 0) {
             if (g_live_shards) throw DeviceError("a sharded build is in flight on device " + std::to_string(arena_device) + ": this process cannot use device " + std::to_string(device) + " until it is freed");
@@ -86,6 +88,8 @@ static void select_device(int device) {
         arena_device = device;
     }
 }
+
+namespace ac { void select_device_checked(int device) { select_device(device); } }
 
 static void validate(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs) {
     if (!seqs || n_seqs == 0) throw DeviceError("no sequences found in input assemblies");
@@ -172,6 +176,7 @@ int ac_release_memory(void) {
         std::lock_guard<std::mutex> lock(g_build_mutex);
         if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
         Arena::device().release_all();
+        release_multi_contexts();
         PinnedPool::get().trim();
         release_host_stager();
 #ifndef AC_EMU
@@ -233,6 +238,42 @@ int ac_compress_build(uint32_t k, uint32_t assembly_count, const ac_seq_view* se
         build_graph(b, assembly_count, h.get());
         *out = h.release();
     });
+}
+
+// compress.rs:42-44 over several devices of one node: one call, one process, the same graph.
+int ac_compress_build_multi(uint32_t k, uint32_t assembly_count, const ac_seq_view* seqs, uint32_t n_seqs, const int* devices, int n_devices,
+                            ac_graph** out) {
+    return guarded([&] {
+        validate(k, seqs, n_seqs);
+        if (!devices || n_devices < 1) throw DeviceError("ac_compress_build_multi: no devices");
+        if (n_devices > 64) throw DeviceError("ac_compress_build_multi: more than 64 devices");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
+        auto h = std::make_unique<ac_graph>();
+        std::vector<SeqView> v(n_seqs);
+        for (uint32_t i = 0; i < n_seqs; i++) {
+            v[i] = SeqView{seqs[i].fwd, seqs[i].length};
+            h->seq_ids.push_back(seqs[i].id);
+            h->seq_lens.push_back(seqs[i].length);
+        }
+        int transport = MULTI_AUTO;
+        if (const char* e = getenv("AC_MULTI_TRANSPORT")) transport = !strcmp(e, "host") ? MULTI_HOST_STAGED : (!strcmp(e, "rccl") ? MULTI_RCCL : MULTI_AUTO);
+        build_multi(k, assembly_count, v, std::vector<int>(devices, devices + n_devices), transport, &h->g, &h->tm, &h->multi);
+        *out = h.release();
+    });
+}
+int ac_multi_info_get(const ac_graph* g, ac_multi_info* o) {
+    if (!g || !o) { g_err = "null pointer"; return 1; }
+    const MultiStats& m = g->multi;
+    memset(o, 0, sizeof *o);
+    o->n_ranks = m.n_ranks; o->transport = m.transport;
+    o->bytes_fragments = m.bytes_fragments; o->bytes_bitmap = m.bytes_bitmap; o->bytes_degrees = m.bytes_degrees; o->bytes_links = m.bytes_links;
+    o->bytes_queries = m.bytes_queries; o->bytes_answers = m.bytes_answers; o->bytes_reduce = m.bytes_reduce;
+    o->queries_total = m.queries_total; o->queries_sent_away = m.queries_sent_away;
+    o->table_capacity_max = m.table_capacity_max; o->table_capacity_sum = m.table_capacity_sum;
+    o->union_text_bytes = m.union_text_bytes; o->fragments = m.fragments; o->distinct = m.distinct;
+    o->seconds_total = m.seconds_total; o->seconds_exchange_max = m.seconds_exchange_max;
+    return 0;
 }
 
 int ac_compress_build_device(uint32_t k, uint32_t assembly_count, const void* d_text, uint64_t n_text,

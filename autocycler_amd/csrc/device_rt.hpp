@@ -67,6 +67,34 @@ __device__ inline void atomic_min32(u32* p, u32 v) { atomicMin(p, v); }
 __device__ inline void atomic_max32(u32* p, u32 v) { atomicMax(p, v); }
 #endif
 
+// ---- device context ------------------------------------------------------------------------------------------------------------
+// Everything a build keeps between its stages and between builds — the device arena, the fill queue, the read-back mailbox, the side
+// stream, the upload ring and its packing threads — lives in a DeviceCtx.  A thread that has not been given one uses the process-wide
+// context (the single-device entries: one build at a time, whatever thread calls).  ac_compress_build_multi runs one host thread per
+// device and gives each of them a context of its own (set_device_ctx), so that N builds drive N devices side by side.
+struct DeviceCtx {
+    static const int SLOTS = 8;
+    void* obj[SLOTS] = {}; void (*del[SLOTS])(void*) = {};
+    int arena_device = -1;      // the device the arena's blocks live on
+    DeviceCtx() {}
+    DeviceCtx(const DeviceCtx&) = delete;
+    DeviceCtx& operator=(const DeviceCtx&) = delete;
+    ~DeviceCtx() { for (int i = SLOTS; i-- > 0;) if (obj[i]) del[i](obj[i]); }
+};
+inline DeviceCtx*& tl_device_ctx() { static thread_local DeviceCtx* p = nullptr; return p; }
+inline DeviceCtx& device_ctx() {      // (the process-wide one is never destroyed: at exit the HIP runtime may be gone before the statics)
+    static DeviceCtx* const process_wide = new DeviceCtx;
+    DeviceCtx* p = tl_device_ctx();
+    return p ? *p : *process_wide;
+}
+inline void set_device_ctx(DeviceCtx* c) { tl_device_ctx() = c; }      // nullptr: back to the process-wide context
+enum { CTX_ARENA = 0, CTX_FILLS, CTX_MAILBOX, CTX_SIDE, CTX_SCRATCH, CTX_STAGER, CTX_POOL };
+template <class T> T& ctx_object(int slot) {
+    DeviceCtx& c = device_ctx();
+    if (!c.obj[slot]) { c.obj[slot] = new T(); c.del[slot] = [](void* p) { delete (T*)p; }; }
+    return *(T*)c.obj[slot];
+}
+
 // ---- buffers --------------------------------------------------------------------------------------
 // Device memory comes from a persistent bump arena (one per process, on the device selected by the C ABI):
 // a build makes ~40 allocations, and hipMalloc/hipFree (the latter synchronises the device) would cost more
@@ -75,7 +103,9 @@ __device__ inline void atomic_max32(u32* p, u32 v) { atomicMax(p, v); }
 // (ac_release_memory() in the C ABI frees it).
 class Arena {
   public:
-    static Arena& device() { static Arena a(false); return a; }
+    static Arena& device() { return ctx_object<Arena>(CTX_ARENA); }
+    Arena() : host_(false) {}
+    ~Arena() { for (auto& b : blocks_) raw_free(b.p); }
     static const size_t COALESCE_LIMIT = (size_t)16 << 30;
     void* alloc(size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255;
@@ -145,7 +175,6 @@ class Arena {
 
   private:
     struct Block { void* p; size_t cap, used; };
-    explicit Arena(bool host) : host_(host) {}
     void on_reset();      // (defined after FillQueue)
     void on_rewind();
     static double wall() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
@@ -281,7 +310,8 @@ template <int UNUSED> __global__ void __launch_bounds__(256) fill_many_kernel(Fi
 }
 class FillQueue {
   public:
-    static FillQueue& get() { static FillQueue q; return q; }
+    static FillQueue& get() { return ctx_object<FillQueue>(CTX_FILLS); }
+    FillQueue() {}
     void add(void* p, size_t bytes, int byte) {
         if (n_ == FILL_MAX) flush();
         const u32 b = (u32)(byte & 0xFF);
@@ -302,7 +332,6 @@ class FillQueue {
     }
     void drop() { n_ = 0; }      // the arena was reset: whatever was queued points at dead buffers
   private:
-    FillQueue() {}
     FillArgs a_;
     int n_ = 0;
 };
@@ -374,8 +403,10 @@ inline void* pinned_scratch(size_t bytes) {
 #ifdef AC_EMU
     (void)bytes; return nullptr;
 #else
-    static void* p = nullptr;
-    static size_t cap = 0;
+    struct Scratch { void* p = nullptr; size_t cap = 0; ~Scratch() { if (p) (void)hipHostFree(p); } };
+    Scratch& sc = ctx_object<Scratch>(CTX_SCRATCH);
+    void*& p = sc.p;
+    size_t& cap = sc.cap;
     if (bytes > cap) {
         if (p) (void)hipHostFree(p);
         cap = std::max<size_t>(bytes, 64 << 10);
@@ -410,7 +441,9 @@ template <int UNUSED> __global__ void __launch_bounds__(256) mailbox_publish_ker
 class Mailbox {
   public:
     static const size_t CAP = (size_t)64 << 10;      // payload bytes
-    static Mailbox& get() { static Mailbox m; return m; }
+    static Mailbox& get() { return ctx_object<Mailbox>(CTX_MAILBOX); }
+    Mailbox() {}
+    ~Mailbox() { release(); }
     // Copies the items (device -> host) behind everything enqueued on stream `s` so far and waits for them.
     void fetch(const MailItem* items, void* const* host_dst, int n, stream_t s) {
         ensure();
@@ -442,7 +475,6 @@ class Mailbox {
         h_ = nullptr; d_ = nullptr;
     }
   private:
-    Mailbox() {}
     void ensure() {      // the page and its device-side address belong to the device that was current when it was mapped
         int dev = 0;
         AC_HIP_CHECK(hipGetDevice(&dev));
@@ -553,7 +585,9 @@ template <class T> T read_scalar(const T* dptr, stream_t s = 0) {
 // synchronisation with stream 0; ordering is by events.
 class SideStream {
   public:
-    static SideStream& get() { static SideStream s; return s; }
+    static SideStream& get() { return ctx_object<SideStream>(CTX_SIDE); }
+    SideStream() {}
+    ~SideStream() { destroy(); }
     stream_t stream() {
 #ifndef AC_EMU
         int dev = 0;
@@ -598,7 +632,6 @@ class SideStream {
     struct Guard { ~Guard() { SideStream::get().sync(); } };   // no copy may outlive the scope that owns its destination
 
   private:
-    SideStream() {}
     void destroy() {
 #ifndef AC_EMU
         if (created_) { (void)hipStreamDestroy(s_); for (auto& e : ev_) (void)hipEventDestroy(e); created_ = false; }

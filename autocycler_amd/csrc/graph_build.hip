@@ -442,6 +442,7 @@ struct PackedText {
     // alphabet check of K1 (pack_check, sequence.rs:39-41): [0] = smallest (sequence index + 1) holding an illegal byte, [1] = number of
     // non-base bytes - 1 (both start as all-ones); expected_nonbase = padding dots + separators the sequence table promises
     DBuf<u32> pack_bad; bool check_alphabet = false; int k = 0; u64 expected_nonbase = 0;
+    u64 index_base = 0;      // sequences of the job in front of this text's first one (a rank of a multi-device build): for messages
     PackCheck chk() const { return PackCheck{seq_off.ptr(), seq_len.ptr(), seq_d1.ptr(), seq_d2.ptr(), n_seqs, k, check_alphabet ? const_cast<u32*>(pack_bad.ptr()) : nullptr}; }
     std::vector<u64> h_off; std::vector<u32> h_len;
     void set_table(const std::vector<uint64_t>& off, const std::vector<uint32_t>& len, const std::vector<uint16_t>& d1,
@@ -472,7 +473,7 @@ struct PackedText {
     // anything but A, C, G, T between its padding dots (sequence.rs:39-41).
     void verify_alphabet(const u32* bad) const {
         if (!check_alphabet) return;
-        if (bad[0] != 0xFFFFFFFFu) throw DeviceError("input sequence " + std::to_string(bad[0]) + " contains non-ACGT characters");
+        if (bad[0] != 0xFFFFFFFFu) throw DeviceError("input sequence " + std::to_string(index_base + bad[0]) + " contains non-ACGT characters");
         const u64 found = (u64)(u32)(bad[1] + 1u);
         if (found != (expected_nonbase & 0xFFFFFFFFULL))
             throw DeviceError("the text does not match its sequence table: " + std::to_string(expected_nonbase) + " padding dots and separators expected, " +
@@ -550,6 +551,7 @@ struct GraphBuilder::Impl {
         std::vector<hipEvent_t> landed;                               // per chunk: both of its copies are on the device
         std::mutex hip_mu; std::string fail; std::atomic<bool> stop{false};
         u64 ticket = 0;                                               // UploadPool: which run of the pool this job is
+        void* stager = nullptr;                                       // the HostStager of the context that started the job (the pool's threads have no context of their own)
         u64 next_wait = 0;                                            // chunks stream 0 already waits for
         void run();
 #endif
@@ -593,6 +595,9 @@ struct GraphBuilder::Impl {
     template <int W> void walk_queries();               // sharded: the keys this rank's walkers start from
     template <int W> void answer_queries(const u64* d_keys, u64 n, u64* d_out);   // sharded: the owned ones, looked up in this rank's table
     DBuf<u64> qkeys; u64 n_queries = 0;
+    DBuf<u32> qidx;                                     // routed position -> query (queries_route)
+    DBuf<u64> qanswers;                                 // the answers in query order (answers_unroute)
+    template <int W> void route_queries(u32 n_shards, u64* d_routed_keys, u64* counts_host);
     const u64* walk_answers = nullptr;                  // sharded: [n_walkers | n_seqs] answers (0 = not found), nullptr = look the table up
     template <int W> void unitigs();                    // K6..K11 on G
     template <int W> void walk();
@@ -620,7 +625,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
     c <<= shift;
     // the capacity the previous build of a text of this very size ended with (a process that builds the same job again, or a
     // stream of similar jobs, does not pay for the overflow retries twice)
-    static u64 memo_n_text = 0, memo_cap = 0; static u32 memo_k = 0; static int memo_shift = -2;      // (a capacity is a number, not memory: valid on any device)
+    static thread_local u64 memo_n_text = 0, memo_cap = 0; static thread_local u32 memo_k = 0; static thread_local int memo_shift = -2;      // (a capacity is a number, not memory: valid on any device)
     if (pt.n_text == memo_n_text && k == memo_k && memo_shift == table_shift() && memo_cap > c) c = memo_cap;
     DBuf<InsertStats> istats(257);       // [256].real doubles as the kernel's error word: one D2H reads everything
     DBuf<u64> sl;
@@ -796,7 +801,7 @@ template <int W> void GraphBuilder::Impl::fragments() {
     exclusive_scan_u64(blen.ptr(), boff.ptr(), n_frags + 1);
     frag_bytes = read_scalar(boff.ptr() + n_frags);
     frag_text.alloc(frag_bytes);
-    launch((frag_bytes + 63) / 64, FragCopyFunctor{loc.d_text, fpos.ptr(), boff.ptr(), n_frags, frag_bytes, frag_text.ptr()});
+    launch((frag_bytes + 63) / 64, FragCopyFunctor{loc.bits.ptr(), loc.mask.ptr(), fpos.ptr(), boff.ptr(), n_frags, frag_bytes, frag_text.ptr()});
     {
         u32 frag_err = 0, pack_bad[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
         ReadBatch rb;
@@ -1033,6 +1038,17 @@ template <int W> void GraphBuilder::Impl::walk_queries() {
     n_queries = n_walkers + loc.n_seqs;
     qkeys.alloc(n_queries * W);
     launch(n_queries, WalkQueryFunctor<W>{loc.ctx((int)k), PC, n_walkers, qkeys.ptr()});
+}
+// The queries in owner order (stable): d_routed_keys[i] = key of query qidx[i]; counts_host[o] = how many go to owner o.
+template <int W> void GraphBuilder::Impl::route_queries(u32 n_shards, u64* d_routed_keys, u64* counts_host) {
+    DBuf<u64> owner64(n_queries), counts(n_shards, true);
+    qidx.alloc(n_queries);
+    launch(n_queries, QueryOwnerFunctor<W>{qkeys.ptr(), (int)k, n_shards, my_owner, owner64.ptr(), qidx.ptr(), counts.ptr()});
+    int bits = 1;
+    while ((1u << bits) < n_shards) bits++;
+    sort_pairs_u64_u32(owner64, qidx, n_queries, bits);
+    launch(n_queries, QueryGatherFunctor<W>{qkeys.ptr(), qidx.ptr(), d_routed_keys});
+    copy_d2h(counts_host, counts.ptr(), (size_t)n_shards * 8);
 }
 template <int W> void GraphBuilder::Impl::answer_queries(const u64* d_keys, u64 n, u64* d_out) {
     launch(n, AnswerFunctor<W>{G->ctx((int)k), graph_table(), d_keys, d_out});
@@ -1368,6 +1384,7 @@ template <int W> struct Stages {
     static void degrees(GraphBuilder::Impl& m);
     static void walk_queries(GraphBuilder::Impl& m);
     static void answer_queries(GraphBuilder::Impl& m, const u64* d_keys, u64 n, u64* d_out);
+    static void route_queries(GraphBuilder::Impl& m, u32 n_shards, u64* d_routed_keys, u64* counts_host);
     static void unitigs(GraphBuilder::Impl& m);
     static void walk(GraphBuilder::Impl& m);
     static void tail(GraphBuilder::Impl& m, FinalGraph* out, bool want_graph, bool want_paths);
@@ -1378,6 +1395,7 @@ template <int W> void Stages<W>::table(GraphBuilder::Impl& m) { m.template table
 template <int W> void Stages<W>::degrees(GraphBuilder::Impl& m) { m.template degrees<W>(); }
 template <int W> void Stages<W>::walk_queries(GraphBuilder::Impl& m) { m.template walk_queries<W>(); }
 template <int W> void Stages<W>::answer_queries(GraphBuilder::Impl& m, const u64* d_keys, u64 n, u64* d_out) { m.template answer_queries<W>(d_keys, n, d_out); }
+template <int W> void Stages<W>::route_queries(GraphBuilder::Impl& m, u32 n_shards, u64* d_routed_keys, u64* counts_host) { m.template route_queries<W>(n_shards, d_routed_keys, counts_host); }
 template <int W> void Stages<W>::unitigs(GraphBuilder::Impl& m) { m.template unitigs<W>(); }
 template <int W> void Stages<W>::walk(GraphBuilder::Impl& m) { m.template walk<W>(); }
 template <int W> void Stages<W>::tail(GraphBuilder::Impl& m, FinalGraph* out, bool want_graph, bool want_paths) { m.template tail<W>(out, want_graph, want_paths); }
@@ -1415,6 +1433,7 @@ GraphBuilder::GraphBuilder(uint32_t k) : impl_(new Impl) {
 }
 GraphBuilder::~GraphBuilder() { delete impl_; }
 uint64_t GraphBuilder::n_text() const { return impl_->loc.n_text; }
+void GraphBuilder::set_sequence_index_base(uint64_t n) { impl_->loc.index_base = n; }
 uint64_t GraphBuilder::n_bases() const { return impl_->loc.n_bases; }
 
 // ---- host entry: sequences in the caller's (pageable) memory -> text + packed text in HBM ----------------------------------
@@ -1429,7 +1448,8 @@ uint64_t GraphBuilder::n_bases() const { return impl_->loc.n_bases; }
 #ifndef AC_EMU
 class UploadPool {
   public:
-    static UploadPool& get() { static UploadPool p; return p; }
+    static UploadPool& get() { return ctx_object<UploadPool>(CTX_POOL); }
+    UploadPool() {}
     // Runs fn() on n threads; returns at once.  One run at a time (the C ABI serialises builds).
     u64 start(int n, std::function<void()> fn) {
         std::unique_lock<std::mutex> lock(mu_);
@@ -1474,7 +1494,9 @@ class HostStager {
   public:
     static const size_t SLOT = (size_t)16 << 20;     // 16 MB per copy: the SDMA path reaches 55 GB/s from 16 MB up (1-4 MB: 25-37 GB/s)
     static const int NS = 12;
-    static HostStager& get() { static HostStager s; return s; }
+    static HostStager& get() { return ctx_object<HostStager>(CTX_STAGER); }
+    HostStager() {}
+    ~HostStager() { release(); }
     void ensure() {
 #ifndef AC_EMU
         int dev = 0;
@@ -1521,7 +1543,6 @@ class HostStager {
     stream_t stream() { return 0; }
 #endif
   private:
-    HostStager() {}
     u8* ring_ = nullptr;
     bool created_ = false;
     int dev_ = -1;
@@ -1674,7 +1695,7 @@ static u64 pack_text_groups(const std::vector<SeqView>& seqs, const std::vector<
     return nonbase;
 }
 // The host entry's alphabet check failed: name the first sequence that holds anything but A, C, G, T between its padding dots.
-[[maybe_unused]] static void throw_bad_alphabet(const std::vector<SeqView>& seqs, uint32_t k, u64 expected, u64 found) {
+[[maybe_unused]] static void throw_bad_alphabet(const std::vector<SeqView>& seqs, uint32_t k, u64 expected, u64 found, u64 index_base = 0) {
     for (size_t i = 0; i < seqs.size(); i++) {
         const u64 plen = (u64)seqs[i].length + k - 1;
         u64 a = 0, b = 0;
@@ -1682,7 +1703,7 @@ static u64 pack_text_groups(const std::vector<SeqView>& seqs, const std::vector<
         while (b < plen - a && seqs[i].fwd[plen - 1 - b] == '.') b++;
         for (u64 j = a; j < plen - b; j++) {
             const u8 c = seqs[i].fwd[j];
-            if (c != 'A' && c != 'C' && c != 'G' && c != 'T') throw DeviceError("input sequence " + std::to_string(i + 1) + " contains non-ACGT characters");
+            if (c != 'A' && c != 'C' && c != 'G' && c != 'T') throw DeviceError("input sequence " + std::to_string(index_base + i + 1) + " contains non-ACGT characters");
         }
     }
     throw DeviceError("internal error: the packed text holds " + std::to_string(found) + " non-base positions, " + std::to_string(expected) + " expected");
@@ -1712,7 +1733,7 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
         nonbase += pack_text_groups(seqs, off, k, n, b / 32, (e + 31) / 32, loc.bits.ptr() + b / 32, (u32*)loc.mask.ptr() + b / 32);
     }
     const u64 expected = loc.expected_nonbase + ((n + 31) / 32 * 32 - n);
-    if (nonbase != expected) throw_bad_alphabet(seqs, k, expected, nonbase);
+    if (nonbase != expected) throw_bad_alphabet(seqs, k, expected, nonbase, loc.index_base);
     if (!upload_mask()) {      // what the device does instead of receiving the mask plane (MaskTableFunctor) must give the packed one
         DBuf<u64> derived(loc.mask.size());
         derived.fill_bytes(0xFF);
@@ -1725,6 +1746,7 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
     impl_->job = job;
     job->seqs = &seqs; job->off = off; job->k = k; job->n = n; job->CH = CH; job->SUB = SUB; job->NSLOT = NSLOT; job->n_chunks = n_chunks;
     job->slot_bytes = SLOT_BYTES;
+    job->stager = &st;
     job->expected_nonbase = loc.expected_nonbase + ((n + 31) / 32 * 32 - n);
     AC_HIP_CHECK(hipGetDevice(&job->dev));
     job->up = st.stream(); job->pk = st.pack_stream();
@@ -1756,7 +1778,7 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
 
 #ifndef AC_EMU
 void GraphBuilder::Impl::UploadJob::run() {
-    HostStager& st = HostStager::get();
+    HostStager& st = *(HostStager*)stager;
     const u64 subs = CH / SUB;
     auto chunk_len = [&](u64 c) { return std::min(n, (c + 1) * CH) - c * CH; };
     auto slot_bits = [&](int sl) { return (u64*)(st.slot(0) + (u64)sl * slot_bytes); };
@@ -1837,7 +1859,7 @@ void GraphBuilder::Impl::finish_upload() {
         st.timed = true;
     } else { (void)hipStreamSynchronize(j->up); (void)hipStreamSynchronize(j->pk); }
     if (fail.empty() && !j->stop.load() && j->nonbase.load() != j->expected_nonbase) {      // sequence.rs:39-41 (every chunk was packed: nobody stopped)
-        try { throw_bad_alphabet(*j->seqs, j->k, j->expected_nonbase, j->nonbase.load()); } catch (const std::exception& ex) { fail = ex.what(); }
+        try { throw_bad_alphabet(*j->seqs, j->k, j->expected_nonbase, j->nonbase.load(), loc.index_base); } catch (const std::exception& ex) { fail = ex.what(); }
     }
     for (auto& e : j->landed) if (e) (void)hipEventDestroy(e);      // (a destroyed event that a stream still waits for stays valid until then)
     delete j;
@@ -2115,6 +2137,17 @@ void GraphBuilder::queries_export(void* d_out) {
 void GraphBuilder::answer_queries(const void* d_keys, uint64_t n, void* d_out) {
     AC_DISPATCH_W(answer_queries, (*impl_, (const u64*)d_keys, n, (u64*)d_out))
     stream_sync();
+}
+void GraphBuilder::queries_route(uint32_t n_shards, void* d_routed_keys, uint64_t* counts_host) {
+    if (n_shards == 0 || n_shards != impl_->n_owners) throw DeviceError("queries_route: shard count mismatch");
+    AC_DISPATCH_W(route_queries, (*impl_, n_shards, (u64*)d_routed_keys, counts_host))
+}
+void GraphBuilder::shard_walk_routed(const void* d_routed_answers) {      // answers in the order queries_route sent the keys
+    Impl& m = *impl_;
+    if (!m.qidx.size() && m.n_queries) throw DeviceError("shard_walk_routed: queries_route has not run");
+    m.qanswers.alloc(m.n_queries);
+    launch(m.n_queries, AnswerScatterFunctor{(const u64*)d_routed_answers, m.qidx.ptr(), m.qanswers.ptr()});
+    shard_walk(m.qanswers.ptr());
 }
 void GraphBuilder::shard_walk(const void* d_answers_mine) {
     Impl& m = *impl_;

@@ -102,12 +102,17 @@ class GraphBuilder {
     void queries_export(void* d_out);
     void answer_queries(const void* d_keys, uint64_t n, void* d_out);   // n keys of any ranks -> n u64 (0 where this rank does not own the key)
     void shard_walk(const void* d_answers_mine);                    // query_count() u64
+    // The same exchange routed by owner (one all-to-all each way instead of all-gather + SUM): the queries in owner order (stable),
+    // counts_host[o] = how many of them rank o's table answers; the owners' answers come back in that order.
+    void queries_route(uint32_t n_shards, void* d_routed_keys, uint64_t* counts_host);
+    void shard_walk_routed(const void* d_routed_answers);
     void reduce_export(int32_t* d_sum, int32_t* d_min);             // 3U and 2U int32
     void reduce_import(const int32_t* d_sum, const int32_t* d_min);
     void shard_finish(FinalGraph* out, bool want_graph, bool want_paths);
     uint64_t path_entry_count() const;
     void paths_export(void* d_out);                                 // int32 per entry, final numbers
     const BuildTimings& timings() const { return tm_; }
+    void set_sequence_index_base(uint64_t n);   // a rank of a multi-device build: how many sequences of the job precede its slice (error messages)
     uint64_t n_text() const;
     uint64_t n_bases() const;   // sum of unpadded lengths
 

@@ -70,6 +70,26 @@ typedef struct {
 int ac_compress_build(uint32_t k, uint32_t assembly_count, const ac_seq_view* seqs, uint32_t n_seqs, int device,
                       ac_graph** out);
 
+/* The same over SEVERAL devices of one node, still one call from one process: devices[r] = HIP ordinal of rank r.  The
+ * library runs one host thread per device; the sequences are sharded by rank (contiguous slices balanced by bases), the k-mer table is
+ * partitioned over the ranks by key hash, and the exchanges between the phases of the build happen inside the library: RCCL over xGMI
+ * (ncclAllReduce, and grouped ncclSend / ncclRecv that route every walk-start key to the one rank that owns it), loaded on first use.  A
+ * device may be named more than once (those ranks then share it and the exchanges are staged through host memory: tests and dry runs);
+ * AC_MULTI_TRANSPORT=host|rccl overrides the choice.  The graph is the one ac_compress_build builds (byte-identical GFA); n_devices = 1
+ * is allowed.  Rust: the shim of INTEGRATION.md passes the ordinals it wants instead of one `device`. */
+int ac_compress_build_multi(uint32_t k, uint32_t assembly_count, const ac_seq_view* seqs, uint32_t n_seqs, const int* devices,
+                            int n_devices, ac_graph** out);
+/* What the multi-device build behind a graph moved between its ranks (n_ranks = 0: a single-device build). */
+typedef struct {
+    uint32_t n_ranks; int transport;   /* transport: 1 = staged through host memory, 2 = RCCL */
+    uint64_t bytes_fragments, bytes_bitmap, bytes_degrees, bytes_links, bytes_queries, bytes_answers, bytes_reduce;   /* received, all ranks */
+    uint64_t queries_total, queries_sent_away;        /* walk-start queries of all ranks / those another rank answered */
+    uint64_t table_capacity_max, table_capacity_sum;  /* slots of the ranks' shares of the job's k-mer table */
+    uint64_t union_text_bytes, fragments, distinct;
+    double seconds_total, seconds_exchange_max;
+} ac_multi_info;
+int ac_multi_info_get(const ac_graph*, ac_multi_info* out);
+
 /* The 2-bit packing the host entry applies before the upload (sequence.rs:39-48 validates the same alphabet): n_text bytes ->
  * (n_text + 31) / 32 words of 2-bit codes (A, C, G, T = 0..3, first base most significant) and as many 32-bit mask words
  * (bit i = byte i is not a base).  force_scalar != 0 selects the portable loop instead of the AVX2 / BMI2 one (both are

@@ -1,0 +1,77 @@
+"""ac_compress_build_multi on the MI355X box (one GPU): the in-library RCCL path in a world of one rank (ncclCommInitAll, ncclAllReduce on
+uint8 / int32 / int64 / uint64, grouped ncclSend / ncclRecv to itself: every call the N-rank build issues), and 2, 3 and 4 ranks sharing
+the one device over the host-staged transport (a thread, a device context, an arena and a k-mer table share per rank) — byte for byte
+against the oracle; BASELINE configs[1] over two ranks against its golden digest."""
+import hashlib
+import json
+import os
+from pathlib import Path
+
+import pytest
+
+import multi_cases as M
+from test_oracle_kats import FIXED
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import autocycler_amd
+    lib = autocycler_amd.load_library()
+    assert lib.ac_device_count() >= 1, "no HIP device visible"
+    return lib
+
+
+def test_rccl_world_of_one(lib, monkeypatch):
+    monkeypatch.setenv("AC_MULTI_TRANSPORT", "rccl")
+    for k in (5, 11, 51):
+        for seed in range(6):
+            import seqgen
+            seqs, fn, hd = seqgen.make_case(seed, k)
+            _, info = M.run_case(None, k, seqs, fn, hd, [0])
+            assert info["transport"] == 2 and info["n_ranks"] == 1
+    seqs, fn, hd = M.synth_case(6, 60_000, 3_000, 1e-3, 1e-4, 99)
+    _, info = M.run_case(None, 51, seqs, fn, hd, [0])
+    assert info["transport"] == 2 and info["queries_total"] > 0 and info["queries_sent_away"] == 0
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_ranks_sharing_the_device(lib, world):
+    assert M.adversarial(None, [0] * world, ks=(11, 51), seeds=range(8)) == 2 * 8 * 2
+    seqs, fn, hd = M.synth_case(8, 60_000, 3_000, 1e-3, 1e-4, 7)
+    gfa1, _ = M.run_case(None, 51, seqs, fn, hd, [0])
+    gfa, info = M.run_case(None, 51, seqs, fn, hd, [0] * world)
+    assert gfa == gfa1 and info["transport"] == 1 and info["n_ranks"] == world
+    seqs, fn, hd = M.mixed_case(world, 4, 40_000)
+    _, info = M.run_case(None, 51, seqs, fn, hd, [0] * world)
+    assert 0 < info["queries_sent_away"] < info["queries_total"]
+    M.run_case(None, 13, [FIXED[c] for c in "abcde"], ["a.fasta", "b.fna", "c.fa", "d.fasta.gz", "e.fna.gz"], list("abcde"), [0] * world)
+
+
+def test_config_b_over_two_ranks_digest(lib):
+    """BASELINE configs[1] (12 x ~5 Mbp, k = 51) as one job over two ranks: the GFA has the oracle's md5 (tests/golden/configB_k51.json)."""
+    import ctypes as C
+    import numpy as np
+    import bench
+    from autocycler_amd import _capi, synth
+    golden = json.loads((ROOT / "tests" / "golden" / "configB_k51.json").read_text())
+    k, n_asm, gen = synth.WORKLOADS["configB_k51"]
+    seqs, fn, hd = synth.flatten(gen())
+    lib.ac_seqs_views.restype = C.POINTER(_capi.SeqView)
+    lib.ac_seqs_count.restype = C.c_uint32
+    lib.ac_seqs_free.argtypes = [C.c_void_p]
+    h = bench.prepare(lib, k, seqs, fn, hd, n_asm, threads=32, repair=1)
+    n = lib.ac_seqs_count(h)
+    views = lib.ac_seqs_views(h)
+    for devices in ([0, 0], [0]):
+        g = C.c_void_p()
+        dv = (C.c_int * len(devices))(*devices)
+        assert lib.ac_compress_build_multi(C.c_uint32(k), C.c_uint32(n_asm), views, C.c_uint32(n), dv, C.c_int(len(devices)), C.byref(g)) == 0, lib.ac_last_error()
+        gr = _capi.Graph(lib, g, n)
+        assert gr.stats_post["unitigs"] == golden["post"]["unitigs"]
+        assert hashlib.md5(gr.gfa(fn, hd).encode()).hexdigest() == golden["gfa_md5"]
+        gr.close()
+    lib.ac_seqs_free(h)
+    assert lib.ac_release_memory() == 0

@@ -1041,14 +1041,22 @@ template <int W> void GraphBuilder::Impl::walk_queries() {
 }
 // The queries in owner order (stable): d_routed_keys[i] = key of query qidx[i]; counts_host[o] = how many go to owner o.
 template <int W> void GraphBuilder::Impl::route_queries(u32 n_shards, u64* d_routed_keys, u64* counts_host) {
-    DBuf<u64> owner64(n_queries), counts(n_shards, true);
+    DBuf<u64> owner64(n_queries), first(n_shards);
     qidx.alloc(n_queries);
-    launch(n_queries, QueryOwnerFunctor<W>{qkeys.ptr(), (int)k, n_shards, my_owner, owner64.ptr(), qidx.ptr(), counts.ptr()});
+    first.fill_bytes(0xFF);
+    launch(n_queries, QueryOwnerFunctor<W>{qkeys.ptr(), (int)k, n_shards, my_owner, owner64.ptr(), qidx.ptr()});
     int bits = 1;
     while ((1u << bits) < n_shards) bits++;
     sort_pairs_u64_u32(owner64, qidx, n_queries, bits);
+    launch(n_queries, OwnerBoundsFunctor{owner64.ptr(), first.ptr()});
     launch(n_queries, QueryGatherFunctor<W>{qkeys.ptr(), qidx.ptr(), d_routed_keys});
-    copy_d2h(counts_host, counts.ptr(), (size_t)n_shards * 8);
+    std::vector<u64> h_first = to_host(first, n_shards);
+    u64 end = n_queries;
+    for (u32 o = n_shards; o-- > 0;) {
+        if (h_first[o] == ~0ULL) { counts_host[o] = 0; continue; }
+        counts_host[o] = end - h_first[o];
+        end = h_first[o];
+    }
 }
 template <int W> void GraphBuilder::Impl::answer_queries(const u64* d_keys, u64 n, u64* d_out) {
     launch(n, AnswerFunctor<W>{G->ctx((int)k), graph_table(), d_keys, d_out});

@@ -22,6 +22,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <cstdio>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -251,6 +252,9 @@ void rank_main(Shared& S, int rank) {
     double xs = 0;
     auto timed = [&](auto&& f) { const double t0 = now_s(); f(); xs += now_s() - t0; };
     auto xalloc = [&](size_t bytes) { return rc.xarena.alloc(bytes ? bytes : 1); };
+    static const bool dbg = getenv("AC_MULTI_DEBUG") != nullptr;
+    double t_lap = now_s();
+    auto lapmsg = [&](const char* what) { if (!dbg) return; stream_sync(); const double t = now_s(); fprintf(stderr, "[multi rank %d] %-22s %8.3f ms\n", rank, what, (t - t_lap) * 1e3); t_lap = t; };
 
     // ---- this rank's slice: host-side pack + upload, local insert, fragments
     const std::vector<SeqView> mine(S.seqs->begin() + (long)S.first[rank], S.seqs->begin() + (long)S.first[rank + 1]);
@@ -262,6 +266,7 @@ void rank_main(Shared& S, int rank) {
     b.set_sequences_host(mine);
     const uint32_t local_hint = (uint32_t)std::max<uint64_t>(1, (uint64_t)((double)S.assembly_count * (double)my_bases / (double)std::max<uint64_t>(all_bases, 1) + 0.5));
     b.shard_begin(local_hint);
+    lapmsg("shard_begin (upload, local insert, fragments)");
 
     // ---- fragments of all ranks -> the union text ('$' + the ranks' fragment texts in rank order) and the record table, on every rank
     uint64_t v3[3] = {b.fragment_count(), b.fragment_text_bytes(), b.local_distinct_count()};
@@ -282,11 +287,14 @@ void rank_main(Shared& S, int rank) {
         b.fragments_export(my_text, my_meta);
         const uint8_t dollar = '$';
         copy_h2d(d_union, &dollar, 1);
+        lapmsg("fragments export");
         timed([&] { X.all_gather_v(rank, my_text, d_union, tb.data(), td.data()); X.all_gather_v(rank, my_meta, d_meta, mb.data(), md.data()); });
+        lapmsg("fragments all-gather");
         stream_sync();
         rc.xarena.rewind(mk);
     }
     b.shard_build_union((uint32_t)rank, (uint32_t)R, d_union, nb_total, d_meta, nf_total);
+    lapmsg("build_union");
 
     // ---- novel bitmap, degree bytes, link words: the owners' contributions add up
     {
@@ -298,6 +306,7 @@ void rank_main(Shared& S, int rank) {
         b.shard_build_novel(bm);
         rc.xarena.rewind(mk);
     }
+    lapmsg("bitmap + build_novel");
     const uint64_t N = b.distinct_count();
     {
         const Arena::Mark mk = rc.xarena.mark();
@@ -307,6 +316,7 @@ void rank_main(Shared& S, int rank) {
         b.shard_build_graph(deg);
         rc.xarena.rewind(mk);
     }
+    lapmsg("degrees + build_graph");
     const uint64_t U = b.unitig_count();
     {
         const Arena::Mark mk = rc.xarena.mark();
@@ -317,6 +327,7 @@ void rank_main(Shared& S, int rank) {
         rc.xarena.rewind(mk);
     }
 
+    lapmsg("links");
     // ---- walk-start keys to their owners, answers back (one all-to-all each way)
     uint64_t nq = b.query_count();
     const uint32_t kw = b.query_key_words();
@@ -344,6 +355,7 @@ void rank_main(Shared& S, int rank) {
         rc.xarena.rewind(mk);
     }
 
+    lapmsg("queries + walk");
     // ---- per-unitig quantities over all sequences
     {
         const Arena::Mark mk = rc.xarena.mark();
@@ -353,9 +365,11 @@ void rank_main(Shared& S, int rank) {
         b.reduce_import(red, red + 3 * U);
         rc.xarena.rewind(mk);
     }
+    lapmsg("reduce");
     // ---- the order-sensitive tail (identical on every rank); rank 0 keeps unitigs + links, every rank the paths of its own sequences
     b.shard_finish(&S.graphs[rank], rank == 0, true);
     S.tms[rank] = b.timings();
+    lapmsg("finish");
     S.xsec[rank] = xs;
     {
         std::lock_guard<std::mutex> lock(S.st_mu);

@@ -844,7 +844,24 @@ int ac_compress_dir(const char* assemblies_dir, const char* autocycler_dir, uint
         // load (host) -> text layout -> H2D -> end repair on the device text -> graph build from the same buffer
         const bool host_repair = getenv("AC_HOST_REPAIR") != nullptr;      // the host implementation, kept for comparison
         // the HIP context and the code objects come up on another thread while the host reads the FASTA files
-        std::thread warm([device] { try { device_warmup(device); } catch (...) {} });
+        // (with the arena and the upload ring it will need, sized from the files' sizes: a .gz holds about four times its size in bases)
+        uint64_t est = 0;
+        {
+            std::error_code ec2;
+            for (auto& e : fs::directory_iterator(assemblies_dir, ec2)) {
+                if (!e.is_regular_file(ec2)) continue;
+                const uint64_t sz = (uint64_t)e.file_size(ec2);
+                est += e.path().extension() == ".gz" ? 4 * sz : sz;
+            }
+        }
+        // (the helper thread also notes which device the arena it reserves lives on — select_device — so that the build's own
+        // select_device, after the join below, finds it in place; nothing else runs in this process meanwhile: the CLI's only call)
+        std::thread warm([device, k, est] {
+            try {
+                { std::lock_guard<std::mutex> lock(g_build_mutex); if (g_live_shards) return; select_device(device); }
+                device_warmup(device, k, est + (est >> 4) + (1u << 20));
+            } catch (...) {}
+        });
         struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{warm};
         ac_seqs s;
         s.lr = load_sequences(assemblies_dir, k, max_contigs, threads, host_repair);

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unistd.h>
 
 #include "../../include/autocycler_hip.h"
 
@@ -82,5 +83,8 @@ int main(int argc, char** argv) {
     fprintf(stderr, "Stage times: load %.3fs, end repair %.3fs, graph build (GPU hot path) %.3fs, write %.3fs\n", times[0], times[1], times[2], times[3]);
     unsigned long long us = (unsigned long long)(total * 1e6);
     fprintf(stderr, "Time to run: %llu:%02llu:%02llu.%06llu\n\n", us / 1000000 / 3600, us / 1000000 / 60 % 60, us / 1000000 % 60, us % 1000000);
-    return 0;
+    // the output files are written and closed: leave without tearing down the HIP runtime, the device arena and the pinned pools
+    // (tens of milliseconds of a sub-second command)
+    fflush(stdout); fflush(stderr);
+    _exit(0);
 }

@@ -1397,6 +1397,7 @@ template <int W> struct Stages {
     static void walk(GraphBuilder::Impl& m);
     static void tail(GraphBuilder::Impl& m, FinalGraph* out, bool want_graph, bool want_paths);
     static void fragments(GraphBuilder::Impl& m);
+    static void warm();      // loads this width's code object (an empty launch of its insert kernel)
 };
 #if AC_W_ONLY != 0 || defined(AC_EMU)
 template <int W> void Stages<W>::table(GraphBuilder::Impl& m) { m.template table<W>(); }
@@ -1408,22 +1409,52 @@ template <int W> void Stages<W>::unitigs(GraphBuilder::Impl& m) { m.template uni
 template <int W> void Stages<W>::walk(GraphBuilder::Impl& m) { m.template walk<W>(); }
 template <int W> void Stages<W>::tail(GraphBuilder::Impl& m, FinalGraph* out, bool want_graph, bool want_paths) { m.template tail<W>(out, want_graph, want_paths); }
 template <int W> void Stages<W>::fragments(GraphBuilder::Impl& m) { m.template fragments<W>(); }
+template <int W> void Stages<W>::warm() {
+#ifndef AC_EMU
+    TextCtx t{}; Table tb{};
+    hipLaunchKernelGGL((insert_wave_kernel<W, false>), dim3(1), dim3(256), 0, 0, t, tb, (u64)0, (u64)0, 256u, (InsertStats*)nullptr, (u32*)nullptr, (u64*)nullptr);      // (no chunk at all: every wavefront returns at once)
+    (void)hipGetLastError();
+#endif
+}
 #endif
 #if AC_W_ONLY != 0
 template struct Stages<AC_W_ONLY>;
 #endif
 
 #if AC_W_ONLY == 0
-void device_warmup(int device) {
+[[maybe_unused]] static void ensure_host_stager();      // (HostStager is defined further down)
+void device_warmup(int device, uint32_t k, uint64_t text_bytes_estimate) {
 #ifndef AC_EMU
+    const bool trace = getenv("AC_DEBUG_WARM") != nullptr;
+    double t0 = now_s();
+    auto lap = [&](const char* what) { if (!trace) return; const double t = now_s(); fprintf(stderr, "[warm] %-28s %7.1f ms\n", what, (t - t0) * 1e3); t0 = t; };
     AC_HIP_CHECK(hipSetDevice(device));
     void* p = nullptr;
     AC_HIP_CHECK(hipMalloc(&p, 4096));
+    lap("context + first hipMalloc");
     hipLaunchKernelGGL(functor_kernel<PackFunctor>, dim3(1), dim3(256), 0, 0, (u64)1, PackFunctor{(const u8*)p, 32, (u64*)((u8*)p + 1024), (u32*)((u8*)p + 2048), 0, PackCheck{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr}});
+    (void)hipDeviceSynchronize();
+    lap("main code object");
+    // the code object of the key width the build will use, the device arena (hipMalloc of gigabytes: ~26 ms per GB) and the pinned upload
+    // ring — everything a fresh process would otherwise pay for inside its first build, while the caller still reads its FASTA files
+    if (k >= 1 && (int)k <= max_supported_k() && (k & 1)) {
+        switch (key_words((int)k)) {
+            case 1: Stages<1>::warm(); break; case 2: Stages<2>::warm(); break; case 3: Stages<3>::warm(); break;
+            case 4: Stages<4>::warm(); break; case 8: Stages<8>::warm(); break; case 16: Stages<16>::warm(); break;
+        }
+        (void)hipDeviceSynchronize();
+        lap("key-width code object");
+    }
+    if (text_bytes_estimate) {
+        Arena::device().reserve(arena_estimate(text_bytes_estimate, true));
+        lap("device arena");
+        ensure_host_stager();
+        lap("pinned upload ring");
+    }
     (void)hipDeviceSynchronize();
     (void)hipFree(p);
 #else
-    (void)device;
+    (void)device; (void)k; (void)text_bytes_estimate;
 #endif
 }
 
@@ -1561,6 +1592,7 @@ class HostStager {
 #endif
 };
 void release_host_stager() { HostStager::get().release(); }
+[[maybe_unused]] static void ensure_host_stager() { HostStager::get().ensure(); }
 
 // Bytes [b, e) of the text layout of `seqs` (off[i] = first padded byte of sequence i; every padded sequence is followed by '$').
 static void fill_text_range(const std::vector<SeqView>& seqs, const std::vector<uint64_t>& off, uint32_t k, u64 b, u64 e, u8* dst) {

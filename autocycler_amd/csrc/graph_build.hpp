@@ -139,7 +139,7 @@ void random_access_ceilings(double* cas_gops, double* read_gops);
 
 // Brings the HIP context and this library's code objects up on `device` (first use costs ~0.2 s): callable from a helper
 // thread while the caller is still busy on the host.
-void device_warmup(int device);
+void device_warmup(int device, uint32_t k = 0, uint64_t text_bytes_estimate = 0);
 
 // K1 on the host (what the packed upload of set_sequences_host runs per piece): n_text bytes -> (n_text + 31) / 32 words of 2-bit
 // codes (first base most significant) and as many 32-bit mask words (bit i = byte i is not a base).

@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--repair", choices=["device", "host"], default="device",
                     help="where sequence_end_repair runs (upstream of the timed region): on the device text, or the host implementation")
     ap.add_argument("--no-independent", action="store_true", help="N > 1: skip the secondary independent-jobs measurement")
+    ap.add_argument("--no-multi-entry", action="store_true", help="N > 1: skip the secondary measurement of the same job through ac_compress_build_multi (one process, N devices)")
     ap.add_argument("--species", choices=["per-gpu", "one"], default="per-gpu",
                     help="sharded mode at N > 1: one species per GPU (mixed-species job, fixed work and output per GPU) or all "
                          "N x A assemblies of one species (path output grows with N^2)")
@@ -426,6 +427,30 @@ def main():
                        "ms_per_step": float(e_i.item()) / args.steps * 1e3,
                        "what": "the same ranks and texts as N independent compress jobs (one per GPU, no data-path collective)"}
 
+    # Secondary figure at N > 1 (not `value`): the same job through the drop-in boundary a Rust caller would use — ONE process driving all N
+    # devices through ac_compress_build_multi (in-library RCCL).  It runs in a subprocess of rank 0 while the other ranks wait (they give their
+    # device memory back first), so whatever happens to it cannot take the benchmark line with it.
+    in_library = None
+    if world > 1 and mode == "sharded" and not args.no_multi_entry and not emu_lib:
+        if g is not None:
+            g.close(); g = None
+        del d_text
+        shard = None
+        torch.cuda.empty_cache()
+        lib.ac_release_memory()
+        barrier()
+        if rank == 0:
+            import subprocess
+            try:
+                pr = subprocess.run([sys.executable, str(ROOT / "tools" / "multi_bench.py"), "--bench-job", str(world), "--assemblies", str(args.assemblies),
+                                     "--genome", str(args.genome), "--steps", str(min(args.steps, 5)), "--warmup", "2"],
+                                    env={**os.environ, "AC_NO_TORCH": "1"}, capture_output=True, text=True, timeout=600)
+                rows = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+                in_library = json.loads(rows[-1]) if rows else {"error": (pr.stderr or "no output")[-400:]}
+            except Exception as e:      # noqa: BLE001 — a timeout or a crash of the subprocess is reported, not raised
+                in_library = {"error": repr(e)[:400]}
+        barrier()
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_bases / 1e6 / (elapsed / args.steps)
@@ -568,6 +593,8 @@ def main():
                         "probes the rest, which is why the stage can be faster than that bound"}
         if independent is not None:
             line["independent_jobs"] = independent
+        if in_library is not None:
+            line["in_library_multi"] = in_library
         if mode == "sharded":
             line["sharded"] = {**last_info, "fragments_rank0": tms[-1]["n_fragments"], "fragment_bytes_rank0": tms[-1]["fragment_bytes"],
                                "local_distinct_rank0": tms[-1]["n_local_distinct"]}

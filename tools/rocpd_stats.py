@@ -1,40 +1,44 @@
 #!/usr/bin/env python3
-"""Per-kernel statistics (calls, total / average duration) out of a rocprofv3 `--kernel-trace` result database (rocpd sqlite, the
-default output format of rocprofv3 7.x): what `--stats` printed as a CSV in earlier versions.
-    python tools/rocpd_stats.py RESULTS.db [--builds N] [--top 40]"""
-import argparse
+"""Per-kernel statistics from a rocprofv3 rocpd SQLite database (the `--kernel-trace --stats` output of
+ROCm 7.2): calls, total / average / min / max duration, share of GPU kernel time.  Writes a CSV summary.
+
+    python tools/rocpd_stats.py gpurun_out/prof/x_results.db [BUILDS] > profiles/r01_kernel_stats.csv
+
+BUILDS (optional): the number of graph builds the profiled command ran — adds calls and milliseconds per build."""
 import re
 import sqlite3
+import sys
 
 
 def short(name):
     name = re.sub(r"^void ", "", name)
-    m = re.match(r"(?:ac::)?functor_kernel(?:_full)?<(?:ac::)?(.*)>\(", name)
+    name = name.replace("ac::", "")
+    m = re.match(r"rocprim::ROCPRIM_\w+::detail::(\w+)<rocprim::ROCPRIM_\w+::detail::wrapped_(\w+?)_config<", name)
+    if m:   # rocPRIM kernels carry their whole instantiation in the name: keep the primitive only
+        return f"rocprim::{m.group(2)} ({m.group(1)})"
+    m = re.match(r"rocprim::ROCPRIM_\w+::detail::(\w+)", name)
     if m:
-        name = m.group(1)
-    name = re.sub(r"\(.*$", "", name)
-    return name[:110]
+        return f"rocprim::{m.group(1)}"
+    return re.sub(r"\(.*$", "", name)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("db")
-    ap.add_argument("--builds", type=int, default=1, help="divide totals by this many builds")
-    ap.add_argument("--top", type=int, default=40)
-    args = ap.parse_args()
-    c = sqlite3.connect(args.db)
-    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
-    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
-    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
-    rows = c.execute(f"select s.kernel_name, count(*), sum(d.end - d.start), min(d.start), max(d.end) from {kd} d join {ks} s on d.kernel_id = s.id "
-                     f"group by s.kernel_name order by 3 desc").fetchall()
-    total = sum(r[2] for r in rows)
-    n = sum(r[1] for r in rows)
-    print(f"# {n} dispatches, {total / 1e6:.3f} ms of kernel time; per build (/{args.builds}): {n / args.builds:.0f} launches, {total / 1e6 / args.builds:.3f} ms")
-    print("kernel,calls_per_build,total_ms_per_build,avg_us,share")
-    for name, calls, dur, _, _ in rows[:args.top]:
-        print(f"{short(name)},{calls / args.builds:.1f},{dur / 1e6 / args.builds:.4f},{dur / 1e3 / calls:.2f},{dur / total:.3f}")
+def main(path, builds=0):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [c[1] for c in cur.execute("pragma table_info('kernels')")]
+    rows = cur.execute("select name, start, end from kernels").fetchall() if "name" in cols else []
+    agg = {}
+    for name, start, end in rows:
+        a = agg.setdefault(short(name), [0, 0, 1 << 62, 0])
+        d = end - start
+        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    total = sum(a[1] for a in agg.values()) or 1
+    extra = ",CallsPerBuild,MsPerBuild" if builds else ""
+    print("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs" + extra)
+    for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        tail = f",{a[0] / builds:.1f},{a[1] / 1e6 / builds:.4f}" if builds else ""
+        print(f"\"{name}\",{a[0]},{a[1]},{a[1] / a[0]:.0f},{100.0 * a[1] / total:.2f},{a[2]},{a[3]}" + tail)
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0)

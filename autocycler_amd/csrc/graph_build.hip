@@ -2149,7 +2149,7 @@ void GraphBuilder::degrees_export(void* d_out) {      // one byte per k-mer: [fi
 void GraphBuilder::shard_build_graph(const void* d_kinfo_sum) {
     Impl& m = *impl_;
     m.t0 = now_s();
-    if (d_kinfo_sum) launch(m.N, KinfoUnpackFunctor{(const u8*)d_kinfo_sum, m.kinfo.ptr()});
+    if (d_kinfo_sum) launch(m.N, KinfoUnpackFunctor{(const u8*)d_kinfo_sum, m.kinfo.ptr(), m.counters.ptr() + 3});
     else if (m.n_owners > 1) throw DeviceError("the degree words of the other ranks are missing");
     AC_DISPATCH_W(unitigs, (*impl_))
 }
@@ -2165,6 +2165,7 @@ void GraphBuilder::links_import(const void* d_links_i32, const void* d_wlinks_i6
     if (d_links_i32 && d_wlinks_i64) {
         copy_d2d(m.links.ptr(), d_links_i32, (size_t)m.U * 10 * 4);
         copy_d2d(m.wlinks.ptr(), d_wlinks_i64, (size_t)m.U * 10 * 8);
+        launch((u64)m.U * 10, LinkSumCheckFunctor{m.links.ptr(), m.U, m.counters.ptr() + 3});
     } else if (m.n_owners > 1) throw DeviceError("the link words of the other ranks are missing");
     AC_DISPATCH_W(walk_queries, (*impl_))
 }

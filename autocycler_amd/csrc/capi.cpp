@@ -911,4 +911,38 @@ int ac_compress_dir(const char* assemblies_dir, const char* autocycler_dir, uint
     });
 }
 
+// The whole command over several devices: load + end repair on the host (the reference's own order, compress.rs:38-41), then ONE
+// ac_compress_build_multi call, then the same writers.
+int ac_compress_dir_multi(const char* assemblies_dir, const char* autocycler_dir, uint32_t k, uint32_t max_contigs, int threads,
+                          const int* devices, int n_devices, ac_graph** graph_out, double* times) {
+    return guarded([&] {
+        namespace fs = std::filesystem;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        check_compress_settings(assemblies_dir, autocycler_dir, k, threads);
+        if (!devices || n_devices < 1) throw DeviceError("ac_compress_dir_multi: no devices");
+        std::error_code ec;
+        fs::create_directories(autocycler_dir, ec);
+        if (ec) throw UserError(std::string("failed to create directory ") + autocycler_dir + "\n" + ec.message());
+        ac_seqs s;
+        s.lr = load_sequences(assemblies_dir, k, max_contigs, threads, /*repair=*/true);
+        s.make_views();
+        double t0 = now();
+        ac_graph* g = nullptr;
+        if (ac_compress_build_multi(k, s.lr.assembly_count, s.views.data(), (uint32_t)s.views.size(), devices, n_devices, &g) != 0) throw DeviceError(g_err);
+        std::unique_ptr<ac_graph> guard(g);
+        double t1 = now();
+        std::vector<SeqMeta> meta(s.lr.seqs.size());
+        for (size_t i = 0; i < meta.size(); i++) meta[i] = SeqMeta{s.lr.seqs[i].id, s.lr.seqs[i].length, s.lr.seqs[i].filename, s.lr.seqs[i].contig_header};
+        write_pieces((fs::path(autocycler_dir) / "input_assemblies.gfa").string(), gfa_chunks(g->g, meta, threads), threads);
+        {
+            std::string y = metrics_yaml(s.lr, g->g.post.unitigs, g->g.post.total_length);
+            std::ofstream f(fs::path(autocycler_dir) / "input_assemblies.yaml", std::ios::binary);
+            f.write(y.data(), (std::streamsize)y.size());
+        }
+        double t2 = now();
+        if (times) { times[0] = s.lr.load_seconds; times[1] = s.lr.repair_seconds; times[2] = t1 - t0; times[3] = t2 - t1; }
+        if (graph_out) *graph_out = guard.release();
+    });
+}
+
 }  // extern "C"

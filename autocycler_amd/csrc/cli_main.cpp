@@ -1,5 +1,6 @@
 // autocycler-compress — standalone driver with the flag surface of `autocycler compress` (main.rs:140-160):
-//   -i/--assemblies_dir DIR  -a/--autocycler_dir DIR  [--kmer 51] [--max_contigs 25] [-t/--threads 8] [--device 0]
+//   -i/--assemblies_dir DIR  -a/--autocycler_dir DIR  [--kmer 51] [--max_contigs 25] [-t/--threads 8] [--device 0 | --devices 0,1,..]
+// (--devices: one job over several GPUs of the node through ac_compress_build_multi; not a flag of the reference)
 // Writes DIR/input_assemblies.gfa and DIR/input_assemblies.yaml (compress.rs:45-46) through the C ABI
 // (ac_compress_dir: C++ loader + end repair, HIP graph build, host tail, buffered GFA writer).
 #include <chrono>
@@ -7,12 +8,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 #include <unistd.h>
 
 #include "../../include/autocycler_hip.h"
 
 static void usage() {
-    fprintf(stderr, "Usage: autocycler-compress --assemblies_dir <DIR> --autocycler_dir <DIR> [--kmer 51] [--max_contigs 25] [--threads 8] [--device 0]\n");
+    fprintf(stderr, "Usage: autocycler-compress --assemblies_dir <DIR> --autocycler_dir <DIR> [--kmer 51] [--max_contigs 25] [--threads 8] [--device 0 | --devices 0,1,..]\n");
 }
 
 // `autocycler decompress` (main.rs:163-175): -i/--in_gfa FILE  [-o/--out_dir DIR]  [-f/--out_file FASTA]
@@ -44,6 +46,7 @@ int main(int argc, char** argv) {
     std::string in, out;
     unsigned k = 51, max_contigs = 25;
     int threads = 8, device = 0;
+    std::vector<int> devices;
     int i = 1;
     if (argc > 1 && strcmp(argv[1], "compress") == 0) i = 2;
     for (; i < argc; i++) {
@@ -58,6 +61,7 @@ int main(int argc, char** argv) {
         else if (a == "--max_contigs") max_contigs = (unsigned)strtoul(val(), nullptr, 10);
         else if (a == "-t" || a == "--threads") threads = atoi(val());
         else if (a == "--device") device = atoi(val());
+        else if (a == "--devices") { const char* v = val(); for (const char* q = v; *q;) { devices.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; } }
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); usage(); return 2; }
     }
@@ -67,7 +71,9 @@ int main(int argc, char** argv) {
     fprintf(stderr, "Settings:\n  --assemblies_dir %s\n  --autocycler_dir %s\n  --kmer %u\n  --threads %d\n\n", in.c_str(), out.c_str(), k, threads);
     ac_graph* g = nullptr;
     double times[4] = {0, 0, 0, 0};
-    if (ac_compress_dir(in.c_str(), out.c_str(), k, max_contigs, threads, device, &g, times) != 0) {
+    const int rc = devices.size() > 1 ? ac_compress_dir_multi(in.c_str(), out.c_str(), k, max_contigs, threads, devices.data(), (int)devices.size(), &g, times)
+                                      : ac_compress_dir(in.c_str(), out.c_str(), k, max_contigs, threads, devices.empty() ? device : devices[0], &g, times);
+    if (rc != 0) {
         fprintf(stderr, "\nError: %s\n", ac_last_error());    // quit_with_error, misc.rs:131-137
         return 1;
     }

@@ -266,6 +266,10 @@ int ac_compress_seqs(uint32_t k, const ac_seqs*, int device, ac_graph** out);
 int ac_compress_dir(const char* assemblies_dir, const char* autocycler_dir, uint32_t k, uint32_t max_contigs,
                     int threads, int device, ac_graph** graph_out, double* times);
 
+/* The same over several devices (ac_compress_build_multi behind the host loader and the host end repair). */
+int ac_compress_dir_multi(const char* assemblies_dir, const char* autocycler_dir, uint32_t k, uint32_t max_contigs, int threads,
+                          const int* devices, int n_devices, ac_graph** graph_out, double* times);
+
 /* Measured ceilings of the device for the two access patterns the graph build is bound by: random atomicCAS and random 8-byte
  * reads on a 134 MB table, in 10^9 operations per second (a ~20 ms microbenchmark; bench.py prices its kernels against them). */
 int ac_random_access_ceilings(int device, double* cas_gops, double* read_gops);

@@ -108,6 +108,24 @@ def cli_matches_the_oracle(tmp_path, k):
     assert pr.returncode == 1 and "Error: directory does not exist" in pr.stderr
 
 
+def compress_dir_multi_matches_the_oracle(lib, tmp_path, k, devices):
+    """The whole command over several ranks (ac_compress_dir_multi: host loader + host end repair + ac_compress_build_multi): the oracle's
+    GFA and YAML for the five-file fixture and for a synthetic directory."""
+    from autocycler_amd import synth
+    src = tmp_path / "asm_multi"
+    write_five_file_fixture(src)
+    src2 = tmp_path / "asm_multi2"
+    synth.write_fasta_dir(synth.make_assemblies(6, genome=30_000, plasmid=2_000, sub=2e-3, indel=2e-4, seed=99), str(src2))
+    dv = (C.c_int * len(devices))(*devices)
+    for n, d in enumerate((src, src2)):
+        out_o, out_p = tmp_path / f"o_multi{n}", tmp_path / f"p_multi{n}"
+        O.compress_dir(d, out_o, k=k)
+        rc = lib.ac_compress_dir_multi(str(d).encode(), str(out_p).encode(), C.c_uint32(k), C.c_uint32(25), C.c_int(4), dv, C.c_int(len(devices)), None, None)
+        assert rc == 0, lib.ac_last_error()
+        assert (out_p / "input_assemblies.gfa").read_bytes() == (out_o / "input_assemblies.gfa").read_bytes()
+        assert (out_p / "input_assemblies.yaml").read_text() == (out_o / "input_assemblies.yaml").read_text()
+
+
 def two_device_ordinals(lib_path):
     """the process-wide device arena belongs to the device of the previous call; a call that names another ordinal
     must not run on its blocks.  (The emulation ignores the ordinal itself but runs the same release path.)"""

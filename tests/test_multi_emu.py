@@ -63,3 +63,9 @@ def test_errors_come_back_from_the_rank_threads(emu):
 def _capi_lib(emu):
     from autocycler_amd import _capi
     return _capi.load_library(emu)
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_whole_command_over_several_ranks(emu, tmp_path, world):
+    import boundary_cases as B
+    B.compress_dir_multi_matches_the_oracle(_capi_lib(emu), tmp_path, 13, [0] * world)

@@ -75,3 +75,20 @@ def test_config_b_over_two_ranks_digest(lib):
         gr.close()
     lib.ac_seqs_free(h)
     assert lib.ac_release_memory() == 0
+
+
+def test_whole_command_over_several_ranks(lib, tmp_path):
+    import subprocess
+    import boundary_cases as B
+    B.compress_dir_multi_matches_the_oracle(lib, tmp_path, 51, [0, 0])
+    # and the CLI's --devices (an extension of the reference's flag surface)
+    import oracle_lib as O
+    cli = ROOT / "autocycler_amd" / "autocycler-compress"
+    src = tmp_path / "asm_cli_multi"
+    B.write_five_file_fixture(src)
+    out_o, out_c = tmp_path / "o_cli_multi", tmp_path / "c_cli_multi"
+    O.compress_dir(src, out_o, k=13)
+    pr = subprocess.run([str(cli), "compress", "-i", str(src), "-a", str(out_c), "--kmer", "13", "--devices", "0,0,0"], capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    assert (out_c / "input_assemblies.gfa").read_bytes() == (out_o / "input_assemblies.gfa").read_bytes()
+    assert (out_c / "input_assemblies.yaml").read_text() == (out_o / "input_assemblies.yaml").read_text()

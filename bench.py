@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--mode", choices=["auto", "single", "sharded", "independent"], default="auto",
                     help="auto: single-device build at N=1, one sharded job at N>1")
     ap.add_argument("--init-builds", type=int, default=2, help="untimed builds before the warmup (one-time process initialisation)")
+    ap.add_argument("--init-seconds", type=float, default=1.5, help="keep running untimed builds until this much time has passed (device clocks ramp up under load)")
     ap.add_argument("--repair", choices=["device", "host"], default="device",
                     help="where sequence_end_repair runs (upstream of the timed region): on the device text, or the host implementation")
     ap.add_argument("--no-independent", action="store_true", help="N > 1: skip the secondary independent-jobs measurement")
@@ -258,11 +259,20 @@ def main():
     # One-time initialisation outside both the warmup and the timed region: the first two builds of a process load
     # the code objects, create the pinned result pool and the copy stream (60-180 ms and ~20 ms instead of ~9 ms).
     cold_first_build_ms = None
-    for i in range(args.init_builds):
+    t_init = time.perf_counter()
+    i = 0
+    # (... and the device's clocks: a process's first 0.3-1.3 s of builds run ~19 % slower than its later ones — E' 23.1 vs 19.4 ms,
+    # mini-E 89 vs 73 ms, whichever library version, with or without per-stage synchronisation: the power management ramping up, DESIGN.md
+    # section 6 — so the untimed builds go on until --init-seconds of them have run)
+    # (N > 1: every rank must run the same number of builds — they are collective — so a fixed count there)
+    n_fixed = args.init_builds if world == 1 else (max(args.init_builds, 8) if args.init_seconds > 0 else args.init_builds)
+    while i < n_fixed or (world == 1 and time.perf_counter() - t_init < args.init_seconds and i < 400):
         tc = time.perf_counter()
         step().close()
         if i == 0:
             cold_first_build_ms = (time.perf_counter() - tc) * 1e3
+        i += 1
+    init_builds_run = i
     if os.environ.get("BENCH_STAGE_TIMING"):      # experiment: keep the per-stage syncs inside the timed loop
         lib.ac_set_stage_timing(C.c_int(1))
     for _ in range(args.warmup):
@@ -496,7 +506,7 @@ def main():
                                        "+ D2H); the host-RAM -> host-RAM bracket of the same region (H2D included, SURVEY.md 8d T_hot) is `t_hot`, the "
                                        "whole command `t_e2e`"},
             "roofline": None,      # (filled in below)
-            "t_hot": t_hot, "t_e2e": t_e2e, "cold_first_build_ms": cold_first_build_ms,
+            "t_hot": t_hot, "t_e2e": t_e2e, "cold_first_build_ms": cold_first_build_ms, "init_builds_run": init_builds_run,
             "total_device_timed_ms": sum(t["total_device"] for t in tms) / len(tms) * 1e3,
             "step_ms_list": [round(x * 1e3, 2) for x in step_s],
             "step_ms": {"min": min(step_s) * 1e3, "median": sorted(step_s)[len(step_s) // 2] * 1e3, "max": max(step_s) * 1e3},

@@ -10,7 +10,7 @@ fi
 timeout 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench exit $?"
 tail -c 3000 gpurun_out/${TAG}_bench.json
 R=$PWD
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof -o prof -- python $R/bench.py --steps 3 --warmup 1 --init-builds 0 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> $R/gpurun_out/${TAG}_rocprof.err; echo "rocprof exit $?"
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof -o prof -- python $R/bench.py --steps 3 --warmup 1 --init-builds 0 --init-seconds 0 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> $R/gpurun_out/${TAG}_rocprof.err; echo "rocprof exit $?"
 cd $R
 ls -R gpurun_out/${TAG}_prof | head -20
 DB=$(find gpurun_out/${TAG}_prof -name '*.db' | head -1)

@@ -8,7 +8,7 @@ R=$PWD
 mkdir -p $R/gpurun_out
 for CTR in FETCH_SIZE WRITE_SIZE; do
   cd /tmp && timeout 600 rocprofv3 --pmc $CTR --kernel-trace -f csv -d $R/gpurun_out/${TAG}_pmc_$CTR -o pmc -- \
-      python $R/bench.py --steps 2 --warmup 1 --init-builds 0 --no-cpu-baseline "$@" > $R/gpurun_out/${TAG}_pmc_${CTR}_bench.json 2> $R/gpurun_out/${TAG}_pmc_$CTR.err
+      python $R/bench.py --steps 2 --warmup 1 --init-builds 0 --init-seconds 0 --no-cpu-baseline "$@" > $R/gpurun_out/${TAG}_pmc_${CTR}_bench.json 2> $R/gpurun_out/${TAG}_pmc_$CTR.err
   echo "$CTR pass exit $?"
   cd $R
   F=$(find gpurun_out/${TAG}_pmc_$CTR -name '*counter_collection.csv' | head -1)

@@ -6,7 +6,7 @@ TAG=${1:-rXX}; NS=${2:-"2 4"}
 mkdir -p gpurun_out
 for N in $NS; do
   BENCH_FORCE_DEVICE=0 BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29500 + N)) \
-      bench.py --gpus $N --steps 3 --warmup 1 --init-builds 1 --no-independent > gpurun_out/${TAG}_shared_gpu_n$N.json 2> gpurun_out/${TAG}_shared_gpu_n$N.err
+      bench.py --gpus $N --steps 3 --warmup 1 --init-builds 1 --init-seconds 0 --no-independent > gpurun_out/${TAG}_shared_gpu_n$N.json 2> gpurun_out/${TAG}_shared_gpu_n$N.err
   echo "N=$N exit $?"
   python - <<PY
 import json

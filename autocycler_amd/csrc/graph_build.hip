@@ -414,7 +414,13 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); if (!e) return -1; int v = atoi(e); return v < 0 ? 0 : (v > 3 ? 3 : v); }      // -1 = automatic
 [[maybe_unused]] static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
 [[maybe_unused]] static u64 wave_chunk_rest() { const char* e = getenv("AC_INSERT_CHUNK_REST"); u64 x = e ? (u64)atoll(e) : 16384; return (std::max<u64>(x, 256) + 63) & ~63ULL; }   // longest chunk of the one-launch rest (r04c: 4096 / 8192 / 16384 = 0.90 / 0.84 / 0.82 ms)
-[[maybe_unused]] static u64 upload_threads() { const char* e = getenv("AC_UPLOAD_THREADS"); long x = e ? atol(e) : 32; return (u64)(x < 1 ? 1 : (x > 128 ? 128 : x)); }   // host threads laying out / packing the text (the byte upload uses at most 8)
+static thread_local int tl_upload_threads_cap = 0;      // a rank of a multi-device build: its share of the host's cores (0 = no cap)
+[[maybe_unused]] static u64 upload_threads() {
+    const char* e = getenv("AC_UPLOAD_THREADS");
+    long x = e ? atol(e) : 32;
+    if (tl_upload_threads_cap > 0 && x > tl_upload_threads_cap) x = tl_upload_threads_cap;
+    return (u64)(x < 1 ? 1 : (x > 128 ? 128 : x));
+}   // host threads laying out / packing the text (the byte upload uses at most 8)
 [[maybe_unused]] static bool host_pack() { const char* e = getenv("AC_HOST_PACK"); return e ? atoi(e) != 0 : true; }      // 0: upload the text as bytes and pack on the device
 [[maybe_unused]] static bool insert_profile() { static const bool v = getenv("AC_INSERT_PROFILE") != nullptr; return v; }      // measurement only
 [[maybe_unused]] static bool expand_rewrite_always() { return getenv("AC_EXPAND_REWRITE_ALWAYS") != nullptr; }      // tests: compact the expand pool after every host check
@@ -1491,6 +1497,7 @@ GraphBuilder::GraphBuilder(uint32_t k) : impl_(new Impl) {
 GraphBuilder::~GraphBuilder() { delete impl_; }
 uint64_t GraphBuilder::n_text() const { return impl_->loc.n_text; }
 void GraphBuilder::set_sequence_index_base(uint64_t n) { impl_->loc.index_base = n; }
+void GraphBuilder::set_upload_threads_cap(int n) { tl_upload_threads_cap = n; }
 uint64_t GraphBuilder::n_bases() const { return impl_->loc.n_bases; }
 
 // ---- host entry: sequences in the caller's (pageable) memory -> text + packed text in HBM ----------------------------------

@@ -113,6 +113,7 @@ class GraphBuilder {
     void paths_export(void* d_out);                                 // int32 per entry, final numbers
     const BuildTimings& timings() const { return tm_; }
     void set_sequence_index_base(uint64_t n);   // a rank of a multi-device build: how many sequences of the job precede its slice (error messages)
+    static void set_upload_threads_cap(int n);  // for the calling thread's builds: at most n packing threads (the ranks of a multi-device build share the host)
     uint64_t n_text() const;
     uint64_t n_bases() const;   // sum of unpadded lengths
 

@@ -261,6 +261,7 @@ void rank_main(Shared& S, int rank) {
     uint64_t my_bases = 0, all_bases = 0;
     for (auto& s : mine) my_bases += s.length;
     for (auto& s : *S.seqs) all_bases += s.length;
+    GraphBuilder::set_upload_threads_cap((int)std::max(2u, std::thread::hardware_concurrency() / (unsigned)std::max(S.R, 1)));
     GraphBuilder b(S.k);
     b.set_sequence_index_base(S.first[rank]);
     b.set_sequences_host(mine);

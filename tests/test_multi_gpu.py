@@ -92,3 +92,31 @@ def test_whole_command_over_several_ranks(lib, tmp_path):
     assert pr.returncode == 0, pr.stderr[-2000:]
     assert (out_c / "input_assemblies.gfa").read_bytes() == (out_o / "input_assemblies.gfa").read_bytes()
     assert (out_c / "input_assemblies.yaml").read_text() == (out_o / "input_assemblies.yaml").read_text()
+
+
+def test_mixed_species_replica_over_four_ranks_digest(lib):
+    """E' (5 species x 20 strains x ~1 Mbp, 45 M distinct k-mers, 1.7 M unitigs) as one job over four ranks sharing the device: the owner-routed key
+    exchange under load (each rank routes ~10^5 walk-start keys to three others) — the GFA has the oracle's md5."""
+    import ctypes as C
+    import bench
+    from autocycler_amd import _capi, synth
+    golden = json.loads((ROOT / "tests" / "golden" / "configEprime_k51.json").read_text())
+    k, n_asm, gen = synth.WORKLOADS["configEprime_k51"]
+    seqs, fn, hd = synth.flatten(gen())
+    lib.ac_seqs_views.restype = C.POINTER(_capi.SeqView)
+    lib.ac_seqs_count.restype = C.c_uint32
+    lib.ac_seqs_free.argtypes = [C.c_void_p]
+    h = bench.prepare(lib, k, seqs, fn, hd, n_asm, threads=32, repair=1)
+    n = lib.ac_seqs_count(h)
+    g = C.c_void_p()
+    dv = (C.c_int * 4)(0, 0, 0, 0)
+    assert lib.ac_compress_build_multi(C.c_uint32(k), C.c_uint32(n_asm), lib.ac_seqs_views(h), C.c_uint32(n), dv, C.c_int(4), C.byref(g)) == 0, lib.ac_last_error()
+    gr = _capi.Graph(lib, g, n)
+    mi = _capi.MultiInfo()
+    lib.ac_multi_info_get(g, C.byref(mi))
+    assert gr.stats_post["unitigs"] == golden["post"]["unitigs"]
+    assert hashlib.md5(gr.gfa(fn, hd).encode()).hexdigest() == golden["gfa_md5"]
+    assert mi.n_ranks == 4 and mi.queries_sent_away > mi.queries_total // 2
+    gr.close()
+    lib.ac_seqs_free(h)
+    assert lib.ac_release_memory() == 0

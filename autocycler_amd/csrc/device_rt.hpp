@@ -662,6 +662,14 @@ static const u64 MAX_LAUNCH_BLOCKS = (u64)1 << 23;
 #ifdef AC_EMU
 inline int emu_order() { const char* e = getenv("AC_EMU_ORDER"); return e ? atoi(e) : 0; }
 #endif
+#ifndef AC_EMU
+// AC_DEBUG_LAUNCH=1: every functor launch is announced on stderr and waited for — the last line before a device fault names the kernel.
+inline bool debug_launch() { static const bool v = [] { const char* e = getenv("AC_DEBUG_LAUNCH"); return e && *e == '1'; }(); return v; }
+template <class F> void debug_launch_note(u64 n, bool after) {
+    if (!after) { fprintf(stderr, "[launch] n=%llu %s\n", (unsigned long long)n, __PRETTY_FUNCTION__); fflush(stderr); }
+    else AC_HIP_CHECK(hipDeviceSynchronize());
+}
+#endif
 template <class F> void launch(u64 n, const F& f, stream_t s = 0) {
     if (n == 0) return;
 #ifdef AC_EMU
@@ -679,10 +687,12 @@ template <class F> void launch(u64 n, const F& f, stream_t s = 0) {
 #else
     const u64 blocks = (n + 255) / 256;
     if (s == 0) flush_fills();
+    if (debug_launch()) debug_launch_note<F>(n, false);
     for (u64 b0 = 0; b0 < blocks; b0 += MAX_LAUNCH_BLOCKS) {
         hipLaunchKernelGGL(functor_kernel<F>, dim3((unsigned)std::min(MAX_LAUNCH_BLOCKS, blocks - b0)), dim3(256), 0, s, n, f, b0 * 256);
         AC_HIP_CHECK(hipGetLastError());
     }
+    if (debug_launch()) debug_launch_note<F>(n, true);
 #endif
 }
 
@@ -704,10 +714,12 @@ template <class F> void launch_full(u64 n, const F& f, stream_t s = 0) {
 #else
     const u64 blocks = (n + 255) / 256;
     if (s == 0) flush_fills();
+    if (debug_launch()) debug_launch_note<F>(n, false);
     for (u64 b0 = 0; b0 < blocks; b0 += MAX_LAUNCH_BLOCKS) {
         hipLaunchKernelGGL(functor_kernel_full<F>, dim3((unsigned)std::min(MAX_LAUNCH_BLOCKS, blocks - b0)), dim3(256), 0, s, n, f, b0 * 256);
         AC_HIP_CHECK(hipGetLastError());
     }
+    if (debug_launch()) debug_launch_note<F>(n, true);
 #endif
 }
 // Bump allocation from a device counter with ONE atomic per wavefront (a counter hit by every lane serialises in L2).

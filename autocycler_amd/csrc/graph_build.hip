@@ -80,7 +80,27 @@ struct Table {
     u32 my_owner;     // inserts of other keys are skipped, lookups of other keys answer "not here" (their owner answers)
     u64* sflags;      // during the insert only (optional): two SIBLING bits per slot (sib_note); MarkFunctor moves them to text positions
     u64* full_at;     // during the insert only (optional): ~(smallest text position whose insert found the table full), by atomic max
+    // during the insert only (optional): the followed runs of at least RUN_MIN positions, three words each — [first position p of the
+    // run | its length n | the position q it repeats, bit 63 = in the same orientation]: position p + i repeats q + i (same) or
+    // q - i (reverse complement), 0 <= i < n.  The path walk copies the unitig paths of such stretches instead of walking them (K10c).
+    // The list is split into RUN_REGIONS regions of run_cap records with a counter each (a wavefront uses the region its chunk number
+    // selects): half a million appends to ONE counter serialise on its cache line — they cost the insert 1.2 ms on config C.
+    u64* runs; u32* run_count; u32 run_cap;
 };
+static const u64 RUN_MIN = 128;
+static const u32 RUN_REGIONS = 256;
+AC_D void run_note(const Table& tb, u64 region, u64 pj, u64 qj, bool same, u64 n) {      // the run the follow from (pj, qj) verified: positions pj + 1 .. pj + n
+    if (!tb.runs || n < RUN_MIN) return;
+    const u32 rg = (u32)(region % RUN_REGIONS);
+    const u32 idx = atomic_add32(tb.run_count + rg, 1u);
+    if (idx >= tb.run_cap) return;      // (a run that is not on the list is walked like any other text)
+    u64* rec = tb.runs + 3 * ((u64)rg * tb.run_cap + idx);
+    // (the anchor itself repeats qj: with it on board two runs that a single-lane opener joins lie back to back, and no walker has to
+    // look the one position between them up — unless qj is not a first occurrence: then it stays outside)
+    const bool with_anchor = ((tb.novel[qj >> 6] >> (qj & 63)) & 1) != 0;
+    if (with_anchor) { rec[0] = pj; rec[1] = n + 1; rec[2] = qj | ((u64)(same ? 1 : 0) << 63); }
+    else { rec[0] = pj + 1; rec[1] = n; rec[2] = (same ? qj + 1 : qj - 1) | ((u64)(same ? 1 : 0) << 63); }
+}
 // Sibling bits.  Two k-mers of one middle are siblings in x (same first base, read in the orientation in which the middle is
 // canonical: key_place) or in y (same last base); a k-mer WITHOUT a sibling in x / y is the only successor / predecessor its text
 // neighbour can have, which the degree pass (DegreeLightFunctor) uses to skip the probe.  The insert finds the siblings for free:
@@ -377,6 +397,8 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 //   AC_NO_MAILBOX     (read once) small read-backs through hipMemcpyAsync + synchronise instead of the mapped mailbox page.
 //   AC_INSERT_PROFILE (read once) per-wavefront cycle split of every insert launch on stderr (measurement).
 [[maybe_unused]] static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : -1; }      // -1 = automatic
+[[maybe_unused]] static bool path_copy() { const char* e = getenv("AC_PATH_COPY"); return e ? atoi(e) != 0 : false; }      // 1: paths of followed runs are copied from the stretch they repeat
+[[maybe_unused]] static u64 run_piece() { const char* e = getenv("AC_RUN_PIECE"); const long v = e ? atol(e) : 0; return v > 0 ? (u64)v : 4096; }      // positions per copied piece of a run (RunFilterFunctor)
 [[maybe_unused]] static bool path_filter() { const char* e = getenv("AC_PATH_FILTER"); return e ? atoi(e) != 0 : true; }   // smallest positions only for possible expand_repeats destinations
 // AC_PATH_DIAG (skips the walk's depth atomics / position updates to price them: the result is WRONG when set) only exists in
 // builds made with -DAC_MEASUREMENT_KNOBS; the shipped library ignores the variable.
@@ -539,6 +561,7 @@ struct GraphBuilder::Impl {
     }
     template <int W> void insert(const PackedText& t, u32 hint, DBuf<u64>* slots_out, u64* cap_out, u64* n_distinct_out, DBuf<u64>* bm_out, bool want_sib = false);
     DBuf<u64> sflags;          // sibling bits per slot, written by the insert (sib_note); empty = not collected
+    DBuf<u64> runs; DBuf<u32> run_count; u32 run_cap = 0;      // the insert's followed runs (Table::runs), for the copying path walk
     void occupancy_bitmap(const DBuf<u64>& sl, u64 c, DBuf<u64>* occ_out, const u64* sflags_in, u64* sib_out);
     DBuf<u64> occ;             // slot-occupancy bitmap of the graph table
     DBuf<u64> sib;             // sibling bits of the graph table's real k-mers, two per text position (MarkFunctor); empty = not used
@@ -597,7 +620,7 @@ struct GraphBuilder::Impl {
 #endif
         pt.pack();
     }
-    Table graph_table() const { return Table{const_cast<u64*>(slots.ptr()), cap - 1, occ.ptr(), nullptr, n_owners, my_owner, nullptr, nullptr}; }
+    Table graph_table() const { return Table{const_cast<u64*>(slots.ptr()), cap - 1, occ.ptr(), nullptr, n_owners, my_owner, nullptr, nullptr, nullptr, nullptr, 0}; }
     template <int W> void fragments();
     template <int W> void table();                      // K2, K3 on G
     void novel_list(u64 known_n);
@@ -611,6 +634,7 @@ struct GraphBuilder::Impl {
     const u64* walk_answers = nullptr;                  // sharded: [n_walkers | n_seqs] answers (0 = not found), nullptr = look the table up
     template <int W> void unitigs();                    // K6..K11 on G
     template <int W> void walk();
+    template <int W> bool walk_copy(u32 PC);            // K10c: false = not worth it (or not possible) for this text, nothing done
     template <int W> void tail(FinalGraph* out, bool want_graph, bool want_paths);
 };
 
@@ -637,6 +661,11 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
     // stream of similar jobs, does not pay for the overflow retries twice)
     static thread_local u64 memo_n_text = 0, memo_cap = 0; static thread_local u32 memo_k = 0; static thread_local int memo_shift = -2;      // (a capacity is a number, not memory: valid on any device)
     if (pt.n_text == memo_n_text && k == memo_k && memo_shift == table_shift() && memo_cap > c) c = memo_cap;
+    const bool want_runs = want_sib && path_copy() && &pt == &loc;      // (want_sib = the graph table of a single-device build)
+    if (want_runs) {
+        run_cap = (u32)std::min<u64>((pt.n_text / RUN_MIN) / RUN_REGIONS * 2 + 256, (u64)1 << 20);      // per region (twice an even share)
+        runs.alloc(3 * (u64)run_cap * RUN_REGIONS); run_count.alloc(RUN_REGIONS);
+    } else { runs = DBuf<u64>(); run_count = DBuf<u32>(); run_cap = 0; }
     DBuf<InsertStats> istats(257);       // [256].real doubles as the kernel's error word: one D2H reads everything
     DBuf<u64> sl;
     DBuf<u64> nbm(pt.n_text / 64 + 2);   // K3a falls out of the insert: bit p set <=> p is the smallest occurrence of its canonical k-mer
@@ -653,7 +682,11 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
         else sflags = DBuf<u64>();
         u32* ierr = (u32*)&istats.ptr()[256].real;
         Table tb{sl.ptr(), c - 1, nullptr, nbm.ptr(), (&pt == &uni) ? n_owners : 1u, (&pt == &uni) ? my_owner : 0u, want_sib ? sflags.ptr() : nullptr,
-                 &istats.ptr()[256].claimed};
+                 &istats.ptr()[256].claimed, nullptr, nullptr, 0};
+        if (want_runs) {      // (the graph text of a single-device build: its path walk can copy)
+            run_count.fill_bytes(0);
+            tb.runs = runs.ptr(); tb.run_count = run_count.ptr(); tb.run_cap = run_cap;
+        }
         phase_end.clear();
         stream_sync();
 #ifndef AC_EMU
@@ -1080,6 +1113,89 @@ template <int W> void GraphBuilder::Impl::answer_queries(const u64* d_keys, u64 
     launch(n, AnswerFunctor<W>{G->ctx((int)k), graph_table(), d_keys, d_out});
 }
 
+// K10c: walk the text between the insert's followed runs, copy the runs' entries from the stretches they repeat (kernels_paths.inc).
+template <int W> bool GraphBuilder::Impl::walk_copy(u32 PC) {
+    TextCtx t = loc.ctx((int)k);
+    Table tb = graph_table();
+    Novel nv{bm.ptr(), wprefix.ptr()};
+    UnitigCtx uc{head.ptr(), scan.ptr(), rank.ptr(), uorient.ptr(), ustart.ptr(), ulen.ptr(), U, N};
+    std::vector<u32> h_cnt = to_host(run_count, RUN_REGIONS);
+    std::vector<u64> h_first(RUN_REGIONS + 1, 0);
+    for (u32 g = 0; g < RUN_REGIONS; g++) h_first[g + 1] = h_first[g] + std::min<u32>(h_cnt[g], run_cap);
+    const u64 R0 = h_first[RUN_REGIONS];
+    if (R0 == 0 || R0 >= 0xFFFFFFF0ULL) return false;
+    const Arena::Mark mk = Arena::device().mark();
+    // the runs in text order, the usable ones only
+    DBuf<u64> key(R0), rfirst(RUN_REGIONS + 1); DBuf<u32> idx(R0);
+    copy_h2d(rfirst.ptr(), h_first.data(), (RUN_REGIONS + 1) * 8);
+    launch(R0, RunKeyFunctor{runs.ptr(), rfirst.ptr(), run_cap, key.ptr(), idx.ptr()});
+    sort_pairs_u64_u32(key, idx, R0, 40);
+    DBuf<RunRec> sorted(R0);
+    launch(R0, RunGatherFunctor{runs.ptr(), idx.ptr(), sorted.ptr()});
+    DBuf<u32> ok(R0 + 1), at(R0 + 1); DBuf<u64> covered(1, true); DBuf<u32> overlap(1, true);
+    ok.fill_bytes(0);
+    DBuf<RunRec> fixed(R0); DBuf<u32> fseq(R0);
+    launch(R0, RunFilterFunctor{sorted.ptr(), fixed.ptr(), R0, nv, loc.n_text, ok.ptr(), covered.ptr(), t, overlap.ptr(), run_piece(), fseq.ptr()});
+    exclusive_scan_u32(ok.ptr(), at.ptr(), R0 + 1);
+    u64 h_cov = 0; u32 h_R = 0, h_overlap = 0;
+    { ReadBatch rb; rb.add(&h_cov, covered.ptr(), 8); rb.add(&h_R, at.ptr() + R0, 4); rb.add(&h_overlap, overlap.ptr(), 4); rb.run(); }
+    const u64 R = h_R;
+    if (getenv("AC_DEBUG_ARENA")) fprintf(stderr, "path copy: %llu runs on the list, %llu usable, covering %llu of %llu positions\n", (unsigned long long)R0, (unsigned long long)R, (unsigned long long)h_cov, (unsigned long long)loc.n_text);
+    if (R == 0 || h_overlap || h_cov * 2 < loc.n_text) { Arena::device().rewind(mk); return false; }      // little to copy: the plain walk
+    DBuf<RunRec> rr(R); DBuf<u32> rseq(R);
+    launch(R0, RunCompactFunctor{fixed.ptr(), ok.ptr(), at.ptr(), rr.ptr(), run_piece(), fseq.ptr(), rseq.ptr()});
+    // the gaps between them, cut into walkers
+    DBuf<u64> gw(R + 2), wfirst(R + 2);
+    launch(R + 2, GapWalkersFunctor{rr.ptr(), R, loc.n_text, PC, gw.ptr()});
+    exclusive_scan_u64(gw.ptr(), wfirst.ptr(), R + 2);
+    const u64 NW = read_scalar(wfirst.ptr() + (R + 1));
+    if (NW == 0 || NW >= 0xFFFFFFF0ULL) { Arena::device().rewind(mk); return false; }
+    DBuf<u64> w_begin(NW), w_end(NW), wcount(NW + 1), woff(NW + 1); DBuf<u32> w_gap(NW);
+    launch(NW, WalkerRangeFunctor{rr.ptr(), R, loc.n_text, PC, wfirst.ptr(), w_begin.ptr(), w_end.ptr(), w_gap.ptr()});
+    const u64 n_slots = ((NW + 63) / 64) * 64 * PC;
+    DBuf<int32_t> stage(n_slots); DBuf<u16> stage_off(n_slots);
+    DBuf<u32> seq_tid(loc.n_seqs), seq_j(loc.n_seqs);
+    wcount.fill_bytes(0);
+    const bool filter = maybe_dest_valid;
+    launch((u64)U * 10, WlinkFlagFunctor{filter ? maybe_dest.ptr() : nullptr, wlinks.ptr(), counters.ptr() + 4});
+    DBuf<V16> uinfo(U);
+    launch(U, WalkInfoFunctor{uc, filter ? maybe_dest.ptr() : nullptr, uinfo.ptr()});
+    launch(NW, PathWalkFunctor<W>{t, t, tb, nv, uc, uinfo.ptr(), wlinks.ptr(), PC, stage.ptr(), wcount.ptr(), seq_tid.ptr(), seq_j.ptr(),
+                                 depth.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), counters.ptr() + 4, filter ? maybe_dest.ptr() : nullptr,
+                                 0, nullptr, NW, w_begin.ptr(), w_end.ptr(), stage_off.ptr()});
+    exclusive_scan_u64(wcount.ptr(), woff.ptr(), NW + 1);
+    const u64 NE = read_scalar(woff.ptr() + NW);      // walked entries
+    DBuf<int32_t> ent(NE); DBuf<u64> ent_pos(NE), ent_end(NE); DBuf<u8> ent_want(NE);
+    launch(NW, WalkCompactFunctor{stage.ptr(), stage_off.ptr(), wcount.ptr(), woff.ptr(), w_begin.ptr(), PC, NW, ulen.ptr(), filter ? maybe_dest.ptr() : nullptr,
+                                  ent.ptr(), ent_pos.ptr(), ent_end.ptr(), ent_want.ptr()});
+    // what every run copies; entries per segment; the final array
+    DBuf<u64> ra(R), rcnt(R + 1), seg(2 * R + 2), segoff(2 * R + 2); DBuf<u32> cov(NE + 1), copies(NE + 1);
+    cov.fill_bytes(0);
+    launch(R, RunRangeFunctor{rr.ptr(), ent_pos.ptr(), ent_end.ptr(), NE, ra.ptr(), rcnt.ptr(), cov.ptr()});
+    launch(2 * R + 2, SegCountFunctor{wfirst.ptr(), woff.ptr(), rcnt.ptr(), R, seg.ptr()});
+    exclusive_scan_u64(seg.ptr(), segoff.ptr(), 2 * R + 2);
+    inclusive_scan_u32(cov.ptr(), copies.ptr(), NE + 1);
+    n_ent = read_scalar(segoff.ptr() + (2 * R + 1));
+    if (getenv("AC_DEBUG_ARENA")) {
+        std::vector<u64> h = to_host(rcnt, R); u64 mx = 0, sum = 0, big = 0, hist[8] = {0};
+        for (u64 v : h) { mx = std::max(mx, v); sum += v; if (v > 256) big++; int b = 0; while ((32ull << b) < v && b < 7) b++; hist[b]++; }
+        fprintf(stderr, "path copy: %llu pieces, entries per piece: max %llu, mean %.1f, %llu above 256; hist(<=32,64,128,..): %llu %llu %llu %llu %llu %llu %llu %llu\n", (unsigned long long)R, (unsigned long long)mx, (double)sum / (double)R, (unsigned long long)big,
+                (unsigned long long)hist[0], (unsigned long long)hist[1], (unsigned long long)hist[2], (unsigned long long)hist[3], (unsigned long long)hist[4], (unsigned long long)hist[5], (unsigned long long)hist[6], (unsigned long long)hist[7]);
+    }
+    // (the scratch above stays where it is until the build ends: for a text this redundant it is a fraction of the text's size)
+    ent_val.alloc(n_ent);
+    int32_t* const out_ptr = ent_val.ptr();
+    launch(NW, GapOutFunctor{ent.ptr(), wcount.ptr(), woff.ptr(), wfirst.ptr(), w_gap.ptr(), segoff.ptr(), copies.ptr(), out_ptr, depth.ptr()});
+    launch_full(R * 32, RunOutFunctor<32, 1>{rr.ptr(), R, ra.ptr(), rcnt.ptr(), segoff.ptr(), ent.ptr(), ent_pos.ptr(), ent_end.ptr(), ulen.ptr(),
+                                             ent_want.ptr(), t, rseq.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), out_ptr});
+    launch(loc.n_seqs, PathOffCopyFunctor{seq_tid.ptr(), seq_j.ptr(), woff.ptr(), wfirst.ptr(), w_gap.ptr(), segoff.ptr(), path_off.ptr()});
+    tm->n_path_entries = n_ent;
+    tm->path_runs_copied = R; tm->path_entries_walked = NE;
+    copy_h2d(path_off.ptr() + loc.n_seqs, &n_ent, 8);
+    launch(loc.n_seqs, PathEndsFunctor{ent_val.ptr(), path_off.ptr(), fs0.ptr(), fe0.ptr()});
+    return true;
+}
+
 // K10 paths of this rank's sequences against the graph: count, scan, write; first / last unitig of every path.
 template <int W> void GraphBuilder::Impl::walk() {
     TextCtx t = loc.ctx((int)k), g = G->ctx((int)k);
@@ -1095,6 +1211,7 @@ template <int W> void GraphBuilder::Impl::walk() {
     maybe_dest_valid = filter;
     if (filter) { maybe_dest.alloc((u64)U * 2); launch((u64)U * 2, MaybeDestFunctor{links.ptr(), maybe_dest.ptr()}); }
     fs0.alloc(U, true); fe0.alloc(U, true);
+    if (runs.size() && !walk_answers && n_owners <= 1 && G == &loc && PC <= 65535 && walk_copy<W>(PC)) { lap(&tm->paths); return; }
     // everything from here to the compaction is the walk's own: 4 bytes of staging per text position (configs[4]: 20 GB) go back to
     // the arena once the entries are compacted — they are compacted into the staging area's own first bytes
     const Arena::Mark walk_mark = Arena::device().mark();

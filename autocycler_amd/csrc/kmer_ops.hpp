@@ -31,6 +31,7 @@
 // indices), left as loops for wide keys (k > 123) where straight-line code for 8 or 16 words per operation inlined into every
 // kernel made the compile take tens of minutes.
 #define AC_UNROLL_W _Pragma("unroll (W <= 4 ? 4 : 1)")
+#define AC_UNROLL_FULL _Pragma("unroll")
 
 namespace ac {
 

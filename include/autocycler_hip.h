@@ -63,6 +63,7 @@ typedef struct {
     double union_pack, union_insert;   /* packing / inserting the union of all ranks' fragments */
     uint64_t n_local_distinct, n_fragments, fragment_bytes;
     double upload_device_ms;    /* ac_compress_build only: first H2D copy issued -> last chunk landed and packed (HIP events) */
+    uint64_t path_runs_copied, path_entries_walked;   /* the copying path walk: runs whose entries were copied, entries really walked (0, 0: plain walk) */
 } ac_timings;
 
 /* Replaces compress.rs:42-44.  k: --kmer (odd).  assembly_count: the reference's capacity hint

@@ -147,7 +147,7 @@ def test_high_diversity_table_growth(emu):
     assert time.time() - t0 < 60
 
 
-KNOB_SETTINGS = [{"AC_TABLE_SHIFT": "0"}, {"AC_TABLE_SHIFT": "2"}, {"AC_MINKEY_VARIANT": "0"}, {"AC_MINKEY_VARIANT": "1"}, {"AC_MINKEY_VARIANT": "2"}, {"AC_MINKEY_VARIANT": "2", "AC_MINKEY_PREFIX_BASES": "2"}, {"AC_PATH_CHUNK": "64"}, {"AC_PATH_FILTER": "0"}, {"AC_EXPAND_REWRITE_ALWAYS": "1"}, {"AC_SEED_RADIX_LIMIT": "0"}, {"AC_EXPAND_WAVE_LIMIT": "0"}, {"AC_EXPAND_WAVE_LIMIT": "1000000000"}, {"AC_HOST_PACK": "0"}, {"AC_SEED_PREFIX_SORT": "0"}, {"AC_SEED_PREFIX_BITS": "3"}, {"AC_SEED_PREFIX_BITS": "12"}, {"AC_REMAP_DIRECT": "1"}, {"AC_SEED_PREFIX_BITS": "3", "AC_SEED_MAX_GROUP": "2"}, {"AC_SEED_PREFIX_BITS": "6", "AC_SEED_MAX_GROUP": "1", "AC_SEED_RADIX_LIMIT": "1000000000"}, {"AC_SEED_PREFIX_SORT": "0", "AC_SEED_RADIX_LIMIT": "0"}, {"AC_PACK_OVERLAP": "0"}, {"AC_RENUM_TWO_PASS": "1"}, {"AC_RENUM_MAX_GROUP": "1"}, {"AC_RENUM_MAX_GROUP": "2"}, {"AC_DEGREE_FLAGS": "0"}, {"AC_DEGREE_REGION_CAP": "1"}, {"AC_DEGREE_REGION_CAP": "3"}, {"AC_DEGREE_FLAGS": "2"}, {"AC_UPLOAD_THREADS": "3"},
+KNOB_SETTINGS = [{"AC_TABLE_SHIFT": "0"}, {"AC_TABLE_SHIFT": "2"}, {"AC_MINKEY_VARIANT": "0"}, {"AC_MINKEY_VARIANT": "1"}, {"AC_MINKEY_VARIANT": "2"}, {"AC_MINKEY_VARIANT": "2", "AC_MINKEY_PREFIX_BASES": "2"}, {"AC_PATH_CHUNK": "64"}, {"AC_PATH_FILTER": "0"}, {"AC_EXPAND_REWRITE_ALWAYS": "1"}, {"AC_SEED_RADIX_LIMIT": "0"}, {"AC_EXPAND_WAVE_LIMIT": "0"}, {"AC_EXPAND_WAVE_LIMIT": "1000000000"}, {"AC_HOST_PACK": "0"}, {"AC_SEED_PREFIX_SORT": "0"}, {"AC_SEED_PREFIX_BITS": "3"}, {"AC_SEED_PREFIX_BITS": "12"}, {"AC_REMAP_DIRECT": "1"}, {"AC_PATH_COPY": "1"}, {"AC_PATH_COPY": "1", "AC_RUN_PIECE": "150"}, {"AC_PATH_COPY": "1", "AC_PATH_FILTER": "0"}, {"AC_SEED_PREFIX_BITS": "3", "AC_SEED_MAX_GROUP": "2"}, {"AC_SEED_PREFIX_BITS": "6", "AC_SEED_MAX_GROUP": "1", "AC_SEED_RADIX_LIMIT": "1000000000"}, {"AC_SEED_PREFIX_SORT": "0", "AC_SEED_RADIX_LIMIT": "0"}, {"AC_PACK_OVERLAP": "0"}, {"AC_RENUM_TWO_PASS": "1"}, {"AC_RENUM_MAX_GROUP": "1"}, {"AC_RENUM_MAX_GROUP": "2"}, {"AC_DEGREE_FLAGS": "0"}, {"AC_DEGREE_REGION_CAP": "1"}, {"AC_DEGREE_REGION_CAP": "3"}, {"AC_DEGREE_FLAGS": "2"}, {"AC_UPLOAD_THREADS": "3"},
                  {"AC_REMAP_BLOCK": "128"}, {"AC_INSERT_ADAPT": "0", "AC_INSERT_GROWTH": "4"}, {"AC_INSERT_CHUNK": "256", "AC_INSERT_WAVES": "1024"}]
 
 
@@ -178,6 +178,23 @@ def test_insert_phase_schedule_on_a_redundant_text(emu, monkeypatch, adapt):
     seqs, fn, hd = _redundant_set(10, 80_000, 2024)
     g, _, _ = parity_util.check_case(51, seqs, fn, hd, lib_path=emu)
     assert g.timings()["insert_launches"] == (3 if adapt == "1" else 5)
+
+
+@pytest.mark.parametrize("piece", ["0", "700"])
+def test_copying_path_walk_on_a_redundant_text(emu, monkeypatch, piece):
+    # K10c (AC_PATH_COPY=1, opt-in): the insert's followed runs are copied from the stretch they repeat instead of being walked; on ten
+    # similar assemblies most of the text lies in runs — the knob must engage (runs copied, fewer entries walked than there are) and
+    # change nothing.  piece: the runs cut into pieces of 700 positions
+    monkeypatch.setenv("AC_PATH_COPY", "1")
+    if piece != "0":
+        monkeypatch.setenv("AC_RUN_PIECE", piece)
+    seqs, fn, hd = _redundant_set(10, 80_000, 2024)
+    g, _, _ = parity_util.check_case(51, seqs, fn, hd, lib_path=emu)
+    tm = g.timings()
+    assert tm["path_runs_copied"] > 0 and 0 < tm["path_entries_walked"] < tm["n_path_entries"] // 2
+    monkeypatch.delenv("AC_PATH_COPY")
+    g, _, _ = parity_util.check_case(51, seqs, fn, hd, lib_path=emu)
+    assert g.timings()["path_runs_copied"] == 0
 
 
 def test_seed_kernel_long_unitigs_across_wavefronts(emu, monkeypatch):

@@ -157,7 +157,7 @@ def test_high_diversity_table_growth():
     assert time.time() - t0 < 120
 
 
-@pytest.mark.parametrize("knobs", [{"AC_TABLE_SHIFT": "0"}, {"AC_TABLE_SHIFT": "2"}, {"AC_MINKEY_VARIANT": "0"}, {"AC_MINKEY_VARIANT": "1"}, {"AC_MINKEY_VARIANT": "2"}, {"AC_MINKEY_VARIANT": "2", "AC_MINKEY_PREFIX_BASES": "2"}, {"AC_PATH_CHUNK": "64"}, {"AC_PATH_FILTER": "0"}, {"AC_EXPAND_REWRITE_ALWAYS": "1"}, {"AC_SEED_RADIX_LIMIT": "0"}, {"AC_SEQ_WRITER": "0"}, {"AC_SEQ_WRITER": "1"}, {"AC_EXPAND_WAVE_LIMIT": "0"}, {"AC_EXPAND_WAVE_LIMIT": "1000000000"}, {"AC_HOST_PACK": "0"}, {"AC_FILL_NOVEL": "0"}, {"AC_UPLOAD_OVERLAP": "0"}, {"AC_SEED_PREFIX_SORT": "0"}, {"AC_SEED_PREFIX_BITS": "3"}, {"AC_SEED_PREFIX_BITS": "12"}, {"AC_REMAP_DIRECT": "1"}, {"AC_SEED_PREFIX_BITS": "3", "AC_SEED_MAX_GROUP": "2"}, {"AC_SEED_PREFIX_BITS": "6", "AC_SEED_MAX_GROUP": "1", "AC_SEED_RADIX_LIMIT": "1000000000"}, {"AC_SEED_PREFIX_SORT": "0", "AC_SEED_RADIX_LIMIT": "0"}, {"AC_EXPAND_GROUP": "64"}, {"AC_EXPAND_GROUP": "8"}, {"AC_EXPAND_GROUP": "32", "AC_EXPAND_WAVE_LIMIT": "4"}, {"AC_PACK_OVERLAP": "0"}, {"AC_RENUM_TWO_PASS": "1"}, {"AC_RENUM_MAX_GROUP": "1"}, {"AC_DEGREE_FLAGS": "0"}, {"AC_DEGREE_REGION_CAP": "1"}, {"AC_DEGREE_REGION_CAP": "3"}, {"AC_DEGREE_FLAGS": "2"}, {"AC_UPLOAD_THREADS": "3"},
+@pytest.mark.parametrize("knobs", [{"AC_TABLE_SHIFT": "0"}, {"AC_TABLE_SHIFT": "2"}, {"AC_MINKEY_VARIANT": "0"}, {"AC_MINKEY_VARIANT": "1"}, {"AC_MINKEY_VARIANT": "2"}, {"AC_MINKEY_VARIANT": "2", "AC_MINKEY_PREFIX_BASES": "2"}, {"AC_PATH_CHUNK": "64"}, {"AC_PATH_FILTER": "0"}, {"AC_EXPAND_REWRITE_ALWAYS": "1"}, {"AC_SEED_RADIX_LIMIT": "0"}, {"AC_SEQ_WRITER": "0"}, {"AC_SEQ_WRITER": "1"}, {"AC_EXPAND_WAVE_LIMIT": "0"}, {"AC_EXPAND_WAVE_LIMIT": "1000000000"}, {"AC_HOST_PACK": "0"}, {"AC_FILL_NOVEL": "0"}, {"AC_UPLOAD_OVERLAP": "0"}, {"AC_SEED_PREFIX_SORT": "0"}, {"AC_SEED_PREFIX_BITS": "3"}, {"AC_SEED_PREFIX_BITS": "12"}, {"AC_REMAP_DIRECT": "1"}, {"AC_PATH_COPY": "1"}, {"AC_PATH_COPY": "1", "AC_RUN_PIECE": "150"}, {"AC_PATH_COPY": "1", "AC_PATH_FILTER": "0"}, {"AC_SEED_PREFIX_BITS": "3", "AC_SEED_MAX_GROUP": "2"}, {"AC_SEED_PREFIX_BITS": "6", "AC_SEED_MAX_GROUP": "1", "AC_SEED_RADIX_LIMIT": "1000000000"}, {"AC_SEED_PREFIX_SORT": "0", "AC_SEED_RADIX_LIMIT": "0"}, {"AC_EXPAND_GROUP": "64"}, {"AC_EXPAND_GROUP": "8"}, {"AC_EXPAND_GROUP": "32", "AC_EXPAND_WAVE_LIMIT": "4"}, {"AC_PACK_OVERLAP": "0"}, {"AC_RENUM_TWO_PASS": "1"}, {"AC_RENUM_MAX_GROUP": "1"}, {"AC_DEGREE_FLAGS": "0"}, {"AC_DEGREE_REGION_CAP": "1"}, {"AC_DEGREE_REGION_CAP": "3"}, {"AC_DEGREE_FLAGS": "2"}, {"AC_UPLOAD_THREADS": "3"},
                                    {"AC_REMAP_BLOCK": "128"}, {"AC_INSERT_ADAPT": "0", "AC_INSERT_GROWTH": "4"},
                                    {"AC_INSERT_CHUNK": "256", "AC_INSERT_WAVES": "1024"}],
                          ids=lambda d: ",".join(f"{a}={b}" for a, b in d.items()))
@@ -170,6 +170,19 @@ def test_tuning_knobs_do_not_change_the_result(monkeypatch, knobs):
         parity_util.check_case(k, seqs, fn, hd)
     seqs, fn, hd = _synth_case(6, 60_000, 3_000, 1e-3, 1e-4, 99)
     parity_util.check_case(51, seqs, fn, hd)
+
+
+@pytest.mark.parametrize("piece", ["0", "700"])
+def test_copying_path_walk_on_a_redundant_text(monkeypatch, piece):
+    # K10c (AC_PATH_COPY=1, opt-in): most of ten similar assemblies lies in followed runs, whose path entries are copied, not walked
+    monkeypatch.setenv("AC_PATH_COPY", "1")
+    if piece != "0":
+        monkeypatch.setenv("AC_RUN_PIECE", piece)
+    for rep in range(3):      # (which runs the insert follows depends on the order its wavefronts ran in)
+        seqs, fn, hd = _synth_case(10, 80_000, 2_000, 2e-4, 2e-5, 2024 + rep)
+        g, _, _ = parity_util.check_case(51, seqs, fn, hd)
+        tm = g.timings()
+        assert tm["path_runs_copied"] > 0 and 0 < tm["path_entries_walked"] < tm["n_path_entries"] // 2
 
 
 @pytest.mark.parametrize("adapt", ["1", "0"])

@@ -737,7 +737,7 @@ int ac_timings_get(const ac_graph* g, ac_timings* o) {
     o->fragments = t.fragments; o->union_pack = t.union_pack; o->union_insert = t.union_insert;
     o->n_local_distinct = t.n_local_distinct; o->n_fragments = t.n_fragments; o->fragment_bytes = t.fragment_bytes;
     o->upload_device_ms = t.upload_device_ms;
-    o->path_runs_copied = t.path_runs_copied; o->path_entries_walked = t.path_entries_walked;
+    o->path_runs_copied = t.path_runs_copied; o->path_entries_walked = t.path_entries_walked; o->position_retries = t.position_retries;
     return 0;
 }
 // The same for a caller that was compiled against another version of the header: at most out_size bytes are written (the struct only

@@ -26,6 +26,7 @@
 namespace ac {
 
 struct DeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct NeedExactPositions {};      // thrown by the tail, caught by GraphBuilder::build (graph_build.hip)
 
 #ifndef AC_EMU
 #define AC_HIP_CHECK(expr)                                                                              \

@@ -399,6 +399,8 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : -1; }      // -1 = automatic
 [[maybe_unused]] static bool path_copy() { const char* e = getenv("AC_PATH_COPY"); return e ? atoi(e) != 0 : false; }      // 1: paths of followed runs are copied from the stretch they repeat
 [[maybe_unused]] static u64 run_piece() { const char* e = getenv("AC_RUN_PIECE"); const long v = e ? atol(e) : 0; return v > 0 ? (u64)v : 4096; }      // positions per copied piece of a run (RunFilterFunctor)
+// AC_POS_CAP: occurrences further than this from both ends of their sequence do not lower a unitig's smallest positions (0 = all do)
+[[maybe_unused]] static u32 pos_cap() { const char* e = getenv("AC_POS_CAP"); const long v = e ? atol(e) : 65536; return v < 0 ? 0u : (u32)std::min<long>(v, 0x3FFFFFFF); }
 [[maybe_unused]] static bool path_filter() { const char* e = getenv("AC_PATH_FILTER"); return e ? atoi(e) != 0 : true; }   // smallest positions only for possible expand_repeats destinations
 // AC_PATH_DIAG (skips the walk's depth atomics / position updates to price them: the result is WRONG when set) only exists in
 // builds made with -DAC_MEASUREMENT_KNOBS; the shipped library ignores the variable.
@@ -545,6 +547,8 @@ struct GraphBuilder::Impl {
     // per-occurrence quantities from the walk over loc
     DBuf<u32> depth, minpos_fwd, minpos_rev; DBuf<u64> path_off; DBuf<int32_t> ent_val; u64 n_ent = 0;
     DBuf<u8> fs0, fe0;
+    // single-device builds: smallest positions beyond it are kept as a lower bound only (kernels_tail.inc exp_avoid_start_of_path); all ones = exact
+    u32 pos_cap_now = 0xFFFFFFFFu; bool exact_positions = false;
     DBuf<u8> maybe_dest; bool maybe_dest_valid = false;      // (unitig, side) that may become an expand_repeats destination (walk's position filter)
     // fragments of a sharded build
     DBuf<u8> frag_text; DBuf<u64> frag_meta; u64 frag_bytes = 0, n_frags = 0;
@@ -1162,7 +1166,7 @@ template <int W> bool GraphBuilder::Impl::walk_copy(u32 PC) {
     launch(U, WalkInfoFunctor{uc, filter ? maybe_dest.ptr() : nullptr, uinfo.ptr()});
     launch(NW, PathWalkFunctor<W>{t, t, tb, nv, uc, uinfo.ptr(), wlinks.ptr(), PC, stage.ptr(), wcount.ptr(), seq_tid.ptr(), seq_j.ptr(),
                                  depth.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), counters.ptr() + 4, filter ? maybe_dest.ptr() : nullptr,
-                                 0, nullptr, NW, w_begin.ptr(), w_end.ptr(), stage_off.ptr()});
+                                 pos_cap_now, 0, nullptr, NW, w_begin.ptr(), w_end.ptr(), stage_off.ptr()});
     exclusive_scan_u64(wcount.ptr(), woff.ptr(), NW + 1);
     const u64 NE = read_scalar(woff.ptr() + NW);      // walked entries
     DBuf<int32_t> ent(NE); DBuf<u64> ent_pos(NE), ent_end(NE); DBuf<u8> ent_want(NE);
@@ -1187,7 +1191,7 @@ template <int W> bool GraphBuilder::Impl::walk_copy(u32 PC) {
     int32_t* const out_ptr = ent_val.ptr();
     launch(NW, GapOutFunctor{ent.ptr(), wcount.ptr(), woff.ptr(), wfirst.ptr(), w_gap.ptr(), segoff.ptr(), copies.ptr(), out_ptr, depth.ptr()});
     launch_full(R * 32, RunOutFunctor<32, 1>{rr.ptr(), R, ra.ptr(), rcnt.ptr(), segoff.ptr(), ent.ptr(), ent_pos.ptr(), ent_end.ptr(), ulen.ptr(),
-                                             ent_want.ptr(), t, rseq.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), out_ptr});
+                                             ent_want.ptr(), t, rseq.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), out_ptr, pos_cap_now});
     launch(loc.n_seqs, PathOffCopyFunctor{seq_tid.ptr(), seq_j.ptr(), woff.ptr(), wfirst.ptr(), w_gap.ptr(), segoff.ptr(), path_off.ptr()});
     tm->n_path_entries = n_ent;
     tm->path_runs_copied = R; tm->path_entries_walked = NE;
@@ -1205,7 +1209,13 @@ template <int W> void GraphBuilder::Impl::walk() {
     const u32 PC = path_chunk(N, U);
     u64 n_walkers = (loc.n_text + PC - 1) / PC;
     depth.alloc(U, true); minpos_fwd.alloc(U); minpos_rev.alloc(U);
-    minpos_fwd.fill_bytes(0xFF); minpos_rev.fill_bytes(0xFF);
+    // (sharded builds keep exact positions: a repeat of the build would have to be agreed between the ranks)
+    pos_cap_now = (exact_positions || walk_answers || n_owners > 1 || G != &loc || pos_cap() == 0) ? 0xFFFFFFFFu : pos_cap();
+    if (pos_cap_now == 0xFFFFFFFFu) { minpos_fwd.fill_bytes(0xFF); minpos_rev.fill_bytes(0xFF); }
+    else {
+        launch(U, FillU32Functor{minpos_fwd.ptr(), (pos_cap_now + 1) | POS_BOUND});
+        launch(U, FillU32Functor{minpos_rev.ptr(), (pos_cap_now + 1) | POS_BOUND});
+    }
     path_off.alloc((u64)loc.n_seqs + 1);
     const bool filter = path_filter();
     maybe_dest_valid = filter;
@@ -1224,7 +1234,7 @@ template <int W> void GraphBuilder::Impl::walk() {
     launch(U, WalkInfoFunctor{uc, filter ? maybe_dest.ptr() : nullptr, uinfo.ptr()});
     launch(n_walkers, PathWalkFunctor<W>{t, g, tb, nv, uc, uinfo.ptr(), wlinks.ptr(), PC, stage.ptr(), wcount.ptr(), seq_tid.ptr(), seq_j.ptr(),
                                         depth.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), counters.ptr() + 4, filter ? maybe_dest.ptr() : nullptr,
-                                        path_diag(), walk_answers, n_walkers});
+                                        pos_cap_now, path_diag(), walk_answers, n_walkers});
     exclusive_scan_u64(wcount.ptr(), woff.ptr(), n_walkers + 1);
     n_ent = read_scalar(woff.ptr() + n_walkers);
     launch(loc.n_seqs, PathOffFunctor{seq_tid.ptr(), seq_j.ptr(), woff.ptr(), path_off.ptr()});
@@ -1497,6 +1507,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     }
     side.sync();                                    // ... and the copies: everything above has landed
     if (loc.pack_bad.size()) loc.verify_alphabet(pack_bad);      // before any internal check: a text with foreign bytes explains them all
+    if (errs[7] & 128u) throw NeedExactPositions();      // (before anything else: a repeat of the build settles it)
     if (errs[7]) throw DeviceError("internal error: expand_repeats pool overflow");
     if (errs[3] || errs[4])
         throw DeviceError("internal error: inconsistent unitig ends (codes " + std::to_string(errs[3]) + "/" + std::to_string(errs[4]) + ")");
@@ -2203,11 +2214,29 @@ void GraphBuilder::build(uint32_t assembly_count_hint, FinalGraph* out) {
     m.check_sizes(m.loc);
     m.pack_overlapped(assembly_count_hint);
     m.lap(&tm_.pack);
-    AC_DISPATCH_W(table, (*impl_))
-    AC_DISPATCH_W(degrees, (*impl_))
-    AC_DISPATCH_W(unitigs, (*impl_))
-    AC_DISPATCH_W(walk, (*impl_))
-    AC_DISPATCH_W(tail, (*impl_, out, true, true))
+    const Arena::Mark packed = Arena::device().mark();
+    for (;;) {
+        try {
+            AC_DISPATCH_W(table, (*impl_))
+            AC_DISPATCH_W(degrees, (*impl_))
+            AC_DISPATCH_W(unitigs, (*impl_))
+            AC_DISPATCH_W(walk, (*impl_))
+            AC_DISPATCH_W(tail, (*impl_, out, true, true))
+            break;
+        } catch (const NeedExactPositions&) {
+            // expand_repeats met a common sequence longer than the bound the walk kept for a destination's smallest position
+            // (exp_avoid_start_of_path): everything behind the packed text again, with exact positions
+            if (m.exact_positions) throw DeviceError("internal error: exact positions were not exact");
+            m.exact_positions = true;
+            {   // the stage times and counts are those of the attempt that delivered
+                BuildTimings again = BuildTimings();
+                again.h2d = tm_.h2d; again.pack = tm_.pack; again.graph_hint = tm_.graph_hint; again.position_retries = tm_.position_retries + 1;
+                tm_ = again;
+            }
+            stream_sync();
+            Arena::device().rewind(packed);
+        }
+    }
 #ifndef AC_EMU
     if (HostStager::get().timed) {      // host entry: first copy issued -> last chunk packed, on the device's clock
         float ms = 0;

@@ -39,6 +39,7 @@ struct BuildTimings {                   // seconds; device stages are bracketed 
     double union_pack = 0, union_insert = 0;   // packing / inserting the union of all ranks' fragments
     uint64_t n_local_distinct = 0, n_fragments = 0, fragment_bytes = 0;
     double upload_device_ms = 0;        // host entry: first copy issued -> last chunk landed and packed (HIP events)
+    uint32_t position_retries = 0;      // builds repeated with exact smallest positions (AC_POS_CAP; kernels_tail.inc exp_avoid_start_of_path)
     uint64_t path_runs_copied = 0, path_entries_walked = 0;   // K10c: followed runs whose path entries were copied / entries that were really walked (0 / 0: the plain walk)
 };
 

@@ -64,6 +64,7 @@ typedef struct {
     uint64_t n_local_distinct, n_fragments, fragment_bytes;
     double upload_device_ms;    /* ac_compress_build only: first H2D copy issued -> last chunk landed and packed (HIP events) */
     uint64_t path_runs_copied, path_entries_walked;   /* the copying path walk: runs whose entries were copied, entries really walked (0, 0: plain walk) */
+    uint64_t position_retries;   /* builds repeated with exact smallest positions because expand_repeats met a common sequence longer than the bound kept (AC_POS_CAP) */
 } ac_timings;
 
 /* Replaces compress.rs:42-44.  k: --kmer (odd).  assembly_count: the reference's capacity hint

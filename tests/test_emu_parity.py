@@ -147,7 +147,7 @@ def test_high_diversity_table_growth(emu):
     assert time.time() - t0 < 60
 
 
-KNOB_SETTINGS = [{"AC_TABLE_SHIFT": "0"}, {"AC_TABLE_SHIFT": "2"}, {"AC_MINKEY_VARIANT": "0"}, {"AC_MINKEY_VARIANT": "1"}, {"AC_MINKEY_VARIANT": "2"}, {"AC_MINKEY_VARIANT": "2", "AC_MINKEY_PREFIX_BASES": "2"}, {"AC_PATH_CHUNK": "64"}, {"AC_PATH_FILTER": "0"}, {"AC_EXPAND_REWRITE_ALWAYS": "1"}, {"AC_SEED_RADIX_LIMIT": "0"}, {"AC_EXPAND_WAVE_LIMIT": "0"}, {"AC_EXPAND_WAVE_LIMIT": "1000000000"}, {"AC_HOST_PACK": "0"}, {"AC_SEED_PREFIX_SORT": "0"}, {"AC_SEED_PREFIX_BITS": "3"}, {"AC_SEED_PREFIX_BITS": "12"}, {"AC_REMAP_DIRECT": "1"}, {"AC_PATH_COPY": "1"}, {"AC_PATH_COPY": "1", "AC_RUN_PIECE": "150"}, {"AC_PATH_COPY": "1", "AC_PATH_FILTER": "0"}, {"AC_SEED_PREFIX_BITS": "3", "AC_SEED_MAX_GROUP": "2"}, {"AC_SEED_PREFIX_BITS": "6", "AC_SEED_MAX_GROUP": "1", "AC_SEED_RADIX_LIMIT": "1000000000"}, {"AC_SEED_PREFIX_SORT": "0", "AC_SEED_RADIX_LIMIT": "0"}, {"AC_PACK_OVERLAP": "0"}, {"AC_RENUM_TWO_PASS": "1"}, {"AC_RENUM_MAX_GROUP": "1"}, {"AC_RENUM_MAX_GROUP": "2"}, {"AC_DEGREE_FLAGS": "0"}, {"AC_DEGREE_REGION_CAP": "1"}, {"AC_DEGREE_REGION_CAP": "3"}, {"AC_DEGREE_FLAGS": "2"}, {"AC_UPLOAD_THREADS": "3"},
+KNOB_SETTINGS = [{"AC_TABLE_SHIFT": "0"}, {"AC_TABLE_SHIFT": "2"}, {"AC_MINKEY_VARIANT": "0"}, {"AC_MINKEY_VARIANT": "1"}, {"AC_MINKEY_VARIANT": "2"}, {"AC_MINKEY_VARIANT": "2", "AC_MINKEY_PREFIX_BASES": "2"}, {"AC_PATH_CHUNK": "64"}, {"AC_PATH_FILTER": "0"}, {"AC_EXPAND_REWRITE_ALWAYS": "1"}, {"AC_SEED_RADIX_LIMIT": "0"}, {"AC_EXPAND_WAVE_LIMIT": "0"}, {"AC_EXPAND_WAVE_LIMIT": "1000000000"}, {"AC_HOST_PACK": "0"}, {"AC_SEED_PREFIX_SORT": "0"}, {"AC_SEED_PREFIX_BITS": "3"}, {"AC_SEED_PREFIX_BITS": "12"}, {"AC_REMAP_DIRECT": "1"}, {"AC_POS_CAP": "0"}, {"AC_POS_CAP": "3"}, {"AC_POS_CAP": "200", "AC_PATH_COPY": "1"}, {"AC_PATH_COPY": "1"}, {"AC_PATH_COPY": "1", "AC_RUN_PIECE": "150"}, {"AC_PATH_COPY": "1", "AC_PATH_FILTER": "0"}, {"AC_SEED_PREFIX_BITS": "3", "AC_SEED_MAX_GROUP": "2"}, {"AC_SEED_PREFIX_BITS": "6", "AC_SEED_MAX_GROUP": "1", "AC_SEED_RADIX_LIMIT": "1000000000"}, {"AC_SEED_PREFIX_SORT": "0", "AC_SEED_RADIX_LIMIT": "0"}, {"AC_PACK_OVERLAP": "0"}, {"AC_RENUM_TWO_PASS": "1"}, {"AC_RENUM_MAX_GROUP": "1"}, {"AC_RENUM_MAX_GROUP": "2"}, {"AC_DEGREE_FLAGS": "0"}, {"AC_DEGREE_REGION_CAP": "1"}, {"AC_DEGREE_REGION_CAP": "3"}, {"AC_DEGREE_FLAGS": "2"}, {"AC_UPLOAD_THREADS": "3"},
                  {"AC_REMAP_BLOCK": "128"}, {"AC_INSERT_ADAPT": "0", "AC_INSERT_GROWTH": "4"}, {"AC_INSERT_CHUNK": "256", "AC_INSERT_WAVES": "1024"}]
 
 
@@ -178,6 +178,28 @@ def test_insert_phase_schedule_on_a_redundant_text(emu, monkeypatch, adapt):
     seqs, fn, hd = _redundant_set(10, 80_000, 2024)
     g, _, _ = parity_util.check_case(51, seqs, fn, hd, lib_path=emu)
     assert g.timings()["insert_launches"] == (3 if adapt == "1" else 5)
+
+
+@pytest.mark.parametrize("copy", ["0", "1"])
+def test_position_bound_and_the_repeat_with_exact_positions(emu, monkeypatch, copy):
+    # The walk only notes smallest positions within AC_POS_CAP of a sequence end; beyond it expand_repeats sees a lower bound, and a
+    # common sequence longer than the bound repeats the build with exact positions (exp_avoid_start_of_path).  With a bound of 1..40
+    # positions the repeat must happen on some of these inputs and never change the result; with the shipped bound it never happens here.
+    monkeypatch.setenv("AC_PATH_COPY", copy)
+    retried = 0
+    for cap in ("1", "7", "40"):
+        monkeypatch.setenv("AC_POS_CAP", cap)
+        for k, seed in ((11, 7), (31, 11), (51, 13), (51, 21)):
+            seqs, fn, hd = seqgen.make_case(seed, k)
+            g, _, _ = parity_util.check_case(k, seqs, fn, hd, lib_path=emu)
+            retried += g.timings()["position_retries"]
+        seqs, fn, hd = _redundant_set(6, 30_000, 77)
+        g, _, _ = parity_util.check_case(51, seqs, fn, hd, lib_path=emu)
+        retried += g.timings()["position_retries"]
+    assert retried > 0
+    monkeypatch.delenv("AC_POS_CAP")
+    g, _, _ = parity_util.check_case(51, seqs, fn, hd, lib_path=emu)
+    assert g.timings()["position_retries"] == 0
 
 
 @pytest.mark.parametrize("piece", ["0", "700"])

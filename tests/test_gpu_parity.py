@@ -157,7 +157,7 @@ def test_high_diversity_table_growth():
     assert time.time() - t0 < 120
 
 
-@pytest.mark.parametrize("knobs", [{"AC_TABLE_SHIFT": "0"}, {"AC_TABLE_SHIFT": "2"}, {"AC_MINKEY_VARIANT": "0"}, {"AC_MINKEY_VARIANT": "1"}, {"AC_MINKEY_VARIANT": "2"}, {"AC_MINKEY_VARIANT": "2", "AC_MINKEY_PREFIX_BASES": "2"}, {"AC_PATH_CHUNK": "64"}, {"AC_PATH_FILTER": "0"}, {"AC_EXPAND_REWRITE_ALWAYS": "1"}, {"AC_SEED_RADIX_LIMIT": "0"}, {"AC_SEQ_WRITER": "0"}, {"AC_SEQ_WRITER": "1"}, {"AC_EXPAND_WAVE_LIMIT": "0"}, {"AC_EXPAND_WAVE_LIMIT": "1000000000"}, {"AC_HOST_PACK": "0"}, {"AC_FILL_NOVEL": "0"}, {"AC_UPLOAD_OVERLAP": "0"}, {"AC_SEED_PREFIX_SORT": "0"}, {"AC_SEED_PREFIX_BITS": "3"}, {"AC_SEED_PREFIX_BITS": "12"}, {"AC_REMAP_DIRECT": "1"}, {"AC_PATH_COPY": "1"}, {"AC_PATH_COPY": "1", "AC_RUN_PIECE": "150"}, {"AC_PATH_COPY": "1", "AC_PATH_FILTER": "0"}, {"AC_SEED_PREFIX_BITS": "3", "AC_SEED_MAX_GROUP": "2"}, {"AC_SEED_PREFIX_BITS": "6", "AC_SEED_MAX_GROUP": "1", "AC_SEED_RADIX_LIMIT": "1000000000"}, {"AC_SEED_PREFIX_SORT": "0", "AC_SEED_RADIX_LIMIT": "0"}, {"AC_EXPAND_GROUP": "64"}, {"AC_EXPAND_GROUP": "8"}, {"AC_EXPAND_GROUP": "32", "AC_EXPAND_WAVE_LIMIT": "4"}, {"AC_PACK_OVERLAP": "0"}, {"AC_RENUM_TWO_PASS": "1"}, {"AC_RENUM_MAX_GROUP": "1"}, {"AC_DEGREE_FLAGS": "0"}, {"AC_DEGREE_REGION_CAP": "1"}, {"AC_DEGREE_REGION_CAP": "3"}, {"AC_DEGREE_FLAGS": "2"}, {"AC_UPLOAD_THREADS": "3"},
+@pytest.mark.parametrize("knobs", [{"AC_TABLE_SHIFT": "0"}, {"AC_TABLE_SHIFT": "2"}, {"AC_MINKEY_VARIANT": "0"}, {"AC_MINKEY_VARIANT": "1"}, {"AC_MINKEY_VARIANT": "2"}, {"AC_MINKEY_VARIANT": "2", "AC_MINKEY_PREFIX_BASES": "2"}, {"AC_PATH_CHUNK": "64"}, {"AC_PATH_FILTER": "0"}, {"AC_EXPAND_REWRITE_ALWAYS": "1"}, {"AC_SEED_RADIX_LIMIT": "0"}, {"AC_SEQ_WRITER": "0"}, {"AC_SEQ_WRITER": "1"}, {"AC_EXPAND_WAVE_LIMIT": "0"}, {"AC_EXPAND_WAVE_LIMIT": "1000000000"}, {"AC_HOST_PACK": "0"}, {"AC_FILL_NOVEL": "0"}, {"AC_UPLOAD_OVERLAP": "0"}, {"AC_SEED_PREFIX_SORT": "0"}, {"AC_SEED_PREFIX_BITS": "3"}, {"AC_SEED_PREFIX_BITS": "12"}, {"AC_REMAP_DIRECT": "1"}, {"AC_POS_CAP": "0"}, {"AC_POS_CAP": "3"}, {"AC_POS_CAP": "200", "AC_PATH_COPY": "1"}, {"AC_PATH_COPY": "1"}, {"AC_PATH_COPY": "1", "AC_RUN_PIECE": "150"}, {"AC_PATH_COPY": "1", "AC_PATH_FILTER": "0"}, {"AC_SEED_PREFIX_BITS": "3", "AC_SEED_MAX_GROUP": "2"}, {"AC_SEED_PREFIX_BITS": "6", "AC_SEED_MAX_GROUP": "1", "AC_SEED_RADIX_LIMIT": "1000000000"}, {"AC_SEED_PREFIX_SORT": "0", "AC_SEED_RADIX_LIMIT": "0"}, {"AC_EXPAND_GROUP": "64"}, {"AC_EXPAND_GROUP": "8"}, {"AC_EXPAND_GROUP": "32", "AC_EXPAND_WAVE_LIMIT": "4"}, {"AC_PACK_OVERLAP": "0"}, {"AC_RENUM_TWO_PASS": "1"}, {"AC_RENUM_MAX_GROUP": "1"}, {"AC_DEGREE_FLAGS": "0"}, {"AC_DEGREE_REGION_CAP": "1"}, {"AC_DEGREE_REGION_CAP": "3"}, {"AC_DEGREE_FLAGS": "2"}, {"AC_UPLOAD_THREADS": "3"},
                                    {"AC_REMAP_BLOCK": "128"}, {"AC_INSERT_ADAPT": "0", "AC_INSERT_GROWTH": "4"},
                                    {"AC_INSERT_CHUNK": "256", "AC_INSERT_WAVES": "1024"}],
                          ids=lambda d: ",".join(f"{a}={b}" for a, b in d.items()))
@@ -170,6 +170,26 @@ def test_tuning_knobs_do_not_change_the_result(monkeypatch, knobs):
         parity_util.check_case(k, seqs, fn, hd)
     seqs, fn, hd = _synth_case(6, 60_000, 3_000, 1e-3, 1e-4, 99)
     parity_util.check_case(51, seqs, fn, hd)
+
+
+@pytest.mark.parametrize("copy", ["0", "1"])
+def test_position_bound_and_the_repeat_with_exact_positions(monkeypatch, copy):
+    # smallest positions beyond AC_POS_CAP are a lower bound; a common sequence longer than the bound repeats the build with exact ones
+    monkeypatch.setenv("AC_PATH_COPY", copy)
+    retried = 0
+    for cap in ("1", "7", "40"):
+        monkeypatch.setenv("AC_POS_CAP", cap)
+        for k, seed in ((11, 7), (51, 13), (51, 21)):
+            seqs, fn, hd = seqgen.make_case(seed, k)
+            g, _, _ = parity_util.check_case(k, seqs, fn, hd)
+            retried += g.timings()["position_retries"]
+        seqs, fn, hd = _synth_case(6, 30_000, 1_500, 1e-3, 1e-4, 77)
+        g, _, _ = parity_util.check_case(51, seqs, fn, hd)
+        retried += g.timings()["position_retries"]
+    assert retried > 0
+    monkeypatch.delenv("AC_POS_CAP")
+    g, _, _ = parity_util.check_case(51, seqs, fn, hd)
+    assert g.timings()["position_retries"] == 0
 
 
 @pytest.mark.parametrize("piece", ["0", "700"])

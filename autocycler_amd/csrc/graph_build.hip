@@ -377,6 +377,11 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 //   AC_PATH_CHUNK     text positions per path walker (default: 5 x the mean unitig length, a power of two in [64, 2048]).
 //   AC_PATH_FILTER    1 (default): the walk keeps smallest positions only for unitig sides that can become expand_repeats
 //                     destinations.
+//   AC_POS_CAP        (65536) single-device builds: occurrences further than this from both ends of their sequence do not lower a
+//                     unitig's smallest positions; beyond it expand_repeats works with a lower bound and, where that cannot decide,
+//                     the build is repeated with exact positions (kernels_tail.inc exp_avoid_start_of_path).  0: every occurrence counts.
+//   AC_PATH_COPY      1: the copying path walk (K10c, walk_copy: followed runs are copied from the stretch they repeat, the text between
+//                     them is walked); AC_RUN_PIECE (4096): positions per copied piece of a run (tests).  Default 0: a small win only.
 //   AC_REMAP_BLOCK    path entries per wavefront in the final renumbering; AC_REMAP_DIRECT=1: its stores go straight to the pinned result block (measured equal).
 //   AC_INSERT_CHUNK / AC_INSERT_GROWTH / AC_INSERT_WAVES   insert phases: longest wavefront chunk, prefix growth factor, wavefronts per phase;
 //   AC_INSERT_ADAPT (default 1) / AC_INSERT_CHUNK_REST      redundant text: everything after the second phase in one launch, and its longest chunk (16384).
@@ -396,6 +401,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 //   AC_UPLOAD_MASK    1: the packed upload also sends the 1-bit mask plane (0.375 B per base instead of 0.25; default: MaskTableFunctor).
 //   AC_NO_MAILBOX     (read once) small read-backs through hipMemcpyAsync + synchronise instead of the mapped mailbox page.
 //   AC_INSERT_PROFILE (read once) per-wavefront cycle split of every insert launch on stderr (measurement).
+//   AC_DEBUG_LAUNCH   (read once) every functor launch announced on stderr and waited for (device_rt.hpp); AC_DEBUG_ARENA: arena and copy-walk figures.
 [[maybe_unused]] static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : -1; }      // -1 = automatic
 [[maybe_unused]] static bool path_copy() { const char* e = getenv("AC_PATH_COPY"); return e ? atoi(e) != 0 : false; }      // 1: paths of followed runs are copied from the stretch they repeat
 [[maybe_unused]] static u64 run_piece() { const char* e = getenv("AC_RUN_PIECE"); const long v = e ? atol(e) : 0; return v > 0 ? (u64)v : 4096; }      // positions per copied piece of a run (RunFilterFunctor)

@@ -80,27 +80,28 @@ struct Table {
     u32 my_owner;     // inserts of other keys are skipped, lookups of other keys answer "not here" (their owner answers)
     u64* sflags;      // during the insert only (optional): two SIBLING bits per slot (sib_note); MarkFunctor moves them to text positions
     u64* full_at;     // during the insert only (optional): ~(smallest text position whose insert found the table full), by atomic max
-    // during the insert only (optional): the followed runs of at least RUN_MIN positions, three words each — [first position p of the
-    // run | its length n | the position q it repeats, bit 63 = in the same orientation]: position p + i repeats q + i (same) or
-    // q - i (reverse complement), 0 <= i < n.  The path walk copies the unitig paths of such stretches instead of walking them (K10c).
-    // The list is split into RUN_REGIONS regions of run_cap records with a counter each (a wavefront uses the region its chunk number
-    // selects): half a million appends to ONE counter serialise on its cache line — they cost the insert 1.2 ms on config C.
-    u64* runs; u32* run_count; u32 run_cap;
+    // during the one-launch rest of a redundant text only (optional): the followed runs of at least RUN_MIN positions, three words each —
+    // [first position p of the run | its length n | the position q it repeats, bit 63 = in the same orientation]: position p + i repeats
+    // q + i (same) or q - i (reverse complement), 0 <= i < n.  The path walk copies the unitig paths of such stretches instead of walking
+    // them (K10c).  A wavefront owns a row of RUN_ROW records (its chunk of <= 16384 positions cannot hold more runs) and counts them in
+    // a register: no atomics, and rows in wavefront order ARE the runs in text order (a shared list cost the insert half a million
+    // atomic appends — 1.2 ms on ONE counter, 0.03 ms on 256 — and the path stage a sort).  run_row0 = the row of this launch's wavefront 0.
+    u64* runs; u32* run_count; u64 run_row0;
 };
 static const u64 RUN_MIN = 128;
-static const u32 RUN_REGIONS = 256;
-AC_D void run_note(const Table& tb, u64 region, u64 pj, u64 qj, bool same, u64 n) {      // the run the follow from (pj, qj) verified: positions pj + 1 .. pj + n
-    if (!tb.runs || n < RUN_MIN) return;
-    const u32 rg = (u32)(region % RUN_REGIONS);
-    const u32 idx = atomic_add32(tb.run_count + rg, 1u);
-    if (idx >= tb.run_cap) return;      // (a run that is not on the list is walked like any other text)
-    u64* rec = tb.runs + 3 * ((u64)rg * tb.run_cap + idx);
+static const u32 RUN_ROW = 128;
+// the run the follow from (pj, qj) verified: positions pj + 1 .. pj + n.  `noted` = the calling wavefront's count so far (one lane calls)
+AC_D void run_note(const Table& tb, u64 wave, u32& noted, u64 pj, u64 qj, bool same, u64 n) {
+    if (!tb.runs || n < RUN_MIN || noted >= RUN_ROW) return;      // (a run that is not on the list is walked like any other text)
+    u64* rec = tb.runs + 3 * ((tb.run_row0 + wave) * RUN_ROW + noted);
+    noted++;
     // (the anchor itself repeats qj: with it on board two runs that a single-lane opener joins lie back to back, and no walker has to
     // look the one position between them up — unless qj is not a first occurrence: then it stays outside)
     const bool with_anchor = ((tb.novel[qj >> 6] >> (qj & 63)) & 1) != 0;
     if (with_anchor) { rec[0] = pj; rec[1] = n + 1; rec[2] = qj | ((u64)(same ? 1 : 0) << 63); }
     else { rec[0] = pj + 1; rec[1] = n; rec[2] = (same ? qj + 1 : qj - 1) | ((u64)(same ? 1 : 0) << 63); }
 }
+AC_D void run_note_done(const Table& tb, u64 wave, u32 noted) { if (tb.runs) tb.run_count[tb.run_row0 + wave] = noted; }
 // Sibling bits.  Two k-mers of one middle are siblings in x (same first base, read in the orientation in which the middle is
 // canonical: key_place) or in y (same last base); a k-mer WITHOUT a sibling in x / y is the only successor / predecessor its text
 // neighbour can have, which the degree pass (DegreeLightFunctor) uses to skip the probe.  The insert finds the siblings for free:
@@ -403,7 +404,23 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 //   AC_INSERT_PROFILE (read once) per-wavefront cycle split of every insert launch on stderr (measurement).
 //   AC_DEBUG_LAUNCH   (read once) every functor launch announced on stderr and waited for (device_rt.hpp); AC_DEBUG_ARENA: arena and copy-walk figures.
 [[maybe_unused]] static int minkey_variant() { const char* e = getenv("AC_MINKEY_VARIANT"); return e ? atoi(e) : -1; }      // -1 = automatic
-[[maybe_unused]] static bool path_copy() { const char* e = getenv("AC_PATH_COPY"); return e ? atoi(e) != 0 : false; }      // 1: paths of followed runs are copied from the stretch they repeat
+// AC_PATH_COPY: 0 never / 1 whenever a redundant text has a one-launch rest / unset: when the cost model below says it pays
+[[maybe_unused]] static int path_copy() { const char* e = getenv("AC_PATH_COPY"); return e ? (atoi(e) != 0 ? 1 : 0) : 2; }
+// The copying path walk (K10c) against the plain one, as measured on MI355X (profiles/r09e_ab_path_copy_rows.txt): the
+// plain walk costs ~70 ps per path entry (its depth atomic, successor gather and staging), the copying walk ~17 ps per copied entry plus
+// ~0.25 ms of launches and read-backs, and the insert ~0.3 ps per text position for ending runs where their source stops being a first
+// occurrence; the first two assemblies' worth of text (the phases before the one-launch rest) is walked either way.  Path entries are
+// estimated from what the insert knows when it decides: of the second assembly's worth of text a share r2 was new k-mers, ~k per variant
+// site, and every site of every one of the A assemblies cuts the unitigs of the final graph about twice.  The estimate is rough (config C:
+// 13.8 M for 10.6 M entries; config D, k = 101: 25 M for ~18 M, and its copying stage gains less than this model says), so the copying walk
+// is only chosen where the predicted saving is half again the predicted cost: on, of the measured workloads, config C (-3.5 %) and off
+// on B, D', D (where it would cost 2 %), E'.
+[[maybe_unused]] static bool path_copy_pays(u64 n_text, u32 assemblies, u32 k, double r2) {
+    const double A = (double)std::max<u32>(assemblies, 1);
+    const double entries = (double)n_text * std::min(1.0, 2.0 * A * r2 / (double)k);
+    const double saving = entries * 53e-12 * std::max(0.0, 1.0 - 2.0 / A), cost = 0.25e-3 + 0.3e-12 * (double)n_text;
+    return saving > 1.5 * cost;
+}
 [[maybe_unused]] static u64 run_piece() { const char* e = getenv("AC_RUN_PIECE"); const long v = e ? atol(e) : 0; return v > 0 ? (u64)v : 4096; }      // positions per copied piece of a run (RunFilterFunctor)
 // AC_POS_CAP: occurrences further than this from both ends of their sequence do not lower a unitig's smallest positions (0 = all do)
 [[maybe_unused]] static u32 pos_cap() { const char* e = getenv("AC_POS_CAP"); const long v = e ? atol(e) : 65536; return v < 0 ? 0u : (u32)std::min<long>(v, 0x3FFFFFFF); }
@@ -571,7 +588,7 @@ struct GraphBuilder::Impl {
     }
     template <int W> void insert(const PackedText& t, u32 hint, DBuf<u64>* slots_out, u64* cap_out, u64* n_distinct_out, DBuf<u64>* bm_out, bool want_sib = false);
     DBuf<u64> sflags;          // sibling bits per slot, written by the insert (sib_note); empty = not collected
-    DBuf<u64> runs; DBuf<u32> run_count; u32 run_cap = 0;      // the insert's followed runs (Table::runs), for the copying path walk
+    DBuf<u64> runs; DBuf<u32> run_count; u64 run_rows = 0, run_rows_cap = 0;      // the insert's followed runs (Table::runs: rows used / reserved), for the copying path walk
     void occupancy_bitmap(const DBuf<u64>& sl, u64 c, DBuf<u64>* occ_out, const u64* sflags_in, u64* sib_out);
     DBuf<u64> occ;             // slot-occupancy bitmap of the graph table
     DBuf<u64> sib;             // sibling bits of the graph table's real k-mers, two per text position (MarkFunctor); empty = not used
@@ -671,11 +688,8 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
     // stream of similar jobs, does not pay for the overflow retries twice)
     static thread_local u64 memo_n_text = 0, memo_cap = 0; static thread_local u32 memo_k = 0; static thread_local int memo_shift = -2;      // (a capacity is a number, not memory: valid on any device)
     if (pt.n_text == memo_n_text && k == memo_k && memo_shift == table_shift() && memo_cap > c) c = memo_cap;
-    const bool want_runs = want_sib && path_copy() && &pt == &loc;      // (want_sib = the graph table of a single-device build)
-    if (want_runs) {
-        run_cap = (u32)std::min<u64>((pt.n_text / RUN_MIN) / RUN_REGIONS * 2 + 256, (u64)1 << 20);      // per region (twice an even share)
-        runs.alloc(3 * (u64)run_cap * RUN_REGIONS); run_count.alloc(RUN_REGIONS);
-    } else { runs = DBuf<u64>(); run_count = DBuf<u32>(); run_cap = 0; }
+    const int copy_mode = (want_sib && &pt == &loc) ? path_copy() : 0;      // (want_sib = the graph table of a single-device build)
+    bool want_runs = false;
     DBuf<InsertStats> istats(257);       // [256].real doubles as the kernel's error word: one D2H reads everything
     DBuf<u64> sl;
     DBuf<u64> nbm(pt.n_text / 64 + 2);   // K3a falls out of the insert: bit p set <=> p is the smallest occurrence of its canonical k-mer
@@ -693,10 +707,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
         u32* ierr = (u32*)&istats.ptr()[256].real;
         Table tb{sl.ptr(), c - 1, nullptr, nbm.ptr(), (&pt == &uni) ? n_owners : 1u, (&pt == &uni) ? my_owner : 0u, want_sib ? sflags.ptr() : nullptr,
                  &istats.ptr()[256].claimed, nullptr, nullptr, 0};
-        if (want_runs) {      // (the graph text of a single-device build: its path walk can copy)
-            run_count.fill_bytes(0);
-            tb.runs = runs.ptr(); tb.run_count = run_count.ptr(); tb.run_cap = run_cap;
-        }
+        runs = DBuf<u64>(); run_count = DBuf<u32>(); run_rows = run_rows_cap = 0;
         phase_end.clear();
         stream_sync();
 #ifndef AC_EMU
@@ -739,6 +750,18 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
                 u64 c = (len / (diverse ? std::max<u64>(insert_waves_target(), insert_waves_diverse()) : insert_waves_target()) + 63) & ~63ULL;
                 u32 chunk = (u32)std::min<u64>(std::max<u64>(c, 256), rest_at_once ? wave_chunk_rest() : wave_chunk_max());
                 u64 n_waves = (len + chunk - 1) / chunk;
+                if (want_runs && rest_at_once) {
+                    // the one-launch rest of a redundant text (with the host entry: its few pieces) notes the runs it follows, a row per
+                    // wavefront; reserved with the first piece for twice what the whole rest needs at this piece's chunk length, and a
+                    // later piece that would not fit does not note (its text is walked)
+                    if (!run_rows_cap) {
+                        run_rows_cap = 2 * ((p_end_all - pb) / chunk + 1) + n_waves + 64;
+                        runs.alloc(3 * run_rows_cap * RUN_ROW); run_count.alloc(run_rows_cap + 1);
+                        run_count.fill_bytes(0);
+                    }
+                    if (run_rows + n_waves <= run_rows_cap) { tb.runs = runs.ptr(); tb.run_count = run_count.ptr(); tb.run_row0 = run_rows; run_rows += n_waves; }
+                    else tb.runs = nullptr;
+                }
 #ifdef AC_EMU
                 launch(n_waves, InsertWaveEmuFunctor<W>{t, tb, pb, pe, chunk, istats.ptr(), ierr});
 #else
@@ -775,6 +798,10 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
                 u64 claimed = 0;
                 for (size_t q = 0; q < 256; q++) claimed += st2[q].claimed;
                 if (st2[256].real == 0 && claimed * 4 <= first * 5) rest_at_once = true;      // <= 25 % of the second stretch was new
+                // ... and whether the path walk will copy the runs this launch follows (then it has to note them)
+                const double r2 = claimed > first ? (double)(claimed - first) / (double)first : 0.0;
+                want_runs = rest_at_once && (copy_mode == 1 || (copy_mode == 2 && path_copy_pays(pt.n_text, hint, k, r2)));
+                if (getenv("AC_DEBUG_ARENA")) fprintf(stderr, "insert: second stretch %.4f new, one-launch rest %d, copying walk %d (mode %d)\n", r2, (int)rest_at_once, (int)want_runs, copy_mode);
             }
         }
 #ifndef AC_EMU
@@ -1129,36 +1156,32 @@ template <int W> bool GraphBuilder::Impl::walk_copy(u32 PC) {
     Table tb = graph_table();
     Novel nv{bm.ptr(), wprefix.ptr()};
     UnitigCtx uc{head.ptr(), scan.ptr(), rank.ptr(), uorient.ptr(), ustart.ptr(), ulen.ptr(), U, N};
-    std::vector<u32> h_cnt = to_host(run_count, RUN_REGIONS);
-    std::vector<u64> h_first(RUN_REGIONS + 1, 0);
-    for (u32 g = 0; g < RUN_REGIONS; g++) h_first[g + 1] = h_first[g] + std::min<u32>(h_cnt[g], run_cap);
-    const u64 R0 = h_first[RUN_REGIONS];
-    if (R0 == 0 || R0 >= 0xFFFFFFF0ULL) return false;
+    // the runs in text order: the rows of the insert's wavefronts one behind the other
     const Arena::Mark mk = Arena::device().mark();
-    // the runs in text order, the usable ones only
-    DBuf<u64> key(R0), rfirst(RUN_REGIONS + 1); DBuf<u32> idx(R0);
-    copy_h2d(rfirst.ptr(), h_first.data(), (RUN_REGIONS + 1) * 8);
-    launch(R0, RunKeyFunctor{runs.ptr(), rfirst.ptr(), run_cap, key.ptr(), idx.ptr()});
-    sort_pairs_u64_u32(key, idx, R0, 40);
+    DBuf<u32> rfirst(run_rows + 1);
+    exclusive_scan_u32(run_count.ptr(), rfirst.ptr(), run_rows + 1);      // (run_count[run_rows] is a zero the insert never touches)
+    const u64 R0 = read_scalar(rfirst.ptr() + run_rows);
+    if (R0 == 0 || R0 >= 0xFFFFFFF0ULL) { Arena::device().rewind(mk); return false; }
     DBuf<RunRec> sorted(R0);
-    launch(R0, RunGatherFunctor{runs.ptr(), idx.ptr(), sorted.ptr()});
+    launch(run_rows * RUN_ROW, RunGatherFunctor{runs.ptr(), run_count.ptr(), rfirst.ptr(), sorted.ptr()});
     DBuf<u32> ok(R0 + 1), at(R0 + 1); DBuf<u64> covered(1, true); DBuf<u32> overlap(1, true);
     ok.fill_bytes(0);
     DBuf<RunRec> fixed(R0); DBuf<u32> fseq(R0);
     launch(R0, RunFilterFunctor{sorted.ptr(), fixed.ptr(), R0, nv, loc.n_text, ok.ptr(), covered.ptr(), t, overlap.ptr(), run_piece(), fseq.ptr()});
     exclusive_scan_u32(ok.ptr(), at.ptr(), R0 + 1);
-    u64 h_cov = 0; u32 h_R = 0, h_overlap = 0;
-    { ReadBatch rb; rb.add(&h_cov, covered.ptr(), 8); rb.add(&h_R, at.ptr() + R0, 4); rb.add(&h_overlap, overlap.ptr(), 4); rb.run(); }
-    const u64 R = h_R;
-    if (getenv("AC_DEBUG_ARENA")) fprintf(stderr, "path copy: %llu runs on the list, %llu usable, covering %llu of %llu positions\n", (unsigned long long)R0, (unsigned long long)R, (unsigned long long)h_cov, (unsigned long long)loc.n_text);
-    if (R == 0 || h_overlap || h_cov * 2 < loc.n_text) { Arena::device().rewind(mk); return false; }      // little to copy: the plain walk
-    DBuf<RunRec> rr(R); DBuf<u32> rseq(R);
+    // pieces, and the gaps between them cut into walkers — launched over a bound on the number of pieces, so that their number, the
+    // positions they cover and the number of walkers reach the host in ONE read-back
+    const u64 Rb = R0 + loc.n_text / run_piece() + 1;
+    DBuf<RunRec> rr(Rb); DBuf<u32> rseq(Rb);
     launch(R0, RunCompactFunctor{fixed.ptr(), ok.ptr(), at.ptr(), rr.ptr(), run_piece(), fseq.ptr(), rseq.ptr()});
-    // the gaps between them, cut into walkers
-    DBuf<u64> gw(R + 2), wfirst(R + 2);
-    launch(R + 2, GapWalkersFunctor{rr.ptr(), R, loc.n_text, PC, gw.ptr()});
-    exclusive_scan_u64(gw.ptr(), wfirst.ptr(), R + 2);
-    const u64 NW = read_scalar(wfirst.ptr() + (R + 1));
+    DBuf<u64> gw(Rb + 2), wfirst(Rb + 2);
+    launch(Rb + 2, GapWalkersFunctor{rr.ptr(), at.ptr() + R0, loc.n_text, PC, gw.ptr()});
+    exclusive_scan_u64(gw.ptr(), wfirst.ptr(), Rb + 2);
+    u64 h_cov = 0, NW = 0; u32 h_R = 0, h_overlap = 0;
+    { ReadBatch rb; rb.add(&h_cov, covered.ptr(), 8); rb.add(&h_R, at.ptr() + R0, 4); rb.add(&h_overlap, overlap.ptr(), 4); rb.add(&NW, wfirst.ptr() + (Rb + 1), 8); rb.run(); }
+    const u64 R = h_R;
+    if (getenv("AC_DEBUG_ARENA")) fprintf(stderr, "path copy: %llu runs on the list, %llu pieces usable, covering %llu of %llu positions, %llu walkers\n", (unsigned long long)R0, (unsigned long long)R, (unsigned long long)h_cov, (unsigned long long)loc.n_text, (unsigned long long)NW);
+    if (R == 0 || h_overlap || h_cov * 2 < loc.n_text) { Arena::device().rewind(mk); return false; }      // little to copy: the plain walk
     if (NW == 0 || NW >= 0xFFFFFFF0ULL) { Arena::device().rewind(mk); return false; }
     DBuf<u64> w_begin(NW), w_end(NW), wcount(NW + 1), woff(NW + 1); DBuf<u32> w_gap(NW);
     launch(NW, WalkerRangeFunctor{rr.ptr(), R, loc.n_text, PC, wfirst.ptr(), w_begin.ptr(), w_end.ptr(), w_gap.ptr()});
@@ -1175,9 +1198,9 @@ template <int W> bool GraphBuilder::Impl::walk_copy(u32 PC) {
                                  pos_cap_now, 0, nullptr, NW, w_begin.ptr(), w_end.ptr(), stage_off.ptr()});
     exclusive_scan_u64(wcount.ptr(), woff.ptr(), NW + 1);
     const u64 NE = read_scalar(woff.ptr() + NW);      // walked entries
-    DBuf<int32_t> ent(NE); DBuf<u64> ent_pos(NE), ent_end(NE); DBuf<u8> ent_want(NE);
-    launch(NW, WalkCompactFunctor{stage.ptr(), stage_off.ptr(), wcount.ptr(), woff.ptr(), w_begin.ptr(), PC, NW, ulen.ptr(), filter ? maybe_dest.ptr() : nullptr,
-                                  ent.ptr(), ent_pos.ptr(), ent_end.ptr(), ent_want.ptr()});
+    DBuf<int32_t> ent(NE); DBuf<u64> ent_pos(NE), ent_end(NE); DBuf<u8> ent_want(NE); DBuf<u32> ent_gap(NE);
+    launch_full(NW, WalkCompactFunctor{stage.ptr(), stage_off.ptr(), wcount.ptr(), woff.ptr(), w_begin.ptr(), w_gap.ptr(), PC, NW, ulen.ptr(),
+                                       filter ? maybe_dest.ptr() : nullptr, ent.ptr(), ent_pos.ptr(), ent_end.ptr(), ent_want.ptr(), ent_gap.ptr()});
     // what every run copies; entries per segment; the final array
     DBuf<u64> ra(R), rcnt(R + 1), seg(2 * R + 2), segoff(2 * R + 2); DBuf<u32> cov(NE + 1), copies(NE + 1);
     cov.fill_bytes(0);
@@ -1195,7 +1218,7 @@ template <int W> bool GraphBuilder::Impl::walk_copy(u32 PC) {
     // (the scratch above stays where it is until the build ends: for a text this redundant it is a fraction of the text's size)
     ent_val.alloc(n_ent);
     int32_t* const out_ptr = ent_val.ptr();
-    launch(NW, GapOutFunctor{ent.ptr(), wcount.ptr(), woff.ptr(), wfirst.ptr(), w_gap.ptr(), segoff.ptr(), copies.ptr(), out_ptr, depth.ptr()});
+    launch(NE, GapOutFunctor{ent.ptr(), ent_gap.ptr(), woff.ptr(), wfirst.ptr(), segoff.ptr(), copies.ptr(), out_ptr, depth.ptr()});
     launch_full(R * 32, RunOutFunctor<32, 1>{rr.ptr(), R, ra.ptr(), rcnt.ptr(), segoff.ptr(), ent.ptr(), ent_pos.ptr(), ent_end.ptr(), ulen.ptr(),
                                              ent_want.ptr(), t, rseq.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), out_ptr, pos_cap_now});
     launch(loc.n_seqs, PathOffCopyFunctor{seq_tid.ptr(), seq_j.ptr(), woff.ptr(), wfirst.ptr(), w_gap.ptr(), segoff.ptr(), path_off.ptr()});
@@ -1227,7 +1250,7 @@ template <int W> void GraphBuilder::Impl::walk() {
     maybe_dest_valid = filter;
     if (filter) { maybe_dest.alloc((u64)U * 2); launch((u64)U * 2, MaybeDestFunctor{links.ptr(), maybe_dest.ptr()}); }
     fs0.alloc(U, true); fe0.alloc(U, true);
-    if (runs.size() && !walk_answers && n_owners <= 1 && G == &loc && PC <= 65535 && walk_copy<W>(PC)) { lap(&tm->paths); return; }
+    if (run_rows && !walk_answers && n_owners <= 1 && G == &loc && PC <= 65535 && walk_copy<W>(PC)) { lap(&tm->paths); return; }
     // everything from here to the compaction is the walk's own: 4 bytes of staging per text position (configs[4]: 20 GB) go back to
     // the arena once the entries are compacted — they are compacted into the staging area's own first bytes
     const Arena::Mark walk_mark = Arena::device().mark();

@@ -568,11 +568,29 @@ def main():
             walk_ceiling = {"name": "random_read", "rate_Gops": rd.value, "operations": ops, "bound_ms": ops / rd.value / 1e6,
                             "frac": ops / rd.value / 1e6 / walk_ms if walk_ms else None,
                             "note": "one dependent gather per path entry plus each walker's start-up lookup, at the device's measured random 8-byte read rate"}
-        others.append(roof("PathWalkFunctor<W> + PathCompactFunctor (stage `paths`)", "get_unitig_path_for_sequence (unitig_graph.rs:407-465) for all sequences",
-                           walk_ms, 8.0 * n_ent + packed_b + 96.0 * U_now,
-                           "every path entry written to its staging slot and once more in text order (2 x 4 B) + the packed text read once + the unitig / "
-                           "successor records (96 B per unitig) read once",
-                           (pmc_of("PathWalkFunctor") or 0) + (pmc_of("PathCompactFunctor") or 0) or None, walk_ceiling))
+        if st.get("path_runs_copied", 0) > 0:
+            # the copying walk (chosen by the library's cost model on large redundant texts): the text between the insert's
+            # followed runs is walked, the runs' entries are copied from the walked entries of the stretch they repeat
+            copy_kernels = ("PathWalkFunctor", "RunOutFunctor", "GapOutFunctor", "WalkCompactFunctor", "RunRangeFunctor", "RunFilterFunctor",
+                            "RunGatherFunctor", "RunCompactFunctor", "GapWalkersFunctor", "WalkerRangeFunctor", "SegCountFunctor", "WlinkFlagFunctor",
+                            "WalkInfoFunctor", "MaybeDestFunctor", "PathOffCopyFunctor", "PathEndsFunctor")
+            walked = st["path_entries_walked"]
+            n_steps = 28      # ~24 dependent launches + 4 read-backs in the stage (profiles/r09e_timeline_path_copy_rows.txt)
+            others.append(roof("copying path walk: PathWalkFunctor<W> over the gaps + RunOutFunctor / GapOutFunctor + run bookkeeping (stage `paths`)",
+                               "get_unitig_path_for_sequence (unitig_graph.rs:407-465) for all sequences",
+                               walk_ms, 8.0 * n_ent + 24.0 * st["path_runs_copied"] + packed_b * (walked / max(n_ent, 1)) + 96.0 * U_now,
+                               "every path entry read once from the walked entries and written once (2 x 4 B) + 24 B per copied run + the walked share of "
+                               "the packed text read once + the unitig / successor records (96 B per unitig) read once",
+                               sum(pmc_of(nm) or 0 for nm in copy_kernels) or None,
+                               {"name": "dependent_launches", "operations": n_steps, "bound_ms": n_steps * 0.010, "frac": n_steps * 0.010 / walk_ms if walk_ms else None,
+                                "note": "kernels and host read-backs that must follow one another (scan -> size -> launch), ~10 us each: the stage's floor once "
+                                        "its per-entry work is streaming copies; %d of %d entries were walked, the rest copied" % (walked, n_ent)}))
+        else:
+            others.append(roof("PathWalkFunctor<W> + PathCompactFunctor (stage `paths`)", "get_unitig_path_for_sequence (unitig_graph.rs:407-465) for all sequences",
+                               walk_ms, 8.0 * n_ent + packed_b + 96.0 * U_now,
+                               "every path entry written to its staging slot and once more in text order (2 x 4 B) + the packed text read once + the unitig / "
+                               "successor records (96 B per unitig) read once",
+                               (pmc_of("PathWalkFunctor") or 0) + (pmc_of("PathCompactFunctor") or 0) or None, walk_ceiling))
         exp_ms = stage["expand"] * 1e3
         n_cand = st["n_candidates"]
         n_launch = st["n_levels"] * st["simplify_passes"]

@@ -212,9 +212,29 @@ def test_gfa_digest_equals_the_oracle(golden_name):
     assert base and "error" not in base[0], rows
     assert base[0]["unitigs"] == golden["post"]["unitigs"]
     assert base[0]["gfa_md5"] == golden["gfa_md5"]
+    # the library's cost model picks the copying path walk for the 96 similar assemblies of config C and for nothing else here
+    assert (base[0]["path_runs_copied"] > 0) == (golden_name == "configC_k51")
 
 
-@pytest.mark.parametrize("variants", ["base", "AC_UPLOAD_MASK=1", "AC_UPLOAD_OVERLAP=0", "AC_HOST_PACK=0", "AC_UPLOAD_THREADS=5", "AC_UPLOAD_SLOTS=2", "AC_UPLOAD_CHUNK_MB=16,AC_UPLOAD_SLOTS=3", "AC_UPLOAD_SLOTS=1,AC_UPLOAD_OVERLAP=0"])
+def test_config_c_digest_with_the_plain_path_walk():
+    """Config C with the copying walk switched off (AC_PATH_COPY=0; the cost model switches it on for this input): the same digest."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    golden = json.loads((root / "tests" / "golden" / "configC_k51.json").read_text())
+    out = subprocess.run([sys.executable, str(root / "tools" / "ab_knobs.py"), "--variants", "AC_PATH_COPY=0;AC_PATH_COPY=1,AC_POS_CAP=0", "--steps", "1", "--workload", "configC_k51"],
+                         env={**os.environ, "AC_NO_TORCH": "1"}, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{") and '"variant"' in l]
+    assert len(rows) == 2 and all("error" not in r for r in rows), rows
+    assert all(r["gfa_md5"] == golden["gfa_md5"] for r in rows)
+    assert rows[0]["path_runs_copied"] == 0 and rows[1]["path_runs_copied"] > 0
+
+
+@pytest.mark.parametrize("variants", ["base", "AC_PATH_COPY=0", "AC_UPLOAD_MASK=1", "AC_UPLOAD_OVERLAP=0", "AC_HOST_PACK=0", "AC_UPLOAD_THREADS=5", "AC_UPLOAD_SLOTS=2", "AC_UPLOAD_CHUNK_MB=16,AC_UPLOAD_SLOTS=3", "AC_UPLOAD_SLOTS=1,AC_UPLOAD_OVERLAP=0"])
 def test_host_entry_full_size_digest(variants):
     """The HOST entry (ac_compress_build from pageable per-sequence buffers: host-side 2-bit pack, chunked upload through the pinned
     ring by background threads, the insert issued chunk by chunk as they land) on the whole config C — 487 MB of text, eight 64 MB

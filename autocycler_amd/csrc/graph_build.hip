@@ -756,6 +756,8 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
                     // later piece that would not fit does not note (its text is walked)
                     if (!run_rows_cap) {
                         run_rows_cap = 2 * ((p_end_all - pb) / chunk + 1) + n_waves + 64;
+                        // (a short first piece has a short chunk: never more than four times what the longest chunks would need)
+                        run_rows_cap = std::min<u64>(run_rows_cap, 4 * (pt.n_text / wave_chunk_rest() + 1) + n_waves + 1024);
                         runs.alloc(3 * run_rows_cap * RUN_ROW); run_count.alloc(run_rows_cap + 1);
                         run_count.fill_bytes(0);
                     }

@@ -281,6 +281,7 @@ const char* ac_last_error(void);
 int ac_device_count(void);       /* number of visible HIP devices (0 if none / no driver) */
 uint32_t ac_max_kmer(void);      /* largest --kmer this build supports */
 const char* ac_version(void);
+const char* ac_source_hash(void);   /* 16 hex digits: digest of the sources this library was built from (csrc/Makefile; tools/source_hash.py) */
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,18 @@ def emu():
     return lib
 
 
+def test_source_hash_matches_the_tree():
+    # bench.py quotes PMC traffic only when it was counted on a library built from exactly these sources
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("source_hash", Path(__file__).resolve().parent.parent / "tools" / "source_hash.py")
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    # (the emulation is rebuilt by emu_lib whenever a source is newer than it; the product library is whatever build() left,
+    # so only its format is checked here — tests/test_gpu_boundary.py compares it with the tree on the device box)
+    assert _capi.load_library(emu_lib.emu_path()).ac_source_hash().decode() == m.source_hash()
+    assert re.fullmatch(r"[0-9a-f]{16}", _capi.load_library().ac_source_hash().decode())
+
+
 def test_header_symbols_exported_by_product_library():
     """The C-ABI library loads (no GPU needed) and exports every function include/autocycler_hip.h declares."""
     header = (ROOT / "include" / "autocycler_hip.h").read_text()
@@ -262,8 +274,15 @@ def test_bench_line_contract_single_rank_dry_run():
         assert abs(r["frac"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 8e12) < 1e-9 * max(1.0, r["frac"])
     assert j["roofline"]["ceiling"] is None or j["roofline"]["ceiling"]["name"] == "cas"
     assert j["roofline"]["whole_path_equiv"]["B_per_bp"] == 49
-    assert j["cpu_baseline_full_size"]["gfa_md5"] == "c28d41ea9e4784f5f1dd06da6b3eb587"
+    # the baseline of record is the whole workload's figure, the sample timed in the run stays beside it
+    assert j["cpu_baseline"]["gfa_md5"] == "c28d41ea9e4784f5f1dd06da6b3eb587" and j["cpu_baseline"]["timed_in_this_run"]["value"] > 0
+    assert 0.5 < j["cpu_baseline"]["value"] < 1.0
     assert "dry run" in j["data"]
+    # the headline is SURVEY.md 8(d)'s T_hot bracket (host RAM -> host RAM); the device-resident one is an extra key
+    assert "T_hot" in j["config"]["timed_region"] and j["value"] == j["t_hot"]["value"] and j["ms_per_step"] == j["t_hot"]["ms_per_step"]
+    assert j["hbm_resident"]["value"] > 0 and j["hbm_resident"]["steps"] == 2 and "RESIDENT IN HBM" in j["hbm_resident"]["timed_region"]
+    assert j["untimed_builds_before_the_timed_steps"]["init"] == j["init_builds_run"] >= 2
+    assert len(j["roofline"]["library_source_hash"]) == 16
     # the host-RAM -> host-RAM bracket of the same region (SURVEY.md 8d T_hot), timed in the same run through ac_compress_build
     for key in ("value", "ms_per_step", "timed_region", "upload_ms", "gfa_md5"):
         assert key in j["t_hot"], key

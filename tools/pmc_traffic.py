@@ -8,6 +8,9 @@ import csv
 import json
 import sys
 
+sys.path.insert(0, __file__.rsplit("/", 1)[0])
+from source_hash import source_hash
+
 
 def load(path):
     return {r["Name"]: float(r[[c for c in r if c.endswith("_per_build")][0]]) * 1024 for r in csv.DictReader(open(path))}
@@ -35,6 +38,7 @@ def main(fetch_csv, write_csv, n_text, tag, builds=7):
     table = {k: {"fetch_raw": f.get(k, 0.0), "write_raw": w.get(k, 0.0), "hbm_side_bytes": f.get(k, 0.0) * fcorr + w.get(k, 0.0)}
              for k in sorted(set(f) | set(w), key=lambda k: -(f.get(k, 0.0) * fcorr + w.get(k, 0.0)))[:64]}
     print(json.dumps({
+        "source_hash": source_hash(),      # the sources the profiled library was built from (bench.py refuses the file when its library differs)
         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), tools/pmc_lean.sh (torch-free driver, "
                   f"{builds} builds of config C per pass) on MI355X; profiles/{tag}_pmc_*_configC.csv",
         "kernel": "insert_wave_kernel<2> (3 phase launches per build, summed)",

@@ -94,6 +94,8 @@ def main():
     rank, world, port, lib_path, device, cases = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     backend = sys.argv[7] if len(sys.argv) > 7 else "gloo"
+    if device == "cuda:rank":      # one distinct GPU per rank (a multi-GPU box)
+        device = f"cuda:{rank}"
     import torch
     import torch.distributed as dist
     if backend == "nccl":

@@ -97,3 +97,14 @@ def test_bulk_accessors_equal_the_per_item_ones(lib):
     assert [(int(l["a"]), bool(l["a_fwd"]), int(l["b"]), bool(l["b_fwd"])) for l in b["links"]] == g.links()
     for sidx in range(len(seqs)):
         assert b["path_entries"][int(b["path_off"][sidx]):int(b["path_off"][sidx + 1])].tolist() == list(g.path(sidx))
+
+
+def test_library_is_built_from_this_tree():
+    """bench.py only quotes PMC traffic counted on a library of exactly the sources in the tree: the digest the loaded product library
+    carries (csrc/Makefile SRC_HASH) is the digest of the tree (tools/source_hash.py)."""
+    import importlib.util
+    from pathlib import Path
+    import autocycler_amd
+    spec = importlib.util.spec_from_file_location("source_hash", Path(__file__).resolve().parent.parent / "tools" / "source_hash.py")
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    assert autocycler_amd.load_library().ac_source_hash().decode() == m.source_hash()

@@ -50,14 +50,14 @@ def test_ranks_sharing_the_device(lib, world):
     M.run_case(None, 13, [FIXED[c] for c in "abcde"], ["a.fasta", "b.fna", "c.fa", "d.fasta.gz", "e.fna.gz"], list("abcde"), [0] * world)
 
 
-def test_config_b_over_two_ranks_digest(lib):
-    """BASELINE configs[1] (12 x ~5 Mbp, k = 51) as one job over two ranks: the GFA has the oracle's md5 (tests/golden/configB_k51.json)."""
+def _golden_job_over(lib, workload, device_lists):
+    """A golden workload (tests/golden/<workload>.json: the oracle's md5) as ONE job through ac_compress_build_multi over each of the device
+    lists; returns the multi info of each build."""
     import ctypes as C
-    import numpy as np
     import bench
     from autocycler_amd import _capi, synth
-    golden = json.loads((ROOT / "tests" / "golden" / "configB_k51.json").read_text())
-    k, n_asm, gen = synth.WORKLOADS["configB_k51"]
+    golden = json.loads((ROOT / "tests" / "golden" / f"{workload}.json").read_text())
+    k, n_asm, gen = synth.WORKLOADS[workload]
     seqs, fn, hd = synth.flatten(gen())
     lib.ac_seqs_views.restype = C.POINTER(_capi.SeqView)
     lib.ac_seqs_count.restype = C.c_uint32
@@ -65,16 +65,59 @@ def test_config_b_over_two_ranks_digest(lib):
     h = bench.prepare(lib, k, seqs, fn, hd, n_asm, threads=32, repair=1)
     n = lib.ac_seqs_count(h)
     views = lib.ac_seqs_views(h)
-    for devices in ([0, 0], [0]):
+    infos = []
+    for devices in device_lists:
         g = C.c_void_p()
         dv = (C.c_int * len(devices))(*devices)
         assert lib.ac_compress_build_multi(C.c_uint32(k), C.c_uint32(n_asm), views, C.c_uint32(n), dv, C.c_int(len(devices)), C.byref(g)) == 0, lib.ac_last_error()
         gr = _capi.Graph(lib, g, n)
+        mi = _capi.MultiInfo()
+        lib.ac_multi_info_get(g, C.byref(mi))
         assert gr.stats_post["unitigs"] == golden["post"]["unitigs"]
         assert hashlib.md5(gr.gfa(fn, hd).encode()).hexdigest() == golden["gfa_md5"]
+        infos.append(mi)
         gr.close()
     lib.ac_seqs_free(h)
     assert lib.ac_release_memory() == 0
+    return infos
+
+
+def test_config_b_over_two_ranks_digest(lib):
+    """BASELINE configs[1] (12 x ~5 Mbp, k = 51) as one job over two ranks: the GFA has the oracle's md5 (tests/golden/configB_k51.json)."""
+    _golden_job_over(lib, "configB_k51", ([0, 0], [0]))
+
+
+def _distinct_devices(lib):
+    n = lib.ac_device_count()
+    if n < 2:
+        pytest.skip(f"{n} HIP device(s) visible: the inter-device RCCL path needs at least two (it runs on the driver's multi-GPU node)")
+    return list(range(min(n, 8)))
+
+
+def test_distinct_devices_adversarial_over_rccl(lib, monkeypatch):
+    """where the box has several GPUs, one rank per DISTINCT device — every exchange of the build is then an RCCL call
+    between two devices (ncclAllReduce, grouped ncclSend / ncclRecv over xGMI), not the host-staged transport ranks sharing a device use."""
+    devices = _distinct_devices(lib)
+    monkeypatch.delenv("AC_MULTI_TRANSPORT", raising=False)
+    for world in sorted({2, len(devices)}):
+        dv = devices[:world]
+        assert M.adversarial(None, dv, ks=(11, 51), seeds=range(8)) == 2 * 8 * 2
+        seqs, fn, hd = M.synth_case(8, 60_000, 3_000, 1e-3, 1e-4, 7)
+        gfa1, _ = M.run_case(None, 51, seqs, fn, hd, [0])
+        gfa, info = M.run_case(None, 51, seqs, fn, hd, dv)
+        assert gfa == gfa1 and info["transport"] == 2 and info["n_ranks"] == world      # 2 = RCCL
+        seqs, fn, hd = M.mixed_case(world, 4, 40_000)
+        _, info = M.run_case(None, 51, seqs, fn, hd, dv)
+        assert info["transport"] == 2 and 0 < info["queries_sent_away"] < info["queries_total"]
+
+
+def test_distinct_devices_golden_digests(lib, monkeypatch):
+    """configs[1] and the mixed-species replica E' as one job over all the box's devices (RCCL): the oracle's md5."""
+    devices = _distinct_devices(lib)
+    monkeypatch.delenv("AC_MULTI_TRANSPORT", raising=False)
+    for workload in ("configB_k51", "configEprime_k51"):
+        for mi in _golden_job_over(lib, workload, (devices[:2], devices)):
+            assert mi.transport == 2 and mi.n_ranks >= 2
 
 
 def test_whole_command_over_several_ranks(lib, tmp_path):
@@ -97,26 +140,5 @@ def test_whole_command_over_several_ranks(lib, tmp_path):
 def test_mixed_species_replica_over_four_ranks_digest(lib):
     """E' (5 species x 20 strains x ~1 Mbp, 45 M distinct k-mers, 1.7 M unitigs) as one job over four ranks sharing the device: the owner-routed key
     exchange under load (each rank routes ~10^5 walk-start keys to three others) — the GFA has the oracle's md5."""
-    import ctypes as C
-    import bench
-    from autocycler_amd import _capi, synth
-    golden = json.loads((ROOT / "tests" / "golden" / "configEprime_k51.json").read_text())
-    k, n_asm, gen = synth.WORKLOADS["configEprime_k51"]
-    seqs, fn, hd = synth.flatten(gen())
-    lib.ac_seqs_views.restype = C.POINTER(_capi.SeqView)
-    lib.ac_seqs_count.restype = C.c_uint32
-    lib.ac_seqs_free.argtypes = [C.c_void_p]
-    h = bench.prepare(lib, k, seqs, fn, hd, n_asm, threads=32, repair=1)
-    n = lib.ac_seqs_count(h)
-    g = C.c_void_p()
-    dv = (C.c_int * 4)(0, 0, 0, 0)
-    assert lib.ac_compress_build_multi(C.c_uint32(k), C.c_uint32(n_asm), lib.ac_seqs_views(h), C.c_uint32(n), dv, C.c_int(4), C.byref(g)) == 0, lib.ac_last_error()
-    gr = _capi.Graph(lib, g, n)
-    mi = _capi.MultiInfo()
-    lib.ac_multi_info_get(g, C.byref(mi))
-    assert gr.stats_post["unitigs"] == golden["post"]["unitigs"]
-    assert hashlib.md5(gr.gfa(fn, hd).encode()).hexdigest() == golden["gfa_md5"]
+    mi, = _golden_job_over(lib, "configEprime_k51", ([0, 0, 0, 0],))
     assert mi.n_ranks == 4 and mi.queries_sent_away > mi.queries_total // 2
-    gr.close()
-    lib.ac_seqs_free(h)
-    assert lib.ac_release_memory() == 0

@@ -63,3 +63,16 @@ def test_rccl_collectives_world_of_one(lib_path):
     cases = ",".join(f"{k}:{seed}" for k in (11, 51) for seed in range(6)) + ",synth:51,mixed:51"
     outs = launch(1, lib_path, "cuda:0", cases, timeout=900, backend="nccl")
     assert "(nccl)" in outs[0]
+
+
+def test_distinct_devices_over_rccl(lib_path):
+    """where the box has several GPUs, one PROCESS per distinct device over the nccl backend (= RCCL) — the layout
+    bench.py --gpus N runs under torch.distributed.run — on the adversarial set, the synthetic and the mixed-species job; every
+    collective of autocycler_amd/sharded.py then moves device buffers between two GPUs.  Skipped on a one-GPU box."""
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip(f"{n} GPU(s) visible: the inter-device RCCL path needs at least two")
+    cases = ",".join(f"{k}:{seed}" for k in (11, 51) for seed in range(8)) + ",synth:51,mixed:51,partition"
+    for world in sorted({2, min(n, 8)}):
+        outs = launch(world, lib_path, "cuda:rank", cases, timeout=900, backend="nccl")
+        assert "(nccl)" in outs[0]

@@ -438,6 +438,27 @@ int ac_shard_answer(ac_shard* s, const void* d_keys_u64, uint64_t n_queries, voi
         s->b->answer_queries(d_keys_u64, n_queries, d_out_u64);
     });
 }
+// The owner-routed form of the walk-start exchange (what ac_compress_build_multi does inside the library, multi_build.cpp): the
+// rank's keys ordered by owner, counts[r] of them for rank r — one all-to-all sends each key to the ONE rank whose table can answer it,
+// ac_shard_answer looks the received keys up, the reverse all-to-all brings the answers back in the same order.
+int ac_shard_queries_route(ac_shard* s, uint32_t n_shards, void* d_routed_keys_u64, uint64_t* counts) {
+    return guarded([&] {
+        if (s->phase != 5) throw DeviceError("ac_shard_queries_route: wrong phase");
+        if (n_shards == 0 || !counts) throw DeviceError("ac_shard_queries_route: no ranks");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->queries_route(n_shards, d_routed_keys_u64, counts);
+    });
+}
+int ac_shard_walk_routed(ac_shard* s, const void* d_routed_answers_u64) {
+    return guarded([&] {
+        if (s->phase != 5) throw DeviceError("ac_shard_walk_routed: wrong phase");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->shard_walk_routed(d_routed_answers_u64);
+        s->phase = 6;
+    });
+}
 int ac_shard_walk(ac_shard* s, const void* d_answers_u64) {
     return guarded([&] {
         if (s->phase != 5) throw DeviceError("ac_shard_walk: wrong phase");

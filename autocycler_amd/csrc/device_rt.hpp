@@ -370,6 +370,18 @@ class DBuf {   // a typed slice of the device arena (no ownership: the arena res
         else AC_HIP_CHECK(hipMemsetAsync(p_, byte, bytes, s));
 #endif
     }
+    // The same from byte `from` (rounded down to 16) to the end: for a buffer whose front a kernel is about to overwrite in full.
+    void fill_bytes_from(size_t from, int byte, stream_t s = 0) {
+        const size_t bytes = n_ * sizeof(T);
+        from &= ~(size_t)15;
+        if (from >= bytes) return;
+#ifdef AC_EMU
+        memset((u8*)p_ + from, byte, bytes - from);
+#else
+        if (s == 0) FillQueue::get().add((u8*)p_ + from, bytes - from, byte);
+        else AC_HIP_CHECK(hipMemsetAsync((u8*)p_ + from, byte, bytes - from, s));
+#endif
+    }
     T* ptr() { return p_; }
     const T* ptr() const { return p_; }
     size_t size() const { return n_; }

@@ -15,9 +15,10 @@ the GPU box, "gloo" in the CPU test-suite):
     ac_shard_build_graph    unitigs (identical everywhere); links, probing owned groups only
       all-reduce SUM        link words                                              (120 B per unitig)
     ac_shard_links_import   the keys this rank's path walkers start from
-      all-gather            the keys of all ranks; ac_shard_answer looks the owned ones up
-      all-reduce SUM        the answers                                             (8 B per 256 input positions)
-    ac_shard_walk           the paths of the local sequences
+    ac_shard_queries_route  ... ordered by owner rank
+      all-to-all            each key to the ONE rank whose table holds it; ac_shard_answer looks them up   (~1/world of the keys per rank)
+      all-to-all (reverse)  the answers, in the order the keys were sent           (8 B per 256 input positions, once)
+    ac_shard_walk_routed    the paths of the local sequences
       all-reduce SUM, MIN   per-unitig depth / path-end counts, smallest positions  (5 x U int32)
     ac_shard_finish         order-sensitive tail (identical on every rank)
       [gather to root]      optional: paths of all sequences in final numbers -> one rank holds the whole GFA;
@@ -106,6 +107,19 @@ class Comm:
             res = None
         self.seconds += time.perf_counter() - t0
         return res
+
+    def all_to_all(self, t, send_counts, recv_counts):
+        """t: 1-D tensor, send_counts[r] elements for rank r (in rank order); returns the recv_counts[r] elements of every rank r, in rank order."""
+        if self.local_only:
+            return t[:send_counts[0]]
+        t0 = time.perf_counter()
+        self.calls["all_to_all_single"] = self.calls.get("all_to_all_single", 0) + 1
+        x = self._out(t[:sum(send_counts)].contiguous())
+        out = torch.empty(sum(recv_counts), dtype=t.dtype, device=x.device)
+        self.dist.all_to_all_single(out, x, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=self.group)
+        out = self._back(out)
+        self.seconds += time.perf_counter() - t0
+        return out
 
     def all_reduce(self, t, op):
         if self.local_only:
@@ -203,21 +217,24 @@ def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False):
             comm.all_reduce(wl, "SUM")
             _check(lib, lib.ac_shard_links_import(h, ptr(lk), ptr(wl)))
             del lk, wl
-        # where this rank's walkers start: keys to everybody, answers from the owners
+        # where this rank's walkers start: every key goes to the ONE rank that owns it (all-to-all), the answers come back the same way
         nq = lib.ac_shard_query_count(h)
         kw = lib.ac_shard_query_key_words(h)
         keys = torch.empty(max(nq * kw, 1), dtype=torch.int64, device=dev)
-        _check(lib, lib.ac_shard_queries_export(h, ptr(keys)))
-        qsz = [q[0] for q in comm.all_gather_sizes([nq])]
-        all_keys = torch.cat(comm.all_gather_padded(keys, [q * kw for q in qsz])).contiguous() if not solo else keys
-        nq_total = sum(qsz)
-        ans = torch.empty(max(nq_total, 1), dtype=torch.int64, device=dev)
-        _check(lib, lib.ac_shard_answer(h, ptr(all_keys), C.c_uint64(nq_total), ptr(ans)))
-        comm.all_reduce(ans, "SUM")
-        q0 = sum(qsz[:comm.rank])
-        mine_ans = ans[q0:q0 + nq].contiguous()
-        _check(lib, lib.ac_shard_walk(h, ptr(mine_ans)))
-        del keys, all_keys, ans, mine_ans
+        to = (C.c_uint64 * comm.world)()
+        _check(lib, lib.ac_shard_queries_route(h, C.c_uint32(comm.world), ptr(keys), to))
+        to = [int(x) for x in to]
+        frm = [row[comm.rank] for row in comm.all_gather_sizes(to)]       # frm[r]: keys rank r sends here
+        in_keys = comm.all_to_all(keys, [c * kw for c in to], [c * kw for c in frm]).contiguous()
+        n_in = sum(frm)
+        in_ans = torch.empty(max(n_in, 1), dtype=torch.int64, device=dev)
+        _check(lib, lib.ac_shard_answer(h, ptr(in_keys), C.c_uint64(n_in), ptr(in_ans)))
+        my_ans = comm.all_to_all(in_ans, frm, to).contiguous()
+        if my_ans.numel() == 0:
+            my_ans = torch.zeros(1, dtype=torch.int64, device=dev)
+        _check(lib, lib.ac_shard_walk_routed(h, ptr(my_ans)))
+        queries_sent_away = nq - to[comm.rank]
+        del keys, in_keys, in_ans, my_ans
         # per-unitig quantities over all sequences
         red = torch.empty(5 * U, dtype=torch.int32, device=dev)
         _check(lib, lib.ac_shard_reduce_export(h, C.c_void_p(red.data_ptr()), C.c_void_p(red.data_ptr() + 12 * U)))
@@ -250,6 +267,6 @@ def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False):
                                                    C.c_int(device_index)))
                 graph.n_seqs = n_total
         return graph, {"fragments": nf_total, "union_text_bytes": nb_total, "distinct": N, "unitigs": U, "comm_s": comm.seconds,
-                       "table_capacity": table_capacity, "walk_queries": nq}
+                       "table_capacity": table_capacity, "walk_queries": nq, "walk_queries_sent_away": queries_sent_away}
     finally:
         lib.ac_shard_free(h)

@@ -168,6 +168,12 @@ uint32_t ac_shard_query_key_words(const ac_shard*);    /* u64 words per query ke
 int ac_shard_queries_export(ac_shard*, void* d_out_u64 /* query_count * query_key_words */);
 int ac_shard_answer(ac_shard*, const void* d_keys_u64, uint64_t n_queries, void* d_out_u64 /* n_queries */);
 int ac_shard_walk(ac_shard*, const void* d_answers_u64 /* query_count: this rank's slice of the summed answers */);
+/* The same exchange routed by owner (north_star's bucket exchange; what ac_compress_build_multi does inside the library): the keys
+ * ordered by owner rank, counts[r] of them for rank r -> all-to-all -> ac_shard_answer on what arrived -> reverse all-to-all ->
+ * ac_shard_walk_routed with the answers in the order ac_shard_queries_route gave the keys.  A rank receives ~1/n_shards of the keys. */
+int ac_shard_queries_route(ac_shard*, uint32_t n_shards, void* d_routed_keys_u64 /* query_count * query_key_words */,
+                           uint64_t* counts /* n_shards */);
+int ac_shard_walk_routed(ac_shard*, const void* d_routed_answers_u64 /* query_count */);
 int ac_shard_reduce_export(ac_shard*, void* d_sum_i32 /* 3U */, void* d_min_i32 /* 2U */);
 int ac_shard_reduce_import(ac_shard*, const void* d_sum_i32, const void* d_min_i32);
 int ac_shard_finish(ac_shard*, int want, ac_graph** out);

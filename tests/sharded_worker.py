@@ -150,7 +150,7 @@ def main():
             sharded_util.run_case(lib_path, k, seqs, fn, hd, comm, dev, repair=repair, device_index=dev.index or 0,
                                   gather_paths=gather)
             if backend == "nccl":
-                for name in ("all_gather_into_tensor", "all_reduce_SUM", "all_reduce_MIN") + (("gather",) if gather else ()):
+                for name in ("all_gather_into_tensor", "all_to_all_single", "all_reduce_SUM", "all_reduce_MIN") + (("gather",) if gather else ()):
                     assert comm.calls.get(name, 0) > 0, f"collective {name} was not issued"
         done += 1
     dist.barrier()

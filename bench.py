@@ -118,7 +118,7 @@ def cpu_baseline(k, sample_assemblies, sample_genome):
                       f"on 1 core (the reference's hot stages are single-threaded); C++ restatement, not the autocycler binary"}
 
 
-def collect_pmc_live(n_text, tag="bench_live", timeout=420):
+def collect_pmc_live(n_text, tag="bench_live", timeout=420, workload=None):
     """HBM-side bytes per kernel per build, counted now: the two rocprofv3 PMC passes of tools/pmc_lean.sh (FETCH_SIZE, WRITE_SIZE;
     --kernel-trace only, one counter per pass) on the torch-free driver building THIS workload with THIS library, summarised by
     tools/pmc_traffic.py.  Returns the dictionary profiles/pmc_traffic.json holds, or an {"error": ...} one."""
@@ -127,13 +127,13 @@ def collect_pmc_live(n_text, tag="bench_live", timeout=420):
     if not shutil.which("rocprofv3"):
         return {"error": "rocprofv3 not on PATH"}
     try:
-        pr = subprocess.run(["bash", str(ROOT / "tools" / "pmc_lean.sh"), tag], cwd=str(ROOT), capture_output=True, text=True, timeout=timeout,
+        pr = subprocess.run(["bash", str(ROOT / "tools" / "pmc_lean.sh"), tag, "base"] + ([workload] if workload else []), cwd=str(ROOT), capture_output=True, text=True, timeout=timeout,
                             env={**os.environ, "AC_NO_TORCH": "1"})
         out = ROOT / "gpurun_out"
         f, w = out / f"{tag}_pmc_FETCH_SIZE.csv", out / f"{tag}_pmc_WRITE_SIZE.csv"
         if not (f.exists() and w.exists() and f.stat().st_size and w.stat().st_size):
             return {"error": "the PMC passes left no summaries: " + (pr.stdout + pr.stderr)[-300:]}
-        pr2 = subprocess.run([sys.executable, str(ROOT / "tools" / "pmc_traffic.py"), str(f), str(w), str(n_text), tag], cwd=str(ROOT),
+        pr2 = subprocess.run([sys.executable, str(ROOT / "tools" / "pmc_traffic.py"), str(f), str(w), str(n_text), tag, "7", workload or "configC_k51"], cwd=str(ROOT),
                              capture_output=True, text=True, timeout=60)
         if pr2.returncode:
             return {"error": pr2.stderr[-300:]}
@@ -153,6 +153,9 @@ def main():
     ap.add_argument("--sub", type=float, default=1e-4)
     ap.add_argument("--indel", type=float, default=1e-5)
     ap.add_argument("--kmer", type=int, default=51)
+    ap.add_argument("--workload", type=str, default=None,
+                    help="N = 1: a named workload of autocycler_amd.synth.WORKLOADS instead of --assemblies / --genome / --kmer, e.g. configEprime_k51 "
+                         "(the mixed-species replica of BASELINE.json configs[4]); its PMC traffic is profiles/pmc_traffic_<name>.json")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-bracket", action="store_true", help="skip the T_hot bracket (host RAM -> host RAM through ac_compress_build)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-command bracket (FASTA directory -> GFA/YAML)")
@@ -209,6 +212,15 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
+    named = None
+    if args.workload:
+        from autocycler_amd import synth as _synth
+        if world != 1:
+            raise SystemExit("--workload names a single-device job")
+        if args.workload not in _synth.WORKLOADS:
+            raise SystemExit(f"--workload: one of {sorted(_synth.WORKLOADS)}")
+        named = _synth.WORKLOADS[args.workload]
+        args.kmer, args.assemblies = named[0], named[1]
     lib = _capi.load_library(emu_lib) if emu_lib else _capi.load_library()          # raises if the HIP extension is missing: no fallback
     lib.ac_seqs_views.restype = C.POINTER(_capi.SeqView)
     lib.ac_seqs_count.restype = C.c_uint32
@@ -222,7 +234,11 @@ def main():
     if mode == "single" and world > 1:
         mode = "independent"
     t0 = time.time()
-    seqs, fn, hd = make_inputs(args, rank, mode == "sharded")
+    if named:
+        from autocycler_amd import synth as _synth
+        seqs, fn, hd = _synth.flatten(named[2]())
+    else:
+        seqs, fn, hd = make_inputs(args, rank, mode == "sharded")
     t_gen = time.time() - t0
     h_seqs = prepare(lib, k, seqs, fn, hd, args.assemblies, threads=os.cpu_count() or 1, repair=1 if args.repair == "host" else 0)
     del seqs
@@ -400,8 +416,8 @@ def main():
         from autocycler_amd import synth
         tmp = Path(tempfile.mkdtemp(prefix="ac_bench_e2e_", dir="/dev/shm" if Path("/dev/shm").is_dir() else None))
         try:
-            synth.write_fasta_dir(synth.make_assemblies(args.assemblies, genome=args.genome, plasmid=args.plasmid, sub=args.sub, indel=args.indel,
-                                                        seed=51_000), tmp / "in")
+            synth.write_fasta_dir(named[2]() if named else synth.make_assemblies(args.assemblies, genome=args.genome, plasmid=args.plasmid, sub=args.sub,
+                                                                                 indel=args.indel, seed=51_000), tmp / "in")
             fasta_bytes = sum(f.stat().st_size for f in (tmp / "in").iterdir())
             threads = min(os.cpu_count() or 8, 32)
             runs = []
@@ -517,23 +533,24 @@ def main():
         # profiles/; rocprofv3 counters cannot be read from inside this process).  Only quoted when this run is the workload the
         # counters were collected on.
         pj, traffic_src, pmc_note = None, None, None
-        pmc = ROOT / "profiles" / "pmc_traffic.json"
-        default_workload = (args.assemblies, args.genome, args.plasmid, args.sub, args.indel, k) == (96, 5_000_000, 100_000, 1e-4, 1e-5, 51)
+        pmc = ROOT / "profiles" / (f"pmc_traffic_{args.workload}.json" if named else "pmc_traffic.json")
+        default_workload = (args.assemblies, args.genome, args.plasmid, args.sub, args.indel, k) == (96, 5_000_000, 100_000, 1e-4, 1e-5, 51) and not named
         if emu_lib and os.environ.get("BENCH_EMU_ASSUME_DEFAULT"):
             default_workload = True      # dry run only: exercise the fields that are quoted for the default workload
+        counted_workload = default_workload or bool(named)      # the workloads tools/pmc_lean.sh can rebuild: config C and the named ones
         lib.ac_source_hash.restype = C.c_char_p
         lib_hash = lib.ac_source_hash().decode()
-        if default_workload and args.pmc != "off":
+        if counted_workload and args.pmc != "off":
             if pmc.exists() and args.pmc != "live":
                 cand = json.loads(pmc.read_text())
                 if cand.get("source_hash") == lib_hash or (emu_lib and os.environ.get("BENCH_EMU_ASSUME_DEFAULT")):
                     pj = cand
-                    traffic_src = ("profiles/pmc_traffic.json: rocprofv3 PMC passes (tools/pmc_lean.sh) on a library built from exactly these sources "
+                    traffic_src = (f"profiles/{pmc.name}: rocprofv3 PMC passes (tools/pmc_lean.sh) on a library built from exactly these sources "
                                    f"(source hash {lib_hash}); FETCH_SIZE x2 per the gfx950 calibration, + WRITE_SIZE")
                 else:
-                    pmc_note = (f"profiles/pmc_traffic.json is stale: collected on sources {cand.get('source_hash')}, this library is {lib_hash}")
+                    pmc_note = (f"profiles/{pmc.name} is stale: collected on sources {cand.get('source_hash')}, this library is {lib_hash}")
             if pj is None and args.pmc in ("auto", "live") and not emu_lib and world == 1:
-                live = collect_pmc_live(n_text)
+                live = collect_pmc_live(n_text, workload=args.workload)
                 if "error" in live:
                     pmc_note = ((pmc_note + "; ") if pmc_note else "") + "live collection failed: " + live["error"]
                 else:
@@ -557,7 +574,7 @@ def main():
             "dtype": "u64", "data": "synthetic" if not emu_lib else "emulation dry run (not a measurement)",
             "config": {"workload": f"{args.assemblies} x ~{args.genome / 1e6:g} Mbp synthetic assemblies per GPU (+plasmid {args.plasmid} bp, "
                                    f"sub {args.sub:g}, indel {args.indel:g}), k={k}, " +
-                                   (f"1 species; {workload_label(args, k)}" if world == 1 else
+                                   ((f"1 species; {workload_label(args, k)}" if not named else f"named workload {args.workload} (autocycler_amd/synth.py WORKLOADS)") if world == 1 else
                                     (f"ONE job of {world} species, one per GPU (mixed-species job as in BASELINE.json configs[4]; rank 0 holds "
                                      "exactly the N=1 workload, configs[2])" if (mode == "sharded" and args.species == "per-gpu") else
                                      f"ONE job of {world * args.assemblies} assemblies of one species" if mode == "sharded" else
@@ -700,8 +717,8 @@ def main():
             a, b2 = args.cpu_sample.split("x")
             sample = cpu_baseline(k, int(a), int(b2))      # timed now, on this box's host cores
             line["cpu_baseline"] = sample
-            gold = ROOT / "tests" / "golden" / "configC_k51.json"      # the oracle on the WHOLE workload, run once where it was recorded
-            if default_workload and gold.exists():
+            gold = ROOT / "tests" / "golden" / (f"{args.workload}.json" if named else "configC_k51.json")      # the oracle on the WHOLE workload, run once where it was recorded
+            if counted_workload and gold.exists():
                 try:
                     gj = json.loads(gold.read_text())
                     hot = gj["seconds"]["kmer_graph"] + gj["seconds"]["unitig_graph"] + gj["seconds"]["simplify"]
@@ -709,9 +726,9 @@ def main():
                     # understates the CPU path 1.8x); the sample timed in this run stays beside it, on this box's cores
                     line["cpu_baseline"] = {
                         "value": (487_499_962 if emu_lib else bases) / 1e6 / hot, "unit": "Mbp/s", "cores": 1, "kind": "port", "seconds": hot,
-                        "sample": "the WHOLE workload (96 x ~5 Mbp, k=51) through the C++ restatement of the reference CPU path, hot stages on 1 core "
+                        "sample": f"the WHOLE workload ({args.workload or 'configC_k51: 96 x ~5 Mbp, k=51'}) through the C++ restatement of the reference CPU path, hot stages on 1 core "
                                   "(the reference's are single-threaded): recorded once by tests/golden/make_configC_golden.sh on " +
-                                  gj.get("host", "the build container") + " (NOT timed in this run: 12 CPU-minutes); its GFA md5 is the digest every "
+                                  gj.get("host", "the build container") + " (NOT timed in this run); its GFA md5 is the digest every "
                                   "device build of this run produced",
                         "gfa_md5": gj["gfa_md5"], "timed_in_this_run": sample}
                 except (KeyError, ValueError, TypeError):

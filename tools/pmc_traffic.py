@@ -27,7 +27,7 @@ def per_pack(path, pat, builds):
     return tot / (builds + 1)
 
 
-def main(fetch_csv, write_csv, n_text, tag, builds=7):
+def main(fetch_csv, write_csv, n_text, tag, builds=7, workload="configC_k51"):
     f, w = load(fetch_csv), load(write_csv)
     pick = lambda d, pat: sum(v for k, v in d.items() if pat in k)
     n_text = int(n_text)
@@ -40,8 +40,9 @@ def main(fetch_csv, write_csv, n_text, tag, builds=7):
     print(json.dumps({
         "source_hash": source_hash(),      # the sources the profiled library was built from (bench.py refuses the file when its library differs)
         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), tools/pmc_lean.sh (torch-free driver, "
-                  f"{builds} builds of config C per pass) on MI355X; profiles/{tag}_pmc_*_configC.csv",
-        "kernel": "insert_wave_kernel<2> (3 phase launches per build, summed)",
+                  f"{builds} builds of {workload} per pass) on MI355X; profiles/{tag}_pmc_*",
+        "workload": workload,
+        "kernel": "insert_wave_kernel<W> (all phase launches of a build, summed)",
         "fetch_size_raw_bytes": kf, "write_size_raw_bytes": kw,
         "calibration": {"kernel": "functor_kernel<PackFunctor>: reads n_text bytes with 16 B/lane loads, writes 0.375*n_text bytes",
                         "n_text": n_text, "fetch_raw_over_known": fcal, "write_raw_over_known": wcal},
@@ -53,4 +54,4 @@ def main(fetch_csv, write_csv, n_text, tag, builds=7):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:6])
+    main(*sys.argv[1:7])

@@ -44,11 +44,13 @@ class Timings(C.Structure):
                 ("analysis", C.c_double), ("finalize", C.c_double), ("n_candidates", C.c_uint32), ("n_levels", C.c_uint32),
                 ("fragments", C.c_double), ("union_pack", C.c_double), ("union_insert", C.c_double),
                 ("n_local_distinct", C.c_uint64), ("n_fragments", C.c_uint64), ("fragment_bytes", C.c_uint64),
-                ("upload_device_ms", C.c_double), ("path_runs_copied", C.c_uint64), ("path_entries_walked", C.c_uint64), ("position_retries", C.c_uint64)]
+                ("upload_device_ms", C.c_double), ("path_runs_copied", C.c_uint64), ("path_entries_walked", C.c_uint64), ("position_retries", C.c_uint64), ("n_candidates_owned", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int)      # ac_allreduce_fn
 
 EXPORTS = ["ac_compress_build", "ac_compress_build_multi", "ac_multi_info_get", "ac_compress_build_device", "ac_pack_text", "ac_text_size", "ac_layout_text", "ac_kmer_count",
            "ac_stats_pre", "ac_stats_post", "ac_unitig_count", "ac_unitig", "ac_unitigs_bulk", "ac_paths_bulk", "ac_unitig_positions", "ac_links",
@@ -56,7 +58,7 @@ EXPORTS = ["ac_compress_build", "ac_compress_build_multi", "ac_multi_info_get", 
            "ac_device_count", "ac_max_kmer", "ac_version", "ac_source_hash", "ac_set_stage_timing", "ac_random_access_ceilings", "ac_release_memory", "ac_end_repair_device", "ac_pairwise_distances", "ac_graph_from_gfa", "ac_graph_kmer_size", "ac_graph_seq_info", "ac_decompress_seq", "ac_decompress",
            "ac_shard_begin", "ac_shard_fragment_sizes", "ac_shard_fragments_export", "ac_shard_build_union",
            "ac_shard_unitig_count", "ac_shard_table_capacity", "ac_shard_bitmap_words", "ac_shard_bitmap_export", "ac_shard_build_novel", "ac_shard_links_export", "ac_shard_links_import",
-           "ac_shard_query_count", "ac_shard_query_key_words", "ac_shard_queries_export", "ac_shard_answer", "ac_shard_walk", "ac_shard_queries_route", "ac_shard_walk_routed", "ac_shard_local_distinct", "ac_shard_set_distinct_upper_bound", "ac_shard_distinct_count", "ac_shard_degrees_export", "ac_shard_build_graph", "ac_gfa_string_parts", "ac_shard_reduce_export", "ac_shard_reduce_import", "ac_shard_finish",
+           "ac_shard_query_count", "ac_shard_query_key_words", "ac_shard_queries_export", "ac_shard_answer", "ac_shard_walk", "ac_shard_queries_route", "ac_shard_walk_routed", "ac_shard_local_distinct", "ac_shard_set_distinct_upper_bound", "ac_shard_distinct_count", "ac_shard_degrees_export", "ac_shard_build_graph", "ac_gfa_string_parts", "ac_shard_reduce_export", "ac_shard_reduce_import", "ac_shard_finish", "ac_shard_set_allreduce", "ac_device_copy",
            "ac_shard_path_entries", "ac_shard_paths_export", "ac_shard_free", "ac_graph_set_paths", "ac_graph_seq_count", "ac_path_counts",
            "ac_seqs_load", "ac_seqs_from_raw", "ac_seqs_count", "ac_seqs_assembly_count", "ac_seqs_views", "ac_seqs_get",
            "ac_seqs_repair_seconds", "ac_seqs_metrics_yaml", "ac_seqs_free", "ac_compress_seqs", "ac_compress_dir", "ac_compress_dir_multi"]
@@ -265,7 +267,7 @@ class MultiInfo(C.Structure):
                [(n, C.c_uint64) for n in ("bytes_fragments", "bytes_bitmap", "bytes_degrees", "bytes_links", "bytes_queries", "bytes_answers",
                                           "bytes_reduce", "queries_total", "queries_sent_away", "table_capacity_max", "table_capacity_sum",
                                           "union_text_bytes", "fragments", "distinct")] + \
-               [("seconds_total", C.c_double), ("seconds_exchange_max", C.c_double)]
+               [("seconds_total", C.c_double), ("seconds_exchange_max", C.c_double), ("candidates_total", C.c_uint64), ("candidates_owned_max", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -273,6 +273,7 @@ int ac_multi_info_get(const ac_graph* g, ac_multi_info* o) {
     o->table_capacity_max = m.table_capacity_max; o->table_capacity_sum = m.table_capacity_sum;
     o->union_text_bytes = m.union_text_bytes; o->fragments = m.fragments; o->distinct = m.distinct;
     o->seconds_total = m.seconds_total; o->seconds_exchange_max = m.seconds_exchange_max;
+    o->candidates_total = m.candidates_total; o->candidates_owned_max = m.candidates_owned_max;
     return 0;
 }
 
@@ -483,6 +484,27 @@ int ac_shard_reduce_import(ac_shard* s, const void* d_sum_i32, const void* d_min
         select_device(s->device);
         s->b->reduce_import((const int32_t*)d_sum_i32, (const int32_t*)d_min_i32);
         s->phase = 7;
+    });
+}
+int ac_shard_set_allreduce(ac_shard* s, ac_allreduce_fn fn, void* user) {
+    return guarded([&] {
+        if (s->phase > 7) throw DeviceError("ac_shard_set_allreduce: wrong phase");
+        if (!fn) { s->b->set_tail_exchange(nullptr); return; }
+        s->b->set_tail_exchange([fn, user](void* d_buf, uint64_t count, int dtype, int op) {
+            if (fn(user, d_buf, count, dtype, op) != 0) throw DeviceError("the caller's all-reduce failed (ac_shard_set_allreduce)");
+        });
+    });
+}
+int ac_device_copy(void* dst, const void* src, uint64_t bytes, int device) {
+    return guarded([&] {
+        if (!bytes) return;
+#ifdef AC_EMU
+        (void)device;
+        memmove(dst, src, (size_t)bytes);
+#else
+        AC_HIP_CHECK(hipSetDevice(device));
+        AC_HIP_CHECK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDefault));
+#endif
     });
 }
 int ac_shard_finish(ac_shard* s, int want, ac_graph** out) {
@@ -759,6 +781,7 @@ int ac_timings_get(const ac_graph* g, ac_timings* o) {
     o->n_local_distinct = t.n_local_distinct; o->n_fragments = t.n_fragments; o->fragment_bytes = t.fragment_bytes;
     o->upload_device_ms = t.upload_device_ms;
     o->path_runs_copied = t.path_runs_copied; o->path_entries_walked = t.path_entries_walked; o->position_retries = t.position_retries;
+    o->n_candidates_owned = t.n_candidates_owned;
     return 0;
 }
 // The same for a caller that was compiled against another version of the header: at most out_size bytes are written (the struct only

@@ -53,6 +53,8 @@ inline void atomic_or32(u32* p, u32 v) { *p |= v; }
 inline void atomic_or64(u64* p, u64 v) { *p |= v; }
 inline void atomic_min32(u32* p, u32 v) { if (v < *p) *p = v; }
 inline void atomic_max32(u32* p, u32 v) { if (v > *p) *p = v; }
+inline u32 atomic_cas32(u32* p, u32 expected, u32 desired) { u32 old = *p; if (old == expected) *p = desired; return old; }
+inline u32 atomic_load32(const u32* p) { return *p; }
 #else
 __device__ inline u64 atomic_cas64(u64* p, u64 expected, u64 desired) {
     return (u64)atomicCAS((unsigned long long*)p, (unsigned long long)expected, (unsigned long long)desired);
@@ -66,6 +68,8 @@ __device__ inline void atomic_or32(u32* p, u32 v) { atomicOr(p, v); }
 __device__ inline void atomic_or64(u64* p, u64 v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
 __device__ inline void atomic_min32(u32* p, u32 v) { atomicMin(p, v); }
 __device__ inline void atomic_max32(u32* p, u32 v) { atomicMax(p, v); }
+__device__ inline u32 atomic_cas32(u32* p, u32 expected, u32 desired) { return atomicCAS(p, expected, desired); }
+__device__ inline u32 atomic_load32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }      // (past this CU's L1: another CU's store is seen)
 #endif
 
 // ---- device context ------------------------------------------------------------------------------------------------------------

@@ -666,6 +666,10 @@ struct GraphBuilder::Impl {
     template <int W> void walk();
     template <int W> bool walk_copy(u32 PC);            // K10c: false = not worth it (or not possible) for this text, nothing done
     template <int W> void tail(FinalGraph* out, bool want_graph, bool want_paths);
+    // sharded builds: in-place all-reduce of a device buffer over the ranks (dtype 0 = uint8, 1 = int32; op 0 = SUM, 1 = MIN), given by
+    // whoever drives the ranks.  With it the tail runs expand_repeats on this rank's share of the junctions only (conflict components,
+    // kernels_tail.inc) and merges the sequences; without it every rank runs all of them.
+    std::function<void(void*, uint64_t, int, int)> tail_xchg;
 };
 
 // K2 insert.  Capacity from the reference's own capacity hint (assembly_count, kmer_graph.rs:40): similar assemblies
@@ -1352,6 +1356,9 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     u64 final_total = total;
     int passes = 0;
     u32 n_cand = 0, n_levels = 0;
+    const bool partitioned = n_owners > 1 && (bool)tail_xchg;      // (decided by the driver: the same on every rank)
+    DBuf<u8> jowner; DBuf<u32> owned_count, gpre, gpost;
+    u32 n_cand_owned = 0;
     {
         u64 J = (u64)U * 2;
         DBuf<u32> cflag(J + 1), cpos(J + 1), prio(J);
@@ -1360,7 +1367,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         exclusive_scan_u32(cflag.ptr(), cpos.ptr(), J + 1);
         n_cand = read_scalar(cpos.ptr() + J);
         if (n_cand == 0) {
-            passes = 1;   // the reference's single pass that moves nothing
+            passes = 1;   // the reference's single pass that moves nothing (the same on every rank of a sharded build: nothing to merge)
         } else {
             u64 C = n_cand;
             DBuf<u32> clist(C), level(C);
@@ -1369,6 +1376,15 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             launch(C, FillU32Functor{level.ptr(), 1u});
             DBuf<u32> changed(8), preds(C * MAX_PREDS); DBuf<u8> npred(C);
             launch(C, LevelPredsFunctor{L, cand.ptr(), clist.ptr(), prio.ptr(), C, preds.ptr(), npred.ptr()});
+            if (partitioned) {      // this rank's share of the junctions: the conflict components it owns
+                DBuf<u32> parent(C);
+                jowner.alloc(C); owned_count.alloc(1); owned_count.fill_bytes(0);
+                launch(C, UfInitFunctor{parent.ptr()});
+                launch(C, UfUnionFunctor{preds.ptr(), npred.ptr(), C, parent.ptr()});
+                launch(C, UfOwnerFunctor{parent.ptr(), n_owners, jowner.ptr()});
+                launch_full((J + 63) & ~63ULL, OwnedDirtyFunctor{cand.ptr(), prio.ptr(), jowner.ptr(), my_owner, dirty.ptr(), owned_count.ptr(), J});
+                gpre.alloc(U, true); gpost.alloc(U, true);
+            }
             for (;;) {   // longest-path levels of the conflict DAG by relaxation (monotone, so stale reads only delay); eight
                 changed.fill_bytes(0);       // sweeps per host check, converged when the last of them changed nothing
                 for (int it = 0; it < 8; it++)
@@ -1400,6 +1416,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             // last pass — and in between whenever the pool is a quarter full: a side that gains again gets a new piece holding its
             // old one as well, so without this the pool use of a many-pass input grows with the square of the passes.
             auto rewrite = [&] {
+                if (partitioned) launch(U, ExpFoldFunctor{e, gpre.ptr(), gpost.ptr()});      // (what the fold makes of the gained pieces: the merge below)
                 launch((u64)U + 1, ExpLenFunctor{e, len64.ptr(), U});
                 exclusive_scan_u64(len64.ptr(), noff.ptr(), (u64)U + 1);
                 final_total = read_scalar(noff.ptr() + U);
@@ -1457,11 +1474,43 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                 if (sh[1] == 0) break;
                 if (used > sub_limit || expand_rewrite_always()) rewrite();
             }
-            if (moved_since_rewrite) rewrite();
+            if (!partitioned) { if (moved_since_rewrite) rewrite(); }
+            else {
+                // every rank ran its own junctions: merge what they did to the unitigs, field by field (kernels_tail.inc), and agree on
+                // the number of passes (the reference's count is that of the component that needed most)
+                DBuf<u8> fown((u64)U * 3); DBuf<int32_t> lens3((u64)U * 3 + 1);
+                launch(U, FieldOwnerFunctor{L, cand.ptr(), prio.ptr(), jowner.ptr(), n_owners, fown.ptr()});
+                launch(U, OwnedLensFunctor{e, fown.ptr(), gpre.ptr(), gpost.ptr(), my_owner, lens3.ptr()});
+                const int32_t neg_passes = -(int32_t)passes;
+                copy_h2d(lens3.ptr() + (u64)U * 3, &neg_passes, 4);
+                stream_sync();
+                tail_xchg(lens3.ptr(), (u64)U * 3, 1, 0);
+                tail_xchg(lens3.ptr() + (u64)U * 3, 1, 1, 1);      // MIN of the negated counts
+                launch((u64)U + 1, Lens3SumFunctor{lens3.ptr(), len64.ptr(), U});
+                exclusive_scan_u64(len64.ptr(), noff.ptr(), (u64)U + 1);
+                int32_t min_neg = 0;
+                {
+                    ReadBatch rb;
+                    rb.add(&final_total, noff.ptr() + U, 8);
+                    rb.add(&min_neg, lens3.ptr() + (u64)U * 3, 4);
+                    rb.add(&n_cand_owned, owned_count.ptr(), 4);
+                    rb.run();
+                }
+                passes = -min_neg;
+                if (final_total > seq_alt.size()) throw DeviceError("internal error: merged sequences longer than before expand_repeats");
+                const u32 per = 16;
+                launch((final_total + per - 1) / per, MergeSeqFunctor{e, fown.ptr(), gpre.ptr(), gpost.ptr(), my_owner, lens3.ptr(), noff.ptr(), U, final_total, alt, per});
+                stream_sync();
+                tail_xchg(alt, final_total, 0, 0);
+                launch(U, ExpResetFunctor{e, noff.ptr()});
+                std::swap(cur, alt);
+                e.cur = cur;
+            }
             (void)moved;
         }
     }
     tm->simplify_passes = (u32)passes; tm->n_candidates = n_cand; tm->n_levels = n_levels;
+    tm->n_candidates_owned = partitioned && n_cand ? n_cand_owned : n_cand;
     lap(&tm->expand);
 
     // K15b second renumber_unitigs (graph_simplification.rs:39): a stable sort of the CURRENT order on the new
@@ -2417,6 +2466,7 @@ void GraphBuilder::reduce_import(const int32_t* d_sum, const int32_t* d_min) {
     launch(m.U, ReduceImportFunctor{m.depth.ptr(), m.fs0.ptr(), m.fe0.ptr(), m.minpos_fwd.ptr(), m.minpos_rev.ptr(), m.U, d_sum, d_min});
     stream_sync();
 }
+void GraphBuilder::set_tail_exchange(std::function<void(void*, uint64_t, int, int)> all_reduce) { impl_->tail_xchg = std::move(all_reduce); }
 void GraphBuilder::shard_finish(FinalGraph* out, bool want_graph, bool want_paths) {
     impl_->t0 = now_s();
     AC_DISPATCH_W(tail, (*impl_, out, want_graph, want_paths))

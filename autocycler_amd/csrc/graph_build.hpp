@@ -7,6 +7,7 @@
 // host_tail.cpp.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -33,6 +34,7 @@ struct BuildTimings {                   // seconds; device stages are bracketed 
     uint32_t insert_launches = 0;       // phases of the run-following insert (same kernel, launched per phase)
     uint64_t insert_real = 0;           // positions that actually touched the table
     uint32_t simplify_passes = 0, n_candidates = 0, n_levels = 0;   // expand_repeats: passes, candidate junctions, conflict levels
+    uint32_t n_candidates_owned = 0;    // ... and the candidate junctions THIS rank ran (a sharded build with a partitioned tail; else all of them)
     // sharded builds (one job over several devices)
     uint32_t local_hint = 0, graph_hint = 0;   // capacity hints of the local / graph table (assembly counts)
     double fragments = 0;               // novel runs of this rank -> fragment text
@@ -110,6 +112,10 @@ class GraphBuilder {
     void shard_walk_routed(const void* d_routed_answers);
     void reduce_export(int32_t* d_sum, int32_t* d_min);             // 3U and 2U int32
     void reduce_import(const int32_t* d_sum, const int32_t* d_min);
+    // Before shard_finish (optional, the same choice on every rank): an in-place all-reduce of a device buffer over the ranks (dtype 0 =
+    // uint8, 1 = int32; op 0 = SUM, 1 = MIN).  With it expand_repeats runs on this rank's share of the junctions only — the conflict
+    // components it owns — and the ranks' results are merged by two SUM all-reduces (field lengths, then the sequence bytes).
+    void set_tail_exchange(std::function<void(void*, uint64_t, int, int)> all_reduce);
     void shard_finish(FinalGraph* out, bool want_graph, bool want_paths);
     uint64_t path_entry_count() const;
     void paths_export(void* d_out);                                 // int32 per entry, final numbers

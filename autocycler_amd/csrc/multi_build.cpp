@@ -367,7 +367,17 @@ void rank_main(Shared& S, int rank) {
         rc.xarena.rewind(mk);
     }
     lapmsg("reduce");
-    // ---- the order-sensitive tail (identical on every rank); rank 0 keeps unitigs + links, every rank the paths of its own sequences
+    // ---- the order-sensitive tail; expand_repeats on this rank's share of the junctions (conflict components), the results merged by two
+    // SUM all-reduces inside shard_finish (kernels_tail.inc; AC_MULTI_TAIL=replicated: every rank runs every junction, as before round 4);
+    // rank 0 keeps unitigs + links, every rank the paths of its own sequences
+    uint64_t tail_bytes = 0;
+    const char* tail_env = getenv("AC_MULTI_TAIL");
+    const bool tail_replicated = tail_env && std::string(tail_env) == "replicated";
+    if (!tail_replicated)
+        b.set_tail_exchange([&](void* d_buf, uint64_t count, int dtype, int op) {
+            tail_bytes += count * (dtype == 0 ? 1 : 4);
+            timed([&] { X.all_reduce(rank, d_buf, count, dtype == 0 ? X_U8 : X_I32, op == 0 ? X_SUM : X_MIN); });
+        });
     b.shard_finish(&S.graphs[rank], rank == 0, true);
     S.tms[rank] = b.timings();
     lapmsg("finish");
@@ -386,6 +396,9 @@ void rank_main(Shared& S, int rank) {
         st.table_capacity_max = std::max<uint64_t>(st.table_capacity_max, b.timings().table_capacity);
         st.table_capacity_sum += b.timings().table_capacity;
         st.union_text_bytes = nb_total; st.fragments = nf_total; st.distinct = N;
+        st.candidates_total = b.timings().n_candidates;
+        st.candidates_owned_max = std::max<uint64_t>(st.candidates_owned_max, b.timings().n_candidates_owned);
+        st.bytes_tail += tail_bytes * (uint64_t)(R - 1) / (uint64_t)R * 2;
     }
 }
 

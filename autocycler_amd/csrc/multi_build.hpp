@@ -22,6 +22,8 @@ struct MultiStats {
     uint64_t table_capacity_max = 0, table_capacity_sum = 0;   // the ranks' shares of the job's k-mer table
     uint64_t union_text_bytes = 0, fragments = 0, distinct = 0;
     double seconds_total = 0, seconds_exchange_max = 0;      // wall clock of the call / the slowest rank's time inside exchanges
+    uint64_t candidates_total = 0, candidates_owned_max = 0; // expand_repeats: candidate junctions of the job / the most one rank ran (its conflict components)
+    uint64_t bytes_tail = 0;                                 // the tail's merge: field lengths + sequence bytes (all-reduces)
 };
 
 // seqs: all sequences of the job in input order; devices[r] = HIP ordinal of rank r (an ordinal may appear more than once: those ranks

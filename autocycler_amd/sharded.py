@@ -20,7 +20,8 @@ the GPU box, "gloo" in the CPU test-suite):
       all-to-all (reverse)  the answers, in the order the keys were sent           (8 B per 256 input positions, once)
     ac_shard_walk_routed    the paths of the local sequences
       all-reduce SUM, MIN   per-unitig depth / path-end counts, smallest positions  (5 x U int32)
-    ac_shard_finish         order-sensitive tail (identical on every rank)
+    ac_shard_finish         order-sensitive tail; expand_repeats on this rank's share of the junctions (conflict components), merged by
+      all-reduce SUM (x2)   field lengths (12 B per unitig) and sequence bytes, through the callback of ac_shard_set_allreduce
       [gather to root]      optional: paths of all sequences in final numbers -> one rank holds the whole GFA;
                             by default every rank keeps the P lines of its own sequences (Graph.gfa(parts=2))
 
@@ -154,7 +155,7 @@ def _check(lib, rc):
         raise _capi.AutocyclerError(lib.ac_last_error().decode(errors="replace"))
 
 
-def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False):
+def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False, partition_tail=True):
     """Runs one sharded compress build.  Returns (Graph, info).  On `root` the Graph holds unitigs, links and
     statistics; every rank's Graph holds the paths of its own sequences (Graph.gfa(parts=2) -> its P lines), unless
     gather_paths: then root's Graph holds the paths of ALL sequences (Graph.gfa() is the whole file) and the other
@@ -241,11 +242,32 @@ def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False):
         comm.all_reduce(red[:3 * U], "SUM")
         comm.all_reduce(red[3 * U:], "MIN")
         _check(lib, lib.ac_shard_reduce_import(h, C.c_void_p(red.data_ptr()), C.c_void_p(red.data_ptr() + 12 * U)))
+        # the tail: expand_repeats on this rank's share of the junctions, merged by all-reduces the library asks for through this callback
+        # (a device buffer of its own: staged through a torch tensor)
+        def _allreduce(_user, d_buf, count, dtype, op):
+            try:
+                t = torch.empty(count, dtype=torch.uint8 if dtype == 0 else torch.int32, device=dev)
+                nbytes = count * (1 if dtype == 0 else 4)
+                if lib.ac_device_copy(C.c_void_p(t.data_ptr()), C.c_void_p(d_buf), C.c_uint64(nbytes), C.c_int(device_index)):
+                    return 1
+                comm.all_reduce(t, "SUM" if op == 0 else "MIN")
+                if dev.type == "cuda":
+                    torch.cuda.synchronize(dev)
+                return lib.ac_device_copy(C.c_void_p(d_buf), C.c_void_p(t.data_ptr()), C.c_uint64(nbytes), C.c_int(device_index))
+            except Exception:      # noqa: BLE001 — an exception must not unwind through the C frames: the library reports the failure
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = _capi.ALLREDUCE_FN(_allreduce)
+        if not comm.local_only and partition_tail:
+            _check(lib, lib.ac_shard_set_allreduce(h, cb, None))
         g = C.c_void_p()
         is_root = comm.rank == root
         want = (1 if is_root else 0) | (0 if (gather_paths and not comm.local_only) else 2)
         _check(lib, lib.ac_shard_finish(h, C.c_int(want), C.byref(g)))
         graph = _capi.Graph(lib, g, shard.n_seqs)
+        tmg = graph.timings()
+        candidates, candidates_owned = tmg["n_candidates"], tmg["n_candidates_owned"]
         if gather_paths and not comm.local_only:      # paths of all sequences -> root
             ne = lib.ac_shard_path_entries(h)
             psz = comm.all_gather_sizes([ne, shard.n_seqs])
@@ -267,6 +289,7 @@ def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False):
                                                    C.c_int(device_index)))
                 graph.n_seqs = n_total
         return graph, {"fragments": nf_total, "union_text_bytes": nb_total, "distinct": N, "unitigs": U, "comm_s": comm.seconds,
-                       "table_capacity": table_capacity, "walk_queries": nq, "walk_queries_sent_away": queries_sent_away}
+                       "table_capacity": table_capacity, "walk_queries": nq, "walk_queries_sent_away": queries_sent_away,
+                       "candidates": candidates, "candidates_owned": candidates_owned}
     finally:
         lib.ac_shard_free(h)

@@ -65,6 +65,7 @@ typedef struct {
     double upload_device_ms;    /* ac_compress_build only: first H2D copy issued -> last chunk landed and packed (HIP events) */
     uint64_t path_runs_copied, path_entries_walked;   /* the copying path walk: runs whose entries were copied, entries really walked (0, 0: plain walk) */
     uint64_t position_retries;   /* builds repeated with exact smallest positions because expand_repeats met a common sequence longer than the bound kept (AC_POS_CAP) */
+    uint32_t n_candidates_owned; /* the candidate junctions THIS rank ran (a job over several devices with a partitioned tail; else = n_candidates) */
 } ac_timings;
 
 /* Replaces compress.rs:42-44.  k: --kmer (odd).  assembly_count: the reference's capacity hint
@@ -89,6 +90,8 @@ typedef struct {
     uint64_t table_capacity_max, table_capacity_sum;  /* slots of the ranks' shares of the job's k-mer table */
     uint64_t union_text_bytes, fragments, distinct;
     double seconds_total, seconds_exchange_max;
+    /* expand_repeats partitioned by conflict component: candidate junctions of the job / the most any one rank ran */
+    uint64_t candidates_total, candidates_owned_max;
 } ac_multi_info;
 int ac_multi_info_get(const ac_graph*, ac_multi_info* out);
 
@@ -176,6 +179,15 @@ int ac_shard_queries_route(ac_shard*, uint32_t n_shards, void* d_routed_keys_u64
 int ac_shard_walk_routed(ac_shard*, const void* d_routed_answers_u64 /* query_count */);
 int ac_shard_reduce_export(ac_shard*, void* d_sum_i32 /* 3U */, void* d_min_i32 /* 2U */);
 int ac_shard_reduce_import(ac_shard*, const void* d_sum_i32, const void* d_min_i32);
+/* Optional, before ac_shard_finish, the same choice on every rank: an in-place all-reduce of a DEVICE buffer over the ranks (dtype 0 =
+ * uint8, 1 = int32; op 0 = SUM, 1 = MIN; returns 0 on success), called from inside ac_shard_finish on the calling thread.  With it the
+ * order-sensitive tail is no longer replicated in full: expand_repeats (graph_simplification.rs:43-86) runs on this rank's share of the
+ * junctions — the conflict components it owns — and the ranks' results are merged by two SUM all-reduces (field lengths, sequence bytes). */
+typedef int (*ac_allreduce_fn)(void* user, void* d_buf, uint64_t count, int dtype, int op);
+int ac_shard_set_allreduce(ac_shard*, ac_allreduce_fn fn, void* user);
+/* Plain copy between two buffers of `device` (or host memory), finished on return: for callers whose collectives want buffers of their
+ * own (autocycler_amd/sharded.py stages ac_allreduce_fn's buffer through a torch tensor with it).  Takes no library lock. */
+int ac_device_copy(void* dst, const void* src, uint64_t bytes, int device);
 int ac_shard_finish(ac_shard*, int want, ac_graph** out);
 uint64_t ac_shard_path_entries(const ac_shard*);
 int ac_shard_paths_export(ac_shard*, void* d_out_i32 /* ac_shard_path_entries() */);

@@ -47,6 +47,13 @@ def run_case(lib_path, k, seqs, filenames, headers, comm, device, repair=True, d
     shard = local_shard(lib, k, loaded, lo, hi, local_assemblies, device)
     g, info = sharded.sharded_build(lib, shard, comm, device_index=device_index, root=0, gather_paths=gather_paths)
     assert g.stats_post["unitigs"] == info["unitigs"]
+    # the tail is partitioned: a rank runs the junctions of its own conflict components only (about 1 / world of them)
+    # (whole components: a small graph whose largest component is a good part of it balances less well)
+    assert info["candidates_owned"] <= info["candidates"]
+    if comm.world > 1 and info["candidates"] >= 400:
+        assert info["candidates_owned"] * comm.world <= 2.0 * info["candidates"] + 128, (info["candidates_owned"], info["candidates"], comm.world)
+    if comm.world == 1:
+        assert info["candidates_owned"] == info["candidates"]
     if gather_paths or comm.world == 1:
         if comm.rank != 0:
             return None

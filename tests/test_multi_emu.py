@@ -47,6 +47,25 @@ def test_synthetic_and_mixed_species_jobs(emu, world):
     assert info["bytes_queries"] == info["queries_sent_away"] * 8 * 1      # k = 21: one-word keys, each sent to exactly ONE rank
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_expand_repeats_is_partitioned_by_conflict_component(emu, world, monkeypatch):
+    """the order-sensitive tail is no longer replicated in full — a rank runs only the junctions of the conflict
+    components it owns (1 / world of them, within the imbalance of whole components), the results are merged by all-reduces, and the
+    graph is still the oracle's (run_case compares).  Also with a rank-local rewrite in between (the merge then separates folded
+    pieces), and against the replicated tail."""
+    for name, (seqs, fn, hd) in {"one species": M.synth_case(8, 60_000, 3_000, 1e-3, 1e-4, 7), "mixed": M.mixed_case(4, 4, 40_000)}.items():
+        gfa, info = M.run_case(emu, 51, seqs, fn, hd, [0] * world)
+        total, most = info["candidates_total"], info["candidates_owned_max"]
+        assert total > 500 and most * world <= 1.5 * total + 64, (name, world, total, most)
+        monkeypatch.setenv("AC_EXPAND_REWRITE_ALWAYS", "1")
+        gfa_rw, _ = M.run_case(emu, 51, seqs, fn, hd, [0] * world)
+        monkeypatch.delenv("AC_EXPAND_REWRITE_ALWAYS")
+        monkeypatch.setenv("AC_MULTI_TAIL", "replicated")
+        gfa_rep, rep = M.run_case(emu, 51, seqs, fn, hd, [0] * world)
+        monkeypatch.delenv("AC_MULTI_TAIL")
+        assert gfa == gfa_rw == gfa_rep and rep["candidates_owned_max"] == rep["candidates_total"] == total
+
+
 def test_errors_come_back_from_the_rank_threads(emu):
     import ctypes as C
     from autocycler_amd import AutocyclerError

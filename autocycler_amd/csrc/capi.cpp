@@ -352,6 +352,28 @@ int ac_shard_fragments_export(ac_shard* s, void* d_text_out, void* d_meta_out) {
         s->b->fragments_export(d_text_out, d_meta_out);
     });
 }
+// The fragment text as 2-bit codes on the union text's word grid (a quarter of the bytes; nothing to pack on the receiving side).
+uint64_t ac_shard_fragment_packed_words(const ac_shard* s, uint64_t union_off) { return s->phase >= 1 ? s->b->fragment_packed_words(union_off) : 0; }
+int ac_shard_fragments_export_packed(ac_shard* s, uint64_t union_off, void* d_words_out, void* d_meta_out) {
+    return guarded([&] {
+        if (s->phase < 1) throw DeviceError("ac_shard_fragments_export_packed: no fragments yet");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->fragments_export_packed(union_off, d_words_out, d_meta_out);
+    });
+}
+int ac_shard_build_union_packed(ac_shard* s, uint32_t rank, uint32_t n_shards, const void* d_staged_words, const uint64_t* first_word,
+                                const uint64_t* n_words, uint64_t n_union_text, const void* d_meta, uint64_t n_fragments_total) {
+    return guarded([&] {
+        if (s->phase != 1) throw DeviceError("ac_shard_build_union_packed: wrong phase");
+        if (!first_word || !n_words) throw DeviceError("ac_shard_build_union_packed: no word table");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->shard_build_union_packed(rank, n_shards, d_staged_words, first_word, n_words, n_union_text, d_meta, n_fragments_total);
+        s->n_shards = n_shards;
+        s->phase = 2;
+    });
+}
 int ac_shard_build_union(ac_shard* s, uint32_t rank, uint32_t n_shards, const void* d_union_text, uint64_t n_union_text,
                          const void* d_meta, uint64_t n_fragments_total) {
     return guarded([&] {

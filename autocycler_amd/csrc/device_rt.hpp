@@ -386,6 +386,15 @@ class DBuf {   // a typed slice of the device arena (no ownership: the arena res
         else AC_HIP_CHECK(hipMemsetAsync((u8*)p_ + from, byte, bytes - from, s));
 #endif
     }
+    void fill_bytes_first(size_t upto, int byte) {      // bytes [0, upto)
+        const size_t bytes = std::min(n_ * sizeof(T), upto);
+        if (!bytes) return;
+#ifdef AC_EMU
+        memset(p_, byte, bytes);
+#else
+        FillQueue::get().add(p_, bytes, byte);
+#endif
+    }
     T* ptr() { return p_; }
     const T* ptr() const { return p_; }
     size_t size() const { return n_; }

@@ -577,7 +577,7 @@ struct GraphBuilder::Impl {
     u32 pos_cap_now = 0xFFFFFFFFu; bool exact_positions = false;
     DBuf<u8> maybe_dest; bool maybe_dest_valid = false;      // (unitig, side) that may become an expand_repeats destination (walk's position filter)
     // fragments of a sharded build
-    DBuf<u8> frag_text; DBuf<u64> frag_meta; u64 frag_bytes = 0, n_frags = 0;
+    DBuf<u8> frag_text; DBuf<u64> frag_meta, frag_fpos, frag_boff; u64 frag_bytes = 0, n_frags = 0;      // (frag_text: only when someone asks for bytes)
     u64 distinct_upper = 0;    // sharded builds: sum of the ranks' local distinct counts (0 = unknown)
 
     void begin(BuildTimings* t) {
@@ -891,14 +891,14 @@ template <int W> void GraphBuilder::Impl::fragments() {
     DBuf<u64> run_start(n_runs), run_end(n_runs);
     launch(nw, RunEdgeFillFunctor{lbm.ptr(), nw, so.ptr(), eo.ptr(), run_start.ptr(), run_end.ptr()});
     n_frags = n_runs + 2 * (u64)loc.n_seqs;
-    DBuf<u64> fpos(n_frags), blen(n_frags + 1), boff(n_frags + 1);
+    DBuf<u64> blen(n_frags + 1);
+    DBuf<u64>& fpos = frag_fpos; DBuf<u64>& boff = frag_boff;      // (kept: fragments_export / fragments_export_packed read them)
+    fpos.alloc(n_frags); boff.alloc(n_frags + 1);
     frag_meta.alloc(n_frags);
     launch(n_frags + 1, FragMetaFunctor{loc.ctx((int)k), run_start.ptr(), run_end.ptr(), n_runs, n_frags, fpos.ptr(), frag_meta.ptr(),
                                         blen.ptr(), counters.ptr() + 6});
     exclusive_scan_u64(blen.ptr(), boff.ptr(), n_frags + 1);
     frag_bytes = read_scalar(boff.ptr() + n_frags);
-    frag_text.alloc(frag_bytes);
-    launch((frag_bytes + 63) / 64, FragCopyFunctor{loc.bits.ptr(), loc.mask.ptr(), fpos.ptr(), boff.ptr(), n_frags, frag_bytes, frag_text.ptr()});
     {
         u32 frag_err = 0, pack_bad[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
         ReadBatch rb;
@@ -2349,12 +2349,34 @@ void GraphBuilder::set_distinct_upper_bound(uint64_t n) { impl_->distinct_upper 
 uint64_t GraphBuilder::fragment_text_bytes() const { return impl_->frag_bytes; }
 uint64_t GraphBuilder::fragment_count() const { return impl_->n_frags; }
 void GraphBuilder::fragments_export(void* d_text_out, void* d_meta_out) {
-    copy_d2d(d_text_out, impl_->frag_text.ptr(), impl_->frag_bytes);
+    Impl& m = *impl_;
+    launch((m.frag_bytes + 63) / 64, FragCopyFunctor{m.loc.bits.ptr(), m.loc.mask.ptr(), m.frag_fpos.ptr(), m.frag_boff.ptr(), m.n_frags, m.frag_bytes, (u8*)d_text_out});
     copy_d2d(d_meta_out, impl_->frag_meta.ptr(), impl_->n_frags * 8);
     stream_sync();
 }
+// The fragment text as 2-bit codes on the union text's word grid (FragPackFunctor): union_off = where this rank's stretch begins in
+// the union text ('$' + the ranks' fragment texts in rank order).
+uint64_t GraphBuilder::fragment_packed_words(uint64_t union_off) const {
+    const u64 n = impl_->frag_bytes;
+    return n ? ((union_off + n - 1) >> 5) - (union_off >> 5) + 1 : 0;
+}
+void GraphBuilder::fragments_export_packed(uint64_t union_off, void* d_words_out, void* d_meta_out) {
+    Impl& m = *impl_;
+    const u64 nw = fragment_packed_words(union_off);
+    if (nw) launch(nw, FragPackFunctor{m.loc.bits.ptr(), m.loc.mask.ptr(), m.frag_fpos.ptr(), m.frag_boff.ptr(), m.n_frags, m.frag_bytes, union_off, (u64*)d_words_out});
+    copy_d2d(d_meta_out, m.frag_meta.ptr(), m.n_frags * 8);
+    stream_sync();
+}
+void GraphBuilder::shard_build_union_packed(uint32_t rank, uint32_t n_shards, const void* d_staged_words, const uint64_t* first_word,
+                                            const uint64_t* n_words, uint64_t n_union_text, const void* d_meta, uint64_t n_frags_total) {
+    build_union_impl(rank, n_shards, nullptr, d_staged_words, first_word, n_words, n_union_text, d_meta, n_frags_total);
+}
 void GraphBuilder::shard_build_union(uint32_t rank, uint32_t n_shards, const uint8_t* d_union_text, uint64_t n_union_text,
                                      const void* d_meta, uint64_t n_frags_total) {
+    build_union_impl(rank, n_shards, d_union_text, nullptr, nullptr, nullptr, n_union_text, d_meta, n_frags_total);
+}
+void GraphBuilder::build_union_impl(uint32_t rank, uint32_t n_shards, const uint8_t* d_union_text, const void* d_staged_words, const uint64_t* first_word,
+                                    const uint64_t* n_words, uint64_t n_union_text, const void* d_meta, uint64_t n_frags_total) {
     if (n_shards == 0 || rank >= n_shards) throw DeviceError("invalid rank / shard count");
     Impl& m = *impl_;
     m.t0 = now_s();
@@ -2377,7 +2399,24 @@ void GraphBuilder::shard_build_union(uint32_t rank, uint32_t n_shards, const uin
     m.uni.set_table(off, len, d1, d2, &flags);
     m.G = &m.uni;
     tm_.graph_hint = n_shards;
-    m.uni.pack();
+    if (d_union_text) m.uni.pack();
+    else {      // the ranks' code words are here already: OR them into place; the mask plane follows from the fragment records
+        PackedText& u = m.uni;
+        u.pack_alloc();
+        const u64 groups = (n_union_text + 31) / 32;
+        u.bits.fill_bytes(0);                                          // (pack_alloc only cleared the slack behind the text)
+        u.mask.fill_bytes_first(((n_union_text + 63) / 64) * 8, 0);   // (... and set the mask's slack: MaskTableFunctor sets the bits of the text's own words)
+        u64 staged_at = 0;
+        for (uint32_t r = 0; r < n_shards; r++) {
+            if (n_words[r]) {
+                if (first_word[r] + n_words[r] > groups) throw DeviceError("fragment words beyond the union text");
+                launch(n_words[r], OrWordsFunctor{(const u64*)d_staged_words + staged_at, n_words[r], first_word[r], u.bits.ptr()});
+            }
+            staged_at += n_words[r];
+        }
+        launch((u64)u.n_seqs + 1, MaskTableFunctor{u.seq_off.ptr(), u.seq_len.ptr(), u.seq_d1.ptr(), u.seq_d2.ptr(), u.n_seqs, (int)impl_->k, n_union_text, u.mask.ptr()});
+        u.packed = true;
+    }
     m.lap(&tm_.union_pack);
     m.n_owners = n_shards; m.my_owner = rank;      // this rank's table holds the k-mers whose home hash it owns
     AC_DISPATCH_W(table, (*impl_))

@@ -90,6 +90,13 @@ class GraphBuilder {
     uint64_t fragment_text_bytes() const;
     uint64_t fragment_count() const;
     void fragments_export(void* d_text_out, void* d_meta_out);      // device buffers: text bytes, 8 bytes per fragment
+    // The same text as 2-bit codes on the union text's word grid — a quarter of the bytes, and nothing to pack on the receiving side.
+    // union_off = where this rank's stretch begins in the union text ('$' + the ranks' fragment texts in rank order).
+    uint64_t fragment_packed_words(uint64_t union_off) const;
+    void fragments_export_packed(uint64_t union_off, void* d_words_out, void* d_meta_out);
+    // d_staged_words: the ranks' word stretches one behind the other (n_words[r] words of rank r, which begin at union word first_word[r])
+    void shard_build_union_packed(uint32_t rank, uint32_t n_shards, const void* d_staged_words, const uint64_t* first_word, const uint64_t* n_words,
+                                  uint64_t n_union_text, const void* d_meta, uint64_t n_frags_total);
     void shard_build_union(uint32_t rank, uint32_t n_shards, const uint8_t* d_union_text, uint64_t n_union_text,
                            const void* d_meta, uint64_t n_frags_total);
     uint64_t bitmap_words() const;                                  // u64 words of the union text's novel bitmap
@@ -128,6 +135,8 @@ class GraphBuilder {
     struct Impl;   // all device state of one build (graph_build.hip)
 
   private:
+    void build_union_impl(uint32_t rank, uint32_t n_shards, const uint8_t* d_union_text, const void* d_staged_words, const uint64_t* first_word,
+                          const uint64_t* n_words, uint64_t n_union_text, const void* d_meta, uint64_t n_frags_total);
     void upload_packed(const std::vector<SeqView>& seqs, const std::vector<uint64_t>& off);
     Impl* impl_;
     BuildTimings tm_;

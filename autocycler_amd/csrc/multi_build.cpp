@@ -280,21 +280,48 @@ void rank_main(Shared& S, int rank) {
         nf_total += all3[3 * r]; nb_total += all3[3 * r + 1]; distinct_upper += all3[3 * r + 2];
     }
     b.set_distinct_upper_bound(distinct_upper);
-    uint8_t* d_union = (uint8_t*)xalloc(nb_total + 64);
+    uint64_t frag_text_received = 0;      // bytes of other ranks' fragment text this rank received
     uint8_t* d_meta = (uint8_t*)xalloc(nf_total * 8);
     {
+        // the fragment texts travel as 2-bit codes on the union text's word grid (a quarter of the bytes; AC_MULTI_FRAGMENTS=bytes: as text)
+        const char* fenv = getenv("AC_MULTI_FRAGMENTS");
+        const bool as_bytes = fenv && std::string(fenv) == "bytes";
         const Arena::Mark mk = rc.xarena.mark();
-        uint8_t* my_text = (uint8_t*)xalloc(tb[rank]); uint8_t* my_meta = (uint8_t*)xalloc(mb[rank]);
-        b.fragments_export(my_text, my_meta);
-        const uint8_t dollar = '$';
-        copy_h2d(d_union, &dollar, 1);
-        lapmsg("fragments export");
-        timed([&] { X.all_gather_v(rank, my_text, d_union, tb.data(), td.data()); X.all_gather_v(rank, my_meta, d_meta, mb.data(), md.data()); });
-        lapmsg("fragments all-gather");
+        uint8_t* my_meta = (uint8_t*)xalloc(mb[rank]);
+        if (as_bytes) {
+            uint8_t* d_union = (uint8_t*)xalloc(nb_total + 64);
+            uint8_t* my_text = (uint8_t*)xalloc(tb[rank]);
+            b.fragments_export(my_text, my_meta);
+            const uint8_t dollar = '$';
+            copy_h2d(d_union, &dollar, 1);
+            lapmsg("fragments export");
+            timed([&] { X.all_gather_v(rank, my_text, d_union, tb.data(), td.data()); X.all_gather_v(rank, my_meta, d_meta, mb.data(), md.data()); });
+            lapmsg("fragments all-gather");
+            stream_sync();
+            b.shard_build_union((uint32_t)rank, (uint32_t)R, d_union, nb_total, d_meta, nf_total);
+            frag_text_received = (nb_total - 1 - tb[rank]);
+        } else {
+            std::vector<uint64_t> first_word(R), n_words(R);
+            std::vector<size_t> wb(R), wd(R);
+            size_t staged = 0;
+            for (int r = 0; r < R; r++) {
+                first_word[r] = (uint64_t)td[r] >> 5;
+                n_words[r] = tb[r] ? (((uint64_t)td[r] + tb[r] - 1) >> 5) - first_word[r] + 1 : 0;
+                wb[r] = (size_t)n_words[r] * 8; wd[r] = staged; staged += wb[r];
+            }
+            uint8_t* d_staged = (uint8_t*)xalloc(staged + 8);
+            uint8_t* my_words = (uint8_t*)xalloc(wb[rank] + 8);
+            b.fragments_export_packed(td[rank], my_words, my_meta);
+            lapmsg("fragments export");
+            timed([&] { X.all_gather_v(rank, my_words, d_staged, wb.data(), wd.data()); X.all_gather_v(rank, my_meta, d_meta, mb.data(), md.data()); });
+            lapmsg("fragments all-gather");
+            stream_sync();
+            b.shard_build_union_packed((uint32_t)rank, (uint32_t)R, d_staged, first_word.data(), n_words.data(), nb_total, d_meta, nf_total);
+            frag_text_received = staged - wb[rank];
+        }
         stream_sync();
         rc.xarena.rewind(mk);
     }
-    b.shard_build_union((uint32_t)rank, (uint32_t)R, d_union, nb_total, d_meta, nf_total);
     lapmsg("build_union");
 
     // ---- novel bitmap, degree bytes, link words: the owners' contributions add up
@@ -385,7 +412,7 @@ void rank_main(Shared& S, int rank) {
     {
         std::lock_guard<std::mutex> lock(S.st_mu);
         MultiStats& st = S.st;
-        const uint64_t others_frag = (nb_total - 1 - tb[rank]) + (nf_total * 8 - mb[rank]);
+        const uint64_t others_frag = frag_text_received + (nf_total * 8 - mb[rank]);
         st.bytes_fragments += others_frag;
         st.bytes_bitmap += b.bitmap_words() * 8 * (uint64_t)(R - 1) / (uint64_t)R * 2;      // reduce-scatter + all-gather of an all-reduce: 2 (R - 1) / R of the buffer per rank
         st.bytes_degrees += N * (uint64_t)(R - 1) / (uint64_t)R * 2;

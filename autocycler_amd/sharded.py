@@ -6,7 +6,7 @@ only the plumbing between its phases — all-gathers and SUM / MIN all-reduces o
 the GPU box, "gloo" in the CPU test-suite):
 
     ac_shard_begin          local k-mer insert -> this rank's novel runs ("fragments")
-      all-gather            fragment text + 8-byte records of every rank           (∝ distinct content, not ∝ input)
+      all-gather            fragment text (2-bit codes) + 8-byte records of every rank  (∝ distinct content, not ∝ input; 0.25 B per base)
     ac_shard_build_union    this rank inserts the union-text k-mers it OWNS (owner = hash of the canonical middle mod world):
                             a table of ~1/world of the job's k-mers
       all-reduce SUM        the ranks' novel bitmaps (disjoint)                     (1 bit per union-text position)
@@ -173,16 +173,22 @@ def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False, 
         gathered = comm.all_gather_sizes([nf, nb, lib.ac_shard_local_distinct(h)])
         sizes = [(f, b) for f, b, _ in gathered]
         lib.ac_shard_set_distinct_upper_bound(h, C.c_uint64(sum(d for _, _, d in gathered)))
-        mine = torch.empty(8 * nf + nb, dtype=torch.uint8, device=dev)       # [records | text]
-        _check(lib, lib.ac_shard_fragments_export(h, C.c_void_p(mine.data_ptr() + 8 * nf), C.c_void_p(mine.data_ptr())))
-        parts = comm.all_gather_padded(mine, [8 * f + b for f, b in sizes])
+        # the fragment texts travel as 2-bit codes on the union text's word grid (a quarter of the bytes): [records | code words] per rank
         nf_total = sum(f for f, _ in sizes)
         nb_total = 1 + sum(b for _, b in sizes)
-        dollar = torch.full((1,), ord("$"), dtype=torch.uint8, device=dev)
-        union = torch.cat([dollar] + [p[8 * f:] for p, (f, _) in zip(parts, sizes)])
+        offs = [1 + sum(b for _, b in sizes[:r]) for r in range(comm.world)]       # where each rank's stretch begins in the union text
+        first_word = [o >> 5 for o in offs]
+        n_words = [(((o + b - 1) >> 5) - (o >> 5) + 1) if b else 0 for o, (_, b) in zip(offs, sizes)]
+        assert lib.ac_shard_fragment_packed_words(h, offs[comm.rank]) == n_words[comm.rank]
+        mine = torch.empty(8 * (nf + n_words[comm.rank]), dtype=torch.uint8, device=dev)
+        _check(lib, lib.ac_shard_fragments_export_packed(h, C.c_uint64(offs[comm.rank]), C.c_void_p(mine.data_ptr() + 8 * nf), C.c_void_p(mine.data_ptr())))
+        parts = comm.all_gather_padded(mine, [8 * (f + w) for (f, _), w in zip(sizes, n_words)])
+        staged = torch.cat([p[8 * f:] for p, (f, _) in zip(parts, sizes)] + [torch.zeros(8, dtype=torch.uint8, device=dev)]).contiguous()
         meta = torch.cat([p[:8 * f] for p, (f, _) in zip(parts, sizes)]).contiguous()    # own tensor: 8-byte aligned
-        _check(lib, lib.ac_shard_build_union(h, C.c_uint32(comm.rank), C.c_uint32(comm.world), C.c_void_p(union.data_ptr()),
-                                             C.c_uint64(nb_total), C.c_void_p(meta.data_ptr()), C.c_uint64(nf_total)))
+        _check(lib, lib.ac_shard_build_union_packed(h, C.c_uint32(comm.rank), C.c_uint32(comm.world), C.c_void_p(staged.data_ptr()),
+                                                    (C.c_uint64 * comm.world)(*first_word), (C.c_uint64 * comm.world)(*n_words),
+                                                    C.c_uint64(nb_total), C.c_void_p(meta.data_ptr()), C.c_uint64(nf_total)))
+        del staged
         del parts, mine
         table_capacity = lib.ac_shard_table_capacity(h)
         solo = comm.local_only       # one rank and no forced collectives: nothing to sum

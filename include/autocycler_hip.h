@@ -151,6 +151,14 @@ int ac_shard_begin(uint32_t k, uint32_t local_assembly_count, const void* d_text
                    uint32_t n_seqs, int device, ac_shard** out);
 int ac_shard_fragment_sizes(const ac_shard*, uint64_t* text_bytes, uint64_t* n_fragments);
 int ac_shard_fragments_export(ac_shard*, void* d_text_out /* text_bytes */, void* d_meta_out /* 8 * n_fragments */);
+/* The same fragment text as 2-bit codes laid out on the UNION text's word grid (a quarter of the bytes over the links, and the receivers do
+ * not pack again): union_off = where this rank's stretch begins in the union text (1 + the text bytes of the ranks before it).  Every rank's
+ * words are all-gathered one behind the other; ac_shard_build_union_packed ORs them into place (rank r's n_words[r] words begin at union
+ * word first_word[r] = union_off_r / 32) and derives the mask plane from the fragment records. */
+uint64_t ac_shard_fragment_packed_words(const ac_shard*, uint64_t union_off);
+int ac_shard_fragments_export_packed(ac_shard*, uint64_t union_off, void* d_words_u64, void* d_meta_out /* 8 * n_fragments */);
+int ac_shard_build_union_packed(ac_shard*, uint32_t rank, uint32_t n_shards, const void* d_staged_words_u64, const uint64_t* first_word,
+                                const uint64_t* n_words, uint64_t n_union_text, const void* d_meta, uint64_t n_fragments_total);
 uint64_t ac_shard_local_distinct(const ac_shard*);                 /* distinct canonical k-mers of this rank's slice */
 void ac_shard_set_distinct_upper_bound(ac_shard*, uint64_t n);     /* optional, before ac_shard_build_union: the sum of all ranks'
                                                                       local counts sizes the owned tables without a retry */

@@ -66,6 +66,19 @@ def test_expand_repeats_is_partitioned_by_conflict_component(emu, world, monkeyp
         assert gfa == gfa_rw == gfa_rep and rep["candidates_owned_max"] == rep["candidates_total"] == total
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_fragments_travel_as_two_bit_codes(emu, world, monkeypatch):
+    """the union text stays 2-bit packed — the ranks exchange code words on the union text's word grid (a quarter of
+    the bytes of the text exchange, AC_MULTI_FRAGMENTS=bytes), the receivers derive the mask plane from the fragment records."""
+    seqs, fn, hd = M.synth_case(8, 60_000, 3_000, 1e-3, 1e-4, 7)
+    gfa, info = M.run_case(emu, 51, seqs, fn, hd, [0] * world)
+    monkeypatch.setenv("AC_MULTI_FRAGMENTS", "bytes")
+    gfa_b, info_b = M.run_case(emu, 51, seqs, fn, hd, [0] * world)
+    assert gfa == gfa_b and info["fragments"] == info_b["fragments"] and info["union_text_bytes"] == info_b["union_text_bytes"]
+    records = 8 * info["fragments"] * (world - 1)            # the 8-byte records travel either way
+    assert (info["bytes_fragments"] - records) * 3.5 <= (info_b["bytes_fragments"] - records) + 64 * world * world
+
+
 def test_errors_come_back_from_the_rank_threads(emu):
     import ctypes as C
     from autocycler_amd import AutocyclerError

@@ -383,23 +383,17 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 //                     the build is repeated with exact positions (kernels_tail.inc exp_avoid_start_of_path).  0: every occurrence counts.
 //   AC_PATH_COPY      1: the copying path walk (K10c, walk_copy: followed runs are copied from the stretch they repeat, the text between
 //                     them is walked); AC_RUN_PIECE (4096): positions per copied piece of a run (tests).  Default 0: a small win only.
-//   AC_REMAP_BLOCK    path entries per wavefront in the final renumbering; AC_REMAP_DIRECT=1: its stores go straight to the pinned result block (measured equal).
+//   AC_REMAP_BLOCK    path entries per wavefront in the final renumbering (tests).
 //   AC_INSERT_CHUNK / AC_INSERT_GROWTH / AC_INSERT_WAVES   insert phases: longest wavefront chunk, prefix growth factor, wavefronts per phase;
-//   AC_INSERT_ADAPT (default 1) / AC_INSERT_CHUNK_REST      redundant text: everything after the second phase in one launch, and its longest chunk (16384).
-//   AC_EXPAND_WAVE_LIMIT   junctions per level from which expand_repeats runs a thread per junction (default: never);
-//   AC_EXPAND_GROUP        lanes per junction otherwise: 16 (default), 8, 32 or 64.
+//   AC_INSERT_ADAPT (default 1)   redundant text: everything after the second phase in one launch (chunks of up to 16384 positions).
 //   AC_EXPAND_REWRITE_ALWAYS  rewrite the sequences contiguously after every host check of the expand passes (tests).
 //   AC_SEQ_WRITER     0 / 1 = always the search-per-thread / the indexed LDS-tiled sequence writers (default: by output size).
 //   AC_DEGREE_FLAGS   1 (default): degrees from the sibling bits the insert collects, probes only where they do not settle it (two
-//                     passes); 2: the same inside the one-pass kernel; 0: every degree by probing (what sharded builds and k < 3 do).
+//                     passes); 0: every degree by probing (what sharded builds and k < 3 do).
 //   AC_RENUM_TWO_PASS 1: renumber with two sorts (length | 32 bases | depth) instead of one (length | 16 bases); AC_RENUM_MAX_GROUP (tests).
-//   AC_FILL_NOVEL     0: novel list by a thread per bitmap word instead of the wavefront-cooperative kernel.
-//   AC_SEQ_BYTES      output bytes per thread of the plain sequence writers (16).
-//   AC_PACK_OVERLAP   0: K1 of the device entry in one launch (default: its tail under the first insert phase, cache-sized tables only).
 //   AC_UPLOAD_THREADS (32) / AC_HOST_PACK (1) / AC_UPLOAD_OVERLAP (1)   host entry: packing threads, 2-bit pack on the host, the
 //                     insert issued chunk by chunk while background threads still pack and send the rest (0: everything is sent
-//                     before anything else is issued); AC_UPLOAD_CHUNK_MB (64; 16, 32, 128), AC_UPLOAD_SLOTS (tests: staging slots).
-//   AC_UPLOAD_MASK    1: the packed upload also sends the 1-bit mask plane (0.375 B per base instead of 0.25; default: MaskTableFunctor).
+//                     before anything else is issued); AC_UPLOAD_SLOTS (tests: staging slots).
 //   AC_NO_MAILBOX     (read once) small read-backs through hipMemcpyAsync + synchronise instead of the mapped mailbox page.
 //   AC_INSERT_PROFILE (read once) per-wavefront cycle split of every insert launch on stderr (measurement).
 //   AC_DEBUG_LAUNCH   (read once) every functor launch announced on stderr and waited for (device_rt.hpp); AC_DEBUG_ARENA: arena and copy-walk figures.
@@ -445,22 +439,17 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
     return pc;
 }
 [[maybe_unused]] static u32 remap_block() { const char* e = getenv("AC_REMAP_BLOCK"); int v = e ? atoi(e) : 4096; v = v < 64 ? 64 : (v > 65536 ? 65536 : v); return (u32)(v & ~63); }
-[[maybe_unused]] static bool remap_direct() { const char* e = getenv("AC_REMAP_DIRECT"); return e ? atoi(e) != 0 : false; }      // 1: the renumbering kernel's stores go straight to the pinned result block
-[[maybe_unused]] static bool fill_novel_plain() { const char* e = getenv("AC_FILL_NOVEL"); return e && atoi(e) == 0; }      // 0: a thread per bitmap word
-[[maybe_unused]] static u32 seq_bytes_per_thread() { const char* e = getenv("AC_SEQ_BYTES"); int v = e ? atoi(e) : 16; return (u32)(v < 1 ? 1 : (v > 256 ? 256 : v)); }      // plain sequence writers: output bytes per thread
-[[maybe_unused]] static bool pack_overlap() { const char* e = getenv("AC_PACK_OVERLAP"); return e ? atoi(e) != 0 : true; }      // 0: K1 of the device entry in one launch
 [[maybe_unused]] static int minkey_prefix_bases() { const char* e = getenv("AC_MINKEY_PREFIX_BASES"); int v = e ? atoi(e) : 31; return v < 1 ? 1 : (v > 31 ? 31 : v); }      // tests: a shorter prefix takes the full-key path often
-[[maybe_unused]] static u32 expand_group() { const char* e = getenv("AC_EXPAND_GROUP"); int v = e ? atoi(e) : 16; return (v == 8 || v == 32 || v == 64) ? (u32)v : 16u; }      // lanes per junction in expand_wave_kernel
 [[maybe_unused]] static bool seed_prefix_sort() { const char* e = getenv("AC_SEED_PREFIX_SORT"); return e ? atoi(e) != 0 : true; }      // 0: seed order by the full-key sorts
 [[maybe_unused]] static u32 seed_max_group() { const char* e = getenv("AC_SEED_MAX_GROUP"); int v = e ? atoi(e) : 1024; return (u32)(v < 1 ? 1 : v); }      // tests: smaller groups take the fallback
 [[maybe_unused]] static int seed_prefix_bits() { const char* e = getenv("AC_SEED_PREFIX_BITS"); int v = e ? atoi(e) : 64; return v < 1 ? 1 : (v > 64 ? 64 : v); }      // tests
 [[maybe_unused]] static u32 degree_region_cap() { const char* e = getenv("AC_DEGREE_REGION_CAP"); int v = e ? atoi(e) : 0; return (u32)(v < 0 ? 0 : v); }      // tests: entries per queue region (0 = sized from N)
-[[maybe_unused]] static u64 upload_chunk_bytes() { const char* e = getenv("AC_UPLOAD_CHUNK_MB"); int v = e ? atoi(e) : 64; return (u64)((v == 16 || v == 32 || v == 128) ? v : 64) << 20; }      // text bytes per upload chunk
+[[maybe_unused]] static u64 upload_chunk_bytes() { return (u64)64 << 20; }      // text bytes per upload chunk (16 MB of codes per copy)
 [[maybe_unused]] static int upload_slots() { const char* e = getenv("AC_UPLOAD_SLOTS"); int v = e ? atoi(e) : 1 << 20; return v < 1 ? 1 : v; }      // tests: fewer staging slots, so that chunks wait for one
-[[maybe_unused]] static int degree_flags() { const char* e = getenv("AC_DEGREE_FLAGS"); return e ? atoi(e) : 1; }      // 0: every degree by probing; 2: sibling bits inside the one-pass kernel; 1: two passes
+[[maybe_unused]] static int degree_flags() { const char* e = getenv("AC_DEGREE_FLAGS"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }      // 0: every degree by probing (what sharded builds and k < 3 do)
 [[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); if (!e) return -1; int v = atoi(e); return v < 0 ? 0 : (v > 3 ? 3 : v); }      // -1 = automatic
 [[maybe_unused]] static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
-[[maybe_unused]] static u64 wave_chunk_rest() { const char* e = getenv("AC_INSERT_CHUNK_REST"); u64 x = e ? (u64)atoll(e) : 16384; return (std::max<u64>(x, 256) + 63) & ~63ULL; }   // longest chunk of the one-launch rest (r04c: 4096 / 8192 / 16384 = 0.90 / 0.84 / 0.82 ms)
+[[maybe_unused]] static u64 wave_chunk_rest() { return 16384; }   // longest chunk of the one-launch rest (r04c: 4096 / 8192 / 16384 = 0.90 / 0.84 / 0.82 ms)
 static thread_local int tl_upload_threads_cap = 0;      // a rank of a multi-device build: its share of the host's cores (0 = no cap)
 [[maybe_unused]] static u64 upload_threads() {
     const char* e = getenv("AC_UPLOAD_THREADS");
@@ -471,7 +460,6 @@ static thread_local int tl_upload_threads_cap = 0;      // a rank of a multi-dev
 [[maybe_unused]] static bool host_pack() { const char* e = getenv("AC_HOST_PACK"); return e ? atoi(e) != 0 : true; }      // 0: upload the text as bytes and pack on the device
 [[maybe_unused]] static bool insert_profile() { static const bool v = getenv("AC_INSERT_PROFILE") != nullptr; return v; }      // measurement only
 [[maybe_unused]] static bool expand_rewrite_always() { return getenv("AC_EXPAND_REWRITE_ALWAYS") != nullptr; }      // tests: compact the expand pool after every host check
-[[maybe_unused]] static u64 expand_wave_limit() { const char* e = getenv("AC_EXPAND_WAVE_LIMIT"); return e ? (u64)atoll(e) : ~0ULL; }      // junctions per level from which expand_repeats runs a thread (not a wavefront) per junction
 #ifdef AC_EMU
 [[maybe_unused]] static bool seq_writer_plain() { return true; }
 #else
@@ -479,12 +467,9 @@ static thread_local int tl_upload_threads_cap = 0;      // a rank of a multi-dev
 #endif
 [[maybe_unused]] static bool seq_writer_forced() { const char* e = getenv("AC_SEQ_WRITER"); return e && atoi(e) == 1; }    // 1 = always the indexed / LDS-tiled writers
 [[maybe_unused]] static u64 seed_radix_limit() { const char* e = getenv("AC_SEED_RADIX_LIMIT"); return e ? (u64)atoll(e) : (1u << 19); }      // unitigs from which the seed order is a radix sort
-[[maybe_unused]] static bool upload_mask() { const char* e = getenv("AC_UPLOAD_MASK"); return e && atoi(e) != 0; }      // 1: the host entry sends the mask plane too (default: the device derives it from the sequence table)
 [[maybe_unused]] static bool upload_overlap() { const char* e = getenv("AC_UPLOAD_OVERLAP"); return e ? atoi(e) != 0 : true; }      // host entry: first insert phases while the upload's tail is in flight
 [[maybe_unused]] static bool insert_adaptive() { const char* e = getenv("AC_INSERT_ADAPT"); return e ? atoi(e) != 0 : true; }
 [[maybe_unused]] static u64 insert_growth() { const char* e = getenv("AC_INSERT_GROWTH"); long x = e ? atol(e) : 2; return (u64)(x < 2 ? 2 : x); }      // phase i+1 ends at growth x the end of phase i
-[[maybe_unused]] static u64 insert_growth_diverse() { const char* e = getenv("AC_INSERT_GROWTH_DIVERSE"); long x = e ? atol(e) : 4; return (u64)(x < 2 ? 2 : x); }
-[[maybe_unused]] static u64 insert_waves_diverse() { const char* e = getenv("AC_INSERT_WAVES_DIVERSE"); long x = e ? atol(e) : 65536; return (u64)(x < 1024 ? 1024 : x); }
 [[maybe_unused]] static u64 insert_waves_target() { const char* e = getenv("AC_INSERT_WAVES"); long x = e ? atol(e) : 16384; return (u64)(x < 1024 ? 1024 : x); }   // wavefronts a long phase is cut into
 
 // A text resident in HBM with its sequence table and its 2-bit packing.
@@ -637,7 +622,7 @@ struct GraphBuilder::Impl {
         // only next to a first phase that claims into a cache-sized table (config C: 5.15 -> 5.08 ms): where the table is far larger
         // (config D: 4 GB) that phase is bound by HBM lines itself and the pack beside it costs more than it hides (28.96 -> 29.13)
         const u64 cap_est = next_pow2(std::max<u64>(1024, pt.n_bases / std::max<u32>(hint, 1) * 3 + 4096));
-        if (pack_overlap() && cap_est <= (1ULL << 25) && H + (1u << 22) < pt.n_text) {
+        if (cap_est <= (1ULL << 25) && H + (1u << 22) < pt.n_text) {
             pt.pack_alloc();
             launch(H / 32, PackFunctor{pt.d_text, pt.n_text, pt.bits.ptr(), (u32*)pt.mask.ptr(), 0, pt.chk()});
             SideStream& side = SideStream::get();
@@ -737,7 +722,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
             // (a text that keeps bringing new k-mers — the adaptive test below said no — has little to follow: its later phases are wider,
             // x4 per phase, and cut into more wavefronts: E' 19.50 -> 19.21 ms, mini-E 77.7 -> 76.6, r08k)
             const bool diverse = launches >= 2 && !rest_at_once && insert_adaptive();
-            u64 pe = (pb == 0) ? first : pb * (diverse ? std::max<u64>(insert_growth(), insert_growth_diverse()) : insert_growth());
+            u64 pe = (pb == 0) ? first : pb * (diverse ? std::max<u64>(insert_growth(), 4) : insert_growth());      // (a diverse text: wider phases, r08k)
             if (rest_at_once || pe > p_end_all || p_end_all - pe < (1u << 16)) pe = p_end_all;
 #ifndef AC_EMU
             if (upload_pending && &pt == &loc && pe + (u64)k + 8192 > upload_avail) {      // this phase reads beyond the first uploaded chunk
@@ -754,7 +739,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
 #endif
             const u64 len = pe - pb;
             {      // one wavefront per chunk: >= ~16 K wavefronts when the phase is long
-                u64 c = (len / (diverse ? std::max<u64>(insert_waves_target(), insert_waves_diverse()) : insert_waves_target()) + 63) & ~63ULL;
+                u64 c = (len / (diverse ? std::max<u64>(insert_waves_target(), 65536) : insert_waves_target()) + 63) & ~63ULL;      // (... cut into more wavefronts)
                 u32 chunk = (u32)std::min<u64>(std::max<u64>(c, 256), rest_at_once ? wave_chunk_rest() : wave_chunk_max());
                 u64 n_waves = (len + chunk - 1) / chunk;
                 if (want_runs && rest_at_once) {
@@ -951,8 +936,7 @@ inline void GraphBuilder::Impl::novel_list(u64 known_n) {
 #ifdef AC_EMU
     launch(n_bm_words, FillNovelFunctor{bm.ptr(), wprefix.ptr(), npos.ptr()});
 #else
-    if (fill_novel_plain()) launch(n_bm_words, FillNovelFunctor{bm.ptr(), wprefix.ptr(), npos.ptr()});
-    else {
+    {
         const u64 blocks = (n_bm_words + 255) / 256;
         if (blocks > 0xFFFFFFULL) throw DeviceError("grid too large");
         flush_fills();
@@ -1304,7 +1288,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         // the indexed / LDS-tiled writer pays for its index (four small launches) from ~16 MB of output on: config C (7.8 MB) 6.02 vs
         // 5.97 ms per build with it, E' (45 MB) 24.9 vs 26.6, config D (126 MB): see DESIGN.md §6
         if (seq_writer_plain() || (n_bytes < ((u64)16 << 20) && !seq_writer_forced())) {
-            const u32 per = seq_bytes_per_thread();
+            const u32 per = 16;      // output bytes per thread (r06n: 64 left most of the chip idle on 7.8 MB)
             if (mode == 0) launch((n_bytes + per - 1) / per, SeqFunctor{g.bits.ptr(), off, ustartpos.ptr(), ulen.ptr(), uorient.ptr(), U, n_bytes, (int)(k / 2), dst, per});
             else launch((n_bytes + per - 1) / per, MaterializeFunctor{*es, off, U, n_bytes, dst, per});
             return;
@@ -1438,22 +1422,13 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
 #ifdef AC_EMU
                         launch_full(cnt, ExpandFunctor{e, clist.ptr(), (u64)hb[lv], (u32)pool.size(), counters.ptr() + 7});
 #else
-                        // sixteen lanes per junction (expand_wave_kernel; AC_EXPAND_GROUP).  The thread-per-junction form
-                        // (ExpandFunctor: the emulation's, and the definition the kernel is read against) used to take over on
-                        // levels of >= 65536 junctions, where a whole wavefront per junction wasted lanes; with four junctions per
-                        // wavefront it no longer wins anywhere (E' expand 4.41 -> 4.19 ms, config D 2.50 -> 2.15): AC_EXPAND_WAVE_LIMIT
-                        if (cnt >= expand_wave_limit()) {
-                            launch_full(cnt, ExpandFunctor{e, clist.ptr(), (u64)hb[lv], (u32)pool.size(), counters.ptr() + 7});
-                            continue;
-                        }
-                        const u32 G = expand_group();
-                        const u64 blocks = (cnt * G + 255) / 256;
+                        // sixteen lanes per junction, four junctions per wavefront (expand_wave_kernel).  The thread-per-junction form
+                        // (ExpandFunctor: the emulation's, and the definition the kernel is read against) and 8 / 32 / 64 lanes were measured and
+                        // retired (r06u/v: G = 16 wins from config C to mixed-species graphs)
+                        const u64 blocks = (cnt * 16 + 255) / 256;
                         if (blocks > 0xFFFFFFULL) throw DeviceError("grid too large");
                         flush_fills();
-                        if (G == 8) hipLaunchKernelGGL((expand_wave_kernel<W, 8>), dim3((unsigned)blocks), dim3(256), 0, 0, e, clist.ptr(), (u64)hb[lv], cnt, (u32)pool.size(), counters.ptr() + 7);
-                        else if (G == 16) hipLaunchKernelGGL((expand_wave_kernel<W, 16>), dim3((unsigned)blocks), dim3(256), 0, 0, e, clist.ptr(), (u64)hb[lv], cnt, (u32)pool.size(), counters.ptr() + 7);
-                        else if (G == 32) hipLaunchKernelGGL((expand_wave_kernel<W, 32>), dim3((unsigned)blocks), dim3(256), 0, 0, e, clist.ptr(), (u64)hb[lv], cnt, (u32)pool.size(), counters.ptr() + 7);
-                        else hipLaunchKernelGGL((expand_wave_kernel<W, 64>), dim3((unsigned)blocks), dim3(256), 0, 0, e, clist.ptr(), (u64)hb[lv], cnt, (u32)pool.size(), counters.ptr() + 7);
+                        hipLaunchKernelGGL((expand_wave_kernel<W, 16>), dim3((unsigned)blocks), dim3(256), 0, 0, e, clist.ptr(), (u64)hb[lv], cnt, (u32)pool.size(), counters.ptr() + 7);
                         AC_HIP_CHECK(hipGetLastError());
 #endif
                     }
@@ -1558,17 +1533,13 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     {
         const u64 RB = remap_block();
         const u64 n_waves = (n_ent + RB - 1) / RB;
-        // Four chunks, each copied while the next is renumbered.  AC_REMAP_DIRECT=1: the final numbers go straight into the caller's pinned
-        // block instead (the kernel's stores ARE the transfer, no copy engine involved) — measured equal (r08j: config C 4.905 vs 4.93 ms,
-        // E' 19.53 vs 19.49): either way the 4 bytes per entry cross PCIe after the final numbering exists, and that transfer is the floor
-        // (42 MB = 0.7 ms on config C).  Not the default: a recycled pinned block may have been allocated under another device's context.
-        const bool direct = want_paths && remap_direct();
-        const u64 per_chunk = direct ? n_waves : std::max<u64>((n_waves + 3) / 4, 64);
+        // Four chunks, each copied while the next is renumbered (the kernel storing straight into the pinned block measured equal, r08j:
+        // either way the 4 bytes per entry cross PCIe after the final numbering exists — 42 MB = 0.7 ms on config C)
+        const u64 per_chunk = std::max<u64>((n_waves + 3) / 4, 64);
         for (u64 w = 0; w < n_waves; w += per_chunk) {
             u64 cnt = std::min<u64>(per_chunk, n_waves - w);
-            launch_full(cnt * 64, RemapFunctor{ent_val.ptr(), number_len.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr(), w, (u32)RB,
-                                               direct ? (int32_t*)out->path_block.p : nullptr});
-            if (want_paths && !direct) {
+            launch_full(cnt * 64, RemapFunctor{ent_val.ptr(), number_len.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr(), w, (u32)RB, nullptr});
+            if (want_paths) {
                 u64 b = w * RB, e2 = std::min<u64>((w + cnt) * RB, n_ent);
                 side.after_main();
                 copy_d2h_async((int32_t*)out->path_block.p + b, ent_val.ptr() + b, (e2 - b) * 4, side.stream());
@@ -2011,7 +1982,7 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
     }
     const u64 expected = loc.expected_nonbase + ((n + 31) / 32 * 32 - n);
     if (nonbase != expected) throw_bad_alphabet(seqs, k, expected, nonbase, loc.index_base);
-    if (!upload_mask()) {      // what the device does instead of receiving the mask plane (MaskTableFunctor) must give the packed one
+    {      // what the device does instead of receiving the mask plane (MaskTableFunctor) must give the packed one
         DBuf<u64> derived(loc.mask.size());
         derived.fill_bytes(0xFF);
         memset(derived.ptr(), 0, (size_t)((n + 63) / 64) * 8);
@@ -2031,7 +2002,7 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
     AC_HIP_CHECK(hipEventRecord(st.begin(), 0));
     AC_HIP_CHECK(hipStreamWaitEvent(job->pk, st.begin(), 0));
     loc.pack_alloc(job->pk);                               // zero codes / all-ones mask beyond the text (and under it, until the copies land)
-    job->send_mask = upload_mask();
+    job->send_mask = false;
     if (!job->send_mask) {      // the mask plane from the sequence table, on the device (MaskTableFunctor): 0.25 instead of 0.375 bytes per base cross PCIe
         AC_HIP_CHECK(hipMemsetAsync(loc.mask.ptr(), 0, (size_t)((n + 63) / 64) * 8, job->pk));
         launch((u64)loc.n_seqs + 1, MaskTableFunctor{loc.seq_off.ptr(), loc.seq_len.ptr(), loc.seq_d1.ptr(), loc.seq_d2.ptr(), loc.n_seqs, (int)k, n, loc.mask.ptr()}, job->pk);
@@ -2402,10 +2373,11 @@ void GraphBuilder::build_union_impl(uint32_t rank, uint32_t n_shards, const uint
     if (d_union_text) m.uni.pack();
     else {      // the ranks' code words are here already: OR them into place; the mask plane follows from the fragment records
         PackedText& u = m.uni;
-        u.pack_alloc();
+        u.pack_alloc();                                                // (clears / sets the slack behind the text)
+        flush_fills();                                                 // (the fills of one batch run side by side: the mask's body below overlaps the slack fill's first bytes)
         const u64 groups = (n_union_text + 31) / 32;
-        u.bits.fill_bytes(0);                                          // (pack_alloc only cleared the slack behind the text)
-        u.mask.fill_bytes_first(((n_union_text + 63) / 64) * 8, 0);   // (... and set the mask's slack: MaskTableFunctor sets the bits of the text's own words)
+        u.bits.fill_bytes(0);
+        u.mask.fill_bytes_first(((n_union_text + 63) / 64) * 8, 0);   // (MaskTableFunctor then sets the bits of the text's own words)
         u64 staged_at = 0;
         for (uint32_t r = 0; r < n_shards; r++) {
             if (n_words[r]) {

@@ -234,7 +234,7 @@ def test_config_c_digest_with_the_plain_path_walk():
     assert rows[0]["path_runs_copied"] == 0 and rows[1]["path_runs_copied"] > 0
 
 
-@pytest.mark.parametrize("variants", ["base", "AC_PATH_COPY=0", "AC_UPLOAD_MASK=1", "AC_UPLOAD_OVERLAP=0", "AC_HOST_PACK=0", "AC_UPLOAD_THREADS=5", "AC_UPLOAD_SLOTS=2", "AC_UPLOAD_CHUNK_MB=16,AC_UPLOAD_SLOTS=3", "AC_UPLOAD_SLOTS=1,AC_UPLOAD_OVERLAP=0"])
+@pytest.mark.parametrize("variants", ["base", "AC_PATH_COPY=0", "AC_UPLOAD_OVERLAP=0", "AC_HOST_PACK=0", "AC_UPLOAD_THREADS=5", "AC_UPLOAD_SLOTS=2", "AC_UPLOAD_CHUNK_MB=16,AC_UPLOAD_SLOTS=3", "AC_UPLOAD_SLOTS=1,AC_UPLOAD_OVERLAP=0"])
 def test_host_entry_full_size_digest(variants):
     """The HOST entry (ac_compress_build from pageable per-sequence buffers: host-side 2-bit pack, chunked upload through the pinned
     ring by background threads, the insert issued chunk by chunk as they land) on the whole config C — 487 MB of text, eight 64 MB

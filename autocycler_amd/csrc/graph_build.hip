@@ -1639,6 +1639,12 @@ void device_warmup(int device, uint32_t k, uint64_t text_bytes_estimate) {
     void* p = nullptr;
     AC_HIP_CHECK(hipMalloc(&p, 4096));
     lap("context + first hipMalloc");
+    // the pinned upload ring (192 MB of hipHostMalloc: ~47 ms) on a thread of its own, beside the code objects (~55 ms): round 4, a fresh
+    // `autocycler-compress` process waited for the two one after the other (profiles/r10e_cli_fresh_process_configC.txt)
+    std::thread ring;
+    std::string ring_fail;
+    if (text_bytes_estimate) ring = std::thread([&] { try { AC_HIP_CHECK(hipSetDevice(device)); ensure_host_stager(); } catch (const std::exception& e) { ring_fail = e.what(); } });
+    struct RingJoin { std::thread& t; ~RingJoin() { if (t.joinable()) t.join(); } } ring_join{ring};
     hipLaunchKernelGGL(functor_kernel<PackFunctor>, dim3(1), dim3(256), 0, 0, (u64)1, PackFunctor{(const u8*)p, 32, (u64*)((u8*)p + 1024), (u32*)((u8*)p + 2048), 0, PackCheck{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr}});
     (void)hipDeviceSynchronize();
     lap("main code object");
@@ -1655,8 +1661,9 @@ void device_warmup(int device, uint32_t k, uint64_t text_bytes_estimate) {
     if (text_bytes_estimate) {
         Arena::device().reserve(arena_estimate(text_bytes_estimate, true));
         lap("device arena");
-        ensure_host_stager();
-        lap("pinned upload ring");
+        ring.join();
+        lap("pinned upload ring (rest)");
+        if (!ring_fail.empty()) throw DeviceError(ring_fail);
     }
     (void)hipDeviceSynchronize();
     (void)hipFree(p);

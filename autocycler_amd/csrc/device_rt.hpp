@@ -17,6 +17,7 @@
 
 #include "kmer_ops.hpp"
 #include "graph_types.hpp"
+#include "wave_rt.hpp"
 
 #ifndef AC_EMU
 #include <hip/hip_runtime.h>
@@ -734,9 +735,13 @@ __global__ void __launch_bounds__(256) functor_kernel_full(u64 n, F f, u64 base 
 template <class F> void launch_full(u64 n, const F& f, stream_t s = 0) {
     if (n == 0) return;
 #ifdef AC_EMU
-    int order = emu_order();
-    if (order == 1) { for (u64 i = n; i-- > 0;) f(i, true); }
-    else { for (u64 i = 0; i < n; i++) f(i, true); }
+    // whole wavefronts in lockstep (wave_rt.hpp): the functor's ballots and shuffles are the ones the device executes
+    (void)s;
+    const u64 blocks = (n + 255) / 256;
+    const F* fp = &f;
+    for (u64 b0 = 0; b0 < blocks; b0 += 0xFFFFFFu)
+        wv::launch_kernel(+[](const F* g, u64 nn, u64 base) { const u64 tid = base + (u64)wv::bid() * 256 + wv::tid(); (*g)(tid, tid < nn); },
+                          (unsigned)std::min<u64>(0xFFFFFFu, blocks - b0), 256u, fp, n, b0 * 256);
 #else
     const u64 blocks = (n + 255) / 256;
     if (s == 0) flush_fills();
@@ -748,33 +753,39 @@ template <class F> void launch_full(u64 n, const F& f, stream_t s = 0) {
     if (debug_launch()) debug_launch_note<F>(n, true);
 #endif
 }
+// A kernel of 256-thread workgroups that uses the wavefront primitives of wave_rt.hpp: hipLaunchKernelGGL on the device, the lockstep
+// emulation under AC_EMU — the same kernel source either way.
+template <class K, class... A> void launch_wave_kernel(K kernel, u64 blocks, stream_t s, A... args) {
+    if (blocks == 0) return;
+    if (blocks > 0xFFFFFFULL) throw DeviceError("grid too large");
+#ifdef AC_EMU
+    (void)s;
+    wv::launch_kernel(kernel, (unsigned)blocks, 256u, args...);
+#else
+    if (s == 0) flush_fills();
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), 0, s, args...);
+    AC_HIP_CHECK(hipGetLastError());
+#endif
+}
 // Bump allocation from a device counter with ONE atomic per wavefront (a counter hit by every lane serialises in L2).
 // All 64 lanes must call it (amount may be 0).  Returns this lane's offset.
 AC_D u32 wave_alloc32(u32* counter, u32 amount) {
-#ifdef AC_EMU
-    u32 o = *counter; *counter += amount; return o;
-#else
-    const int lane = (int)(threadIdx.x & 63);
+    const int lane = wv::lane();
     u32 incl = amount;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { u32 t = (u32)__shfl_up((int)incl, o); if (lane >= o) incl += t; }
-    u32 total = (u32)__shfl((int)incl, 63);
+    for (int o = 1; o < 64; o <<= 1) { u32 t = (u32)wv::shfl_up((int)incl, o); if (lane >= o) incl += t; }
+    u32 total = (u32)wv::shfl((int)incl, 63);
     u32 base = 0;
-    if (lane == 0 && total) base = atomicAdd(counter, total);
-    base = (u32)__shfl((int)base, 0);
+    if (lane == 0 && total) base = atomic_add32(counter, total);
+    base = (u32)wv::shfl((int)base, 0);
     return base + incl - amount;
-#endif
 }
 // Adds the wavefront's total of `v` to a device counter with one atomic.  All 64 lanes must call it.
 AC_D void wave_add64(u64* counter, u32 v) {
-#ifdef AC_EMU
-    *counter += v;
-#else
     u32 t = v;
 #pragma unroll
-    for (int o = 32; o; o >>= 1) t += (u32)__shfl_xor((int)t, o);
-    if ((threadIdx.x & 63) == 0 && t) atomic_add64(counter, (u64)t);
-#endif
+    for (int o = 32; o; o >>= 1) t += (u32)wv::shfl_xor((int)t, o);
+    if (wv::lane() == 0 && t) atomic_add64(counter, (u64)t);
 }
 
 // ---- device primitives ----------------------------------------------------------------------------

@@ -12,6 +12,9 @@
 //   * every unitig lies contiguously inside the run of novel positions of the first sequence that
 //     contains it, so unitigs = segments of the sorted novel-position list cut at non-internal steps;
 //   * unitig forward strand = strand holding its smallest k-mer; seed number = rank of that k-mer.
+#ifdef AC_EMU
+#define AC_EMU_DEFINE_CTX_SWITCH      // (the lockstep emulation's context switch is defined by this translation unit: wave_rt.hpp)
+#endif
 #include "graph_build.hpp"
 
 #include <chrono>
@@ -460,11 +463,7 @@ static thread_local int tl_upload_threads_cap = 0;      // a rank of a multi-dev
 [[maybe_unused]] static bool host_pack() { const char* e = getenv("AC_HOST_PACK"); return e ? atoi(e) != 0 : true; }      // 0: upload the text as bytes and pack on the device
 [[maybe_unused]] static bool insert_profile() { static const bool v = getenv("AC_INSERT_PROFILE") != nullptr; return v; }      // measurement only
 [[maybe_unused]] static bool expand_rewrite_always() { return getenv("AC_EXPAND_REWRITE_ALWAYS") != nullptr; }      // tests: compact the expand pool after every host check
-#ifdef AC_EMU
-[[maybe_unused]] static bool seq_writer_plain() { return true; }
-#else
 [[maybe_unused]] static bool seq_writer_plain() { const char* e = getenv("AC_SEQ_WRITER"); return e && atoi(e) == 0; }      // 0 = always the search-per-thread writers
-#endif
 [[maybe_unused]] static bool seq_writer_forced() { const char* e = getenv("AC_SEQ_WRITER"); return e && atoi(e) == 1; }    // 1 = always the indexed / LDS-tiled writers
 [[maybe_unused]] static u64 seed_radix_limit() { const char* e = getenv("AC_SEED_RADIX_LIMIT"); return e ? (u64)atoll(e) : (1u << 19); }      // unitigs from which the seed order is a radix sort
 [[maybe_unused]] static bool upload_overlap() { const char* e = getenv("AC_UPLOAD_OVERLAP"); return e ? atoi(e) != 0 : true; }      // host entry: first insert phases while the upload's tail is in flight
@@ -756,18 +755,12 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
                     if (run_rows + n_waves <= run_rows_cap) { tb.runs = runs.ptr(); tb.run_count = run_count.ptr(); tb.run_row0 = run_rows; run_rows += n_waves; }
                     else tb.runs = nullptr;
                 }
-#ifdef AC_EMU
-                launch(n_waves, InsertWaveEmuFunctor<W>{t, tb, pb, pe, chunk, istats.ptr(), ierr});
-#else
-                u64 blocks = (n_waves + 3) / 4;
-                if (blocks > 0xFFFFFFULL) throw DeviceError("grid too large");
-                flush_fills();
+                const u64 blocks = (n_waves + 3) / 4;
+#ifndef AC_EMU
                 if (insert_profile()) {      // measurement only: per-wavefront cycle split of this launch on stderr
                     DBuf<u64> prof(16);
                     prof.fill_bytes(0);
-                    flush_fills();
-                    hipLaunchKernelGGL((insert_wave_kernel<W, true>), dim3((unsigned)blocks), dim3(256), 0, 0, t, tb, pb, pe, chunk, istats.ptr(), ierr, prof.ptr());
-                    AC_HIP_CHECK(hipGetLastError());
+                    launch_wave_kernel(insert_wave_kernel<W, true>, blocks, 0, t, tb, pb, pe, chunk, istats.ptr(), ierr, prof.ptr());
                     std::vector<u64> h = to_host(prof, 16);
                     fprintf(stderr, "insert launch %u: positions %llu chunk %u waves %llu | opener %llu steps avg %.0f cy | wide %llu steps avg %.0f cy | follow %llu runs avg %.0f cy | "
                             "wave avg %.0f cy, longest %llu cy\n", launches, (unsigned long long)len, chunk, (unsigned long long)h[7],
@@ -777,11 +770,13 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
                     hipEvent_t ea, eb;
                     AC_HIP_CHECK(hipEventCreate(&ea)); AC_HIP_CHECK(hipEventCreate(&eb));
                     evs.push_back(ea); evs.push_back(eb);
+                    flush_fills();
                     AC_HIP_CHECK(hipEventRecord(ea, 0));
-                    hipLaunchKernelGGL((insert_wave_kernel<W, false>), dim3((unsigned)blocks), dim3(256), 0, 0, t, tb, pb, pe, chunk, istats.ptr(), ierr, (u64*)nullptr);
-                    AC_HIP_CHECK(hipGetLastError());
+                    launch_wave_kernel(insert_wave_kernel<W, false>, blocks, 0, t, tb, pb, pe, chunk, istats.ptr(), ierr, (u64*)nullptr);
                     AC_HIP_CHECK(hipEventRecord(eb, 0));
                 }
+#else
+                launch_wave_kernel(insert_wave_kernel<W, false>, blocks, 0, t, tb, pb, pe, chunk, istats.ptr(), ierr, (u64*)nullptr);      // the same kernel, lanes in lockstep (wave_rt.hpp)
 #endif
             }
             launches++;
@@ -933,17 +928,7 @@ inline void GraphBuilder::Impl::novel_list(u64 known_n) {
         tm->n_distinct = N;
     }
     npos.alloc(N);
-#ifdef AC_EMU
-    launch(n_bm_words, FillNovelFunctor{bm.ptr(), wprefix.ptr(), npos.ptr()});
-#else
-    {
-        const u64 blocks = (n_bm_words + 255) / 256;
-        if (blocks > 0xFFFFFFULL) throw DeviceError("grid too large");
-        flush_fills();
-        hipLaunchKernelGGL(fill_novel_wave_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, 0, bm.ptr(), wprefix.ptr(), npos.ptr(), n_bm_words);
-        AC_HIP_CHECK(hipGetLastError());
-    }
-#endif
+    launch_wave_kernel(fill_novel_wave_kernel<0>, (n_bm_words + 255) / 256, 0, (const u64*)bm.ptr(), (const u32*)wprefix.ptr(), npos.ptr(), n_bm_words);
     kinfo.alloc(N, true);
     lap(&tm->collect_sort);
 }
@@ -1022,30 +1007,14 @@ template <int W> void GraphBuilder::Impl::unitigs() {
         const u64 n_waves = (N + 63) / 64;
         DBuf<MinPre> upre(U), wfirst(n_waves), wlast(n_waves);
         MinPreArgs a{t, npos.ptr(), scan.ptr(), N, upre.ptr(), wfirst.ptr(), wlast.ptr(), minkey_prefix_bases()};
-#ifdef AC_EMU
-        launch(n_waves, MinPreWaveEmuFunctor<W>{a});
-#else
-        const u64 blocks = (N + 255) / 256;
-        if (blocks > 0xFFFFFFULL) throw DeviceError("grid too large");
-        flush_fills();
-        hipLaunchKernelGGL(minpre_wave_kernel<W>, dim3((unsigned)blocks), dim3(256), 0, 0, a);
-        AC_HIP_CHECK(hipGetLastError());
-#endif
+        launch_wave_kernel(minpre_wave_kernel<W>, (N + 255) / 256, 0, a);
         launch(U, MinFinishFunctor<W>{t, npos.ptr(), ustart.ptr(), U, N, upre.ptr(), wfirst.ptr(), wlast.ptr(), umin.ptr()});
     } else if constexpr (W <= 4) {
         if (mk == 1) {      // wavefront form: keys stay in registers
             const u64 n_waves = (N + 63) / 64;
             DBuf<MinVal<W>> wfirst(n_waves), wlast(n_waves);
             MinWaveArgs<W> a{t, npos.ptr(), scan.ptr(), N, umin.ptr(), wfirst.ptr(), wlast.ptr()};
-#ifdef AC_EMU
-            launch(n_waves, MinWaveEmuFunctor<W>{a});
-#else
-            const u64 blocks = (N + 255) / 256;
-            if (blocks > 0xFFFFFFULL) throw DeviceError("grid too large");
-            flush_fills();
-            hipLaunchKernelGGL(minkey_wave_kernel<W>, dim3((unsigned)blocks), dim3(256), 0, 0, a);
-            AC_HIP_CHECK(hipGetLastError());
-#endif
+            launch_wave_kernel(minkey_wave_kernel<W>, (N + 255) / 256, 0, a);
             launch(U, MinJoinFunctor<W>{ustart.ptr(), U, N, wfirst.ptr(), wlast.ptr(), umin.ptr()});
         } else {
             DBuf<MinVal<W>> vals(N); DBuf<u32> seg(N);
@@ -1293,22 +1262,16 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             else launch((n_bytes + per - 1) / per, MaterializeFunctor{*es, off, U, n_bytes, dst, per});
             return;
         }
-#ifndef AC_EMU
         const u64 n_blocks = (n_bytes + 63) / 64;
         if (n_blocks == 0) return;
         DBuf<u32> bmax(n_blocks), first(n_blocks);
         bmax.fill_bytes(0);
         launch(U, BlockMaxFunctor{off, U, n_blocks, bmax.ptr()});
         inclusive_max_scan_u32(bmax.ptr(), first.ptr(), n_blocks);
-        const u64 grid = (n_blocks + 255) / 256;
-        if (grid > 0xFFFFFFULL) throw DeviceError("grid too large");
         SeqSrc q{g.bits.ptr(), ustartpos.ptr(), ulen.ptr(), uorient.ptr(), (int)(k / 2)};
         ExpState e0{};
-        flush_fills();
-        if (mode == 0) hipLaunchKernelGGL(seq_write_kernel<0>, dim3((unsigned)grid), dim3(256), 0, 0, q, e0, off, first.ptr(), U, n_bytes, dst);
-        else hipLaunchKernelGGL(seq_write_kernel<1>, dim3((unsigned)grid), dim3(256), 0, 0, q, *es, off, first.ptr(), U, n_bytes, dst);
-        AC_HIP_CHECK(hipGetLastError());
-#endif
+        if (mode == 0) launch_wave_kernel(seq_write_kernel<0>, (n_blocks + 255) / 256, 0, q, e0, off, (const u32*)first.ptr(), U, n_bytes, dst);
+        else launch_wave_kernel(seq_write_kernel<1>, (n_blocks + 255) / 256, 0, q, *es, off, (const u32*)first.ptr(), U, n_bytes, dst);
     };
     write_seqs(0, nullptr, useq_off.ptr(), total, useq.ptr());
     lap(&tm->seqs);
@@ -1419,18 +1382,10 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                     for (u32 lv = 1; lv <= n_levels; lv++) {
                         const u64 cnt = (u64)(hb[lv + 1] - hb[lv]);
                         if (cnt == 0) continue;
-#ifdef AC_EMU
-                        launch_full(cnt, ExpandFunctor{e, clist.ptr(), (u64)hb[lv], (u32)pool.size(), counters.ptr() + 7});
-#else
-                        // sixteen lanes per junction, four junctions per wavefront (expand_wave_kernel).  The thread-per-junction form
-                        // (ExpandFunctor: the emulation's, and the definition the kernel is read against) and 8 / 32 / 64 lanes were measured and
-                        // retired (r06u/v: G = 16 wins from config C to mixed-species graphs)
-                        const u64 blocks = (cnt * 16 + 255) / 256;
-                        if (blocks > 0xFFFFFFULL) throw DeviceError("grid too large");
-                        flush_fills();
-                        hipLaunchKernelGGL((expand_wave_kernel<W, 16>), dim3((unsigned)blocks), dim3(256), 0, 0, e, clist.ptr(), (u64)hb[lv], cnt, (u32)pool.size(), counters.ptr() + 7);
-                        AC_HIP_CHECK(hipGetLastError());
-#endif
+                        // sixteen lanes per junction, four junctions per wavefront (expand_wave_kernel; the emulation runs the same kernel in
+                        // lockstep, wave_rt.hpp).  A thread per junction and 8 / 32 / 64 lanes were measured and retired (r06u/v: G = 16
+                        // wins from config C to mixed-species graphs)
+                        launch_wave_kernel(expand_wave_kernel<W, 16>, (cnt * 16 + 255) / 256, 0, e, (const u32*)clist.ptr(), (u64)hb[lv], cnt, (u32)pool.size(), counters.ptr() + 7);
                     }
                 }
                 u64 sh[2]; u32 used = 0;

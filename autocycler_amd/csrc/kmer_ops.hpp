@@ -206,6 +206,13 @@ AC_HD int clz64(u64 x) {
     return x ? __clzll((long long)x) : 64;
 #endif
 }
+AC_HD int ctz64(u64 x) {
+#ifdef AC_EMU
+    return x ? __builtin_ctzll(x) : 64;
+#else
+    return x ? (__ffsll((long long)x) - 1) : 64;
+#endif
+}
 AC_HD int ctz32(u32 x) {
 #ifdef AC_EMU
     return x ? __builtin_ctz(x) : 32;

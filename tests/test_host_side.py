@@ -35,6 +35,16 @@ def test_source_hash_matches_the_tree():
     assert re.fullmatch(r"[0-9a-f]{16}", _capi.load_library().ac_source_hash().decode())
 
 
+def test_lockstep_emulation_of_the_wave_primitives(tmp_path):
+    """autocycler_amd/csrc/wave_rt.hpp under AC_EMU — what lets the CPU suite run the SAME wave kernels the device runs — checked on its own:
+    ballots, shuffles, a barrier over LDS, diverging lane groups, lanes that return early, a reported deadlock."""
+    import subprocess
+    exe = tmp_path / "wave_rt_check"
+    subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-I", str(ROOT / "autocycler_amd" / "csrc"), str(ROOT / "tests" / "c_client" / "wave_rt_check.cpp"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "wave_rt_check: OK" in out.stdout, out.stdout[-2000:]
+
+
 def test_header_symbols_exported_by_product_library():
     """The C-ABI library loads (no GPU needed) and exports every function include/autocycler_hip.h declares."""
     header = (ROOT / "include" / "autocycler_hip.h").read_text()

@@ -447,7 +447,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static u32 seed_max_group() { const char* e = getenv("AC_SEED_MAX_GROUP"); int v = e ? atoi(e) : 1024; return (u32)(v < 1 ? 1 : v); }      // tests: smaller groups take the fallback
 [[maybe_unused]] static int seed_prefix_bits() { const char* e = getenv("AC_SEED_PREFIX_BITS"); int v = e ? atoi(e) : 64; return v < 1 ? 1 : (v > 64 ? 64 : v); }      // tests
 [[maybe_unused]] static u32 degree_region_cap() { const char* e = getenv("AC_DEGREE_REGION_CAP"); int v = e ? atoi(e) : 0; return (u32)(v < 0 ? 0 : v); }      // tests: entries per queue region (0 = sized from N)
-[[maybe_unused]] static u64 upload_chunk_bytes() { return (u64)64 << 20; }      // text bytes per upload chunk (16 MB of codes per copy)
+[[maybe_unused]] static u64 upload_chunk_bytes() { return (u64)64 << 20; }      // text bytes per upload chunk (16 MB of codes per copy; 8-32 MB chunks over 2-3 copy queues: 2.8 against 3.2 ms in tools/microbench/upload_probe.hip, nothing in the build: r10o)
 [[maybe_unused]] static int upload_slots() { const char* e = getenv("AC_UPLOAD_SLOTS"); int v = e ? atoi(e) : 1 << 20; return v < 1 ? 1 : v; }      // tests: fewer staging slots, so that chunks wait for one
 [[maybe_unused]] static int degree_flags() { const char* e = getenv("AC_DEGREE_FLAGS"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }      // 0: every degree by probing (what sharded builds and k < 3 do)
 [[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); if (!e) return -1; int v = atoi(e); return v < 0 ? 0 : (v > 3 ? 3 : v); }      // -1 = automatic
@@ -592,7 +592,7 @@ struct GraphBuilder::Impl {
         std::vector<uint64_t> off;
         uint32_t k = 0; u64 n = 0, CH = 0, SUB = 0, n_chunks = 0, slot_bytes = 0; int NSLOT = 0, dev = 0;
         hipStream_t up = nullptr, pk = nullptr;
-        u64* d_bits = nullptr; u32* d_mask = nullptr; bool send_mask = false;
+        u64* d_bits = nullptr;
         std::atomic<u64> next{0}, nonbase{0}; u64 expected_nonbase = 0;      // alphabet check: non-base bytes the packers met / the sequence table promises
         std::vector<std::atomic<u32>> done, slot_state, issued;      // slot_state: 0 untouched, 1 someone is waiting for the slot, 2 free
         std::vector<hipEvent_t> landed;                               // per chunk: both of its copies are on the device
@@ -1785,7 +1785,10 @@ static void fill_text_range(const std::vector<SeqView>& seqs, const std::vector<
 // K1 on the host: 32 text bytes -> one word of 2-bit codes (first base most significant) + 32 mask bits, exactly what PackFunctor
 // computes on the device.  AVX2 classifies 32 bytes at a time, BMI2 `pext` squeezes 8 codes out of 8 bytes; ~12 GB/s of text per
 // core, so sixteen threads pack as fast as the host's memory delivers the text.
-static void pack_groups_scalar(const u8* t, u64 n_groups, u64* bits, u32* mask) {
+// All of them return the number of mask bits they saw set; `mask` may be null (the upload derives the mask plane on the device and
+// only needs the count for the alphabet check).
+static u64 pack_groups_scalar(const u8* t, u64 n_groups, u64* bits, u32* mask) {
+    u64 nonbase = 0;
     for (u64 g = 0; g < n_groups; g++) {
         u64 w = 0; u32 m = 0;
         for (int i = 0; i < 32; i++) {
@@ -1795,17 +1798,21 @@ static void pack_groups_scalar(const u8* t, u64 n_groups, u64* bits, u32* mask) 
             w |= (u64)c << (62 - 2 * i);
             m |= bad << i;
         }
-        bits[g] = w; mask[g] = m;
+        bits[g] = w;
+        if (mask) mask[g] = m;
+        nonbase += (u64)__builtin_popcount(m);
     }
+    return nonbase;
 }
 #if defined(__x86_64__)
 }  // namespace ac
 #include <immintrin.h>
 namespace ac {
-__attribute__((target("avx2,bmi2"))) static void pack_groups_avx2(const u8* t, u64 n_groups, u64* bits, u32* mask) {
+__attribute__((target("avx2,bmi2,popcnt"))) static u64 pack_groups_avx2(const u8* t, u64 n_groups, u64* bits, u32* mask) {
     const __m256i vA = _mm256_set1_epi8('A'), vC = _mm256_set1_epi8('C'), vG = _mm256_set1_epi8('G'), vT = _mm256_set1_epi8('T');
     const __m256i three = _mm256_set1_epi8(3);
     const u64 M = 0x0303030303030303ULL;
+    u64 nonbase = 0;
     for (u64 g = 0; g < n_groups; g++) {
         const __m256i v = _mm256_loadu_si256((const __m256i*)(t + g * 32));
         const __m256i good = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, vA), _mm256_cmpeq_epi8(v, vC)),
@@ -1813,23 +1820,27 @@ __attribute__((target("avx2,bmi2"))) static void pack_groups_avx2(const u8* t, u
         // ((ch >> 1) ^ (ch >> 2)) & 3 per byte: 16-bit shifts only move a neighbour's bit into bit 7, which the mask drops
         __m256i c = _mm256_and_si256(_mm256_xor_si256(_mm256_srli_epi16(v, 1), _mm256_srli_epi16(v, 2)), three);
         c = _mm256_and_si256(c, good);
-        mask[g] = ~(u32)_mm256_movemask_epi8(good);
+        const u32 bad = ~(u32)_mm256_movemask_epi8(good);
+        if (mask) mask[g] = bad;
+        nonbase += (u64)__builtin_popcount(bad);
         alignas(32) u64 q[4];
         _mm256_store_si256((__m256i*)q, c);
         bits[g] = (_pext_u64(__builtin_bswap64(q[0]), M) << 48) | (_pext_u64(__builtin_bswap64(q[1]), M) << 32) |
                   (_pext_u64(__builtin_bswap64(q[2]), M) << 16) | _pext_u64(__builtin_bswap64(q[3]), M);
     }
+    return nonbase;
 }
 // Two groups (64 bytes) per step with AVX-512: codes ((ch >> 1) ^ (ch >> 2)) & 3 under the "is a base" mask, four of them folded into
 // a byte by two multiply-adds (4 a + b per byte pair, then 16 x + y per pair of those), sixteen bytes narrowed out of the dwords and
 // reversed inside each half so that the first base ends up most significant; the mask bits are the compare masks as they come.
-__attribute__((target("avx512f,avx512bw,avx512vl,ssse3"))) static void pack_groups_avx512(const u8* t, u64 n_groups, u64* bits, u32* mask) {
+// (Non-temporal stores for the codes — written once, read next by the copy engine — measured neutral: r10l / r10m.)
+__attribute__((target("avx512f,avx512bw,avx512vl,ssse3,popcnt"))) static u64 pack_groups_avx512(const u8* t, u64 n_groups, u64* bits, u32* mask) {
     const __m512i vA = _mm512_set1_epi8('A'), vC = _mm512_set1_epi8('C'), vG = _mm512_set1_epi8('G'), vT = _mm512_set1_epi8('T');
     const __m512i three = _mm512_set1_epi8(3);
     const __m512i w1 = _mm512_set1_epi16(0x0104);      // per byte pair (first, second): 4 * first + second   (low byte = first in memory)
     const __m512i w2 = _mm512_set1_epi32(0x00010010);  // per word pair: 16 * first + second
     const __m128i rev = _mm_set_epi8(8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7);
-    u64 g = 0;
+    u64 g = 0, nonbase = 0;
     for (; g + 2 <= n_groups; g += 2) {
         const __m512i v = _mm512_loadu_si512((const void*)(t + g * 32));
         const __mmask64 good = _mm512_cmpeq_epi8_mask(v, vA) | _mm512_cmpeq_epi8_mask(v, vC) | _mm512_cmpeq_epi8_mask(v, vG) | _mm512_cmpeq_epi8_mask(v, vT);
@@ -1840,21 +1851,23 @@ __attribute__((target("avx512f,avx512bw,avx512vl,ssse3"))) static void pack_grou
         const __m128i by = _mm_shuffle_epi8(_mm512_cvtepi32_epi8(n32), rev);
         _mm_storeu_si128((__m128i*)(bits + g), by);
         const u64 bad = ~(u64)good;
-        mask[g] = (u32)bad; mask[g + 1] = (u32)(bad >> 32);
+        if (mask) { mask[g] = (u32)bad; mask[g + 1] = (u32)(bad >> 32); }
+        nonbase += (u64)__builtin_popcountll(bad);
     }
-    if (g < n_groups) pack_groups_avx2(t + g * 32, n_groups - g, bits + g, mask + g);
+    if (g < n_groups) nonbase += pack_groups_avx2(t + g * 32, n_groups - g, bits + g, mask ? mask + g : nullptr);
+    return nonbase;
 }
 #endif
-static void pack_groups(const u8* t, u64 n_groups, u64* bits, u32* mask) {
+static u64 pack_groups(const u8* t, u64 n_groups, u64* bits, u32* mask) {
 #if defined(__x86_64__)
     static const bool simd_off = getenv("AC_PACK_SCALAR") != nullptr;
     static const bool fast = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !simd_off;
     static const bool wide = fast && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") &&
                              getenv("AC_PACK_AVX2") == nullptr;
-    if (wide) { pack_groups_avx512(t, n_groups, bits, mask); return; }
-    if (fast) { pack_groups_avx2(t, n_groups, bits, mask); return; }
+    if (wide) return pack_groups_avx512(t, n_groups, bits, mask);
+    if (fast) return pack_groups_avx2(t, n_groups, bits, mask);
 #endif
-    pack_groups_scalar(t, n_groups, bits, mask);
+    return pack_groups_scalar(t, n_groups, bits, mask);
 }
 
 void pack_text_host(const uint8_t* text, uint64_t n_text, uint64_t* bits, uint32_t* mask32, bool force_scalar) {
@@ -1879,13 +1892,13 @@ static u64 pack_text_groups(const std::vector<SeqView>& seqs, const std::vector<
     size_t lo = 0, hi = seqs.size();
     while (lo < hi) { size_t mid = (lo + hi) / 2; if (off[mid] + (u64)seqs[mid].length + k - 1 + 1 <= b) lo = mid + 1; else hi = mid; }
     size_t i = lo;
-    u64 g = g0;
+    u64 g = g0, nonbase = 0;
     auto slow = [&](u64 gg) {      // a group with a separator (or the text's end) in it
         u8 tmp[32];
         const u64 tb = gg * 32, te = std::min(n_text, tb + 32);
         if (tb < te) fill_text_range(seqs, off, k, tb, te, tmp);
         for (u64 j = te > tb ? te - tb : 0; j < 32; j++) tmp[j] = '$';
-        pack_groups(tmp, 1, bits + (gg - g0), mask + (gg - g0));
+        nonbase += pack_groups(tmp, 1, bits + (gg - g0), mask ? mask + (gg - g0) : nullptr);
     };
     while (g < g1) {
         while (i < seqs.size() && off[i] + (u64)seqs[i].length + k - 1 <= g * 32) i++;      // sequence i ends at or before this group's start
@@ -1894,14 +1907,12 @@ static u64 pack_text_groups(const std::vector<SeqView>& seqs, const std::vector<
         if (g * 32 < s0) { slow(g++); continue; }
         const u64 g_in = std::min(g1, s1 / 32);      // groups [g, g_in) lie wholly inside [s0, s1)
         if (g_in > g) {
-            pack_groups(seqs[i].fwd + (g * 32 - s0), g_in - g, bits + (g - g0), mask + (g - g0));
+            nonbase += pack_groups(seqs[i].fwd + (g * 32 - s0), g_in - g, bits + (g - g0), mask ? mask + (g - g0) : nullptr);
             g = g_in;
         } else {
             slow(g++);
         }
     }
-    u64 nonbase = 0;
-    for (u64 q = 0; q < g1 - g0; q++) nonbase += (u64)__builtin_popcount(mask[q]);
     return nonbase;
 }
 // The host entry's alphabet check failed: name the first sequence that holds anything but A, C, G, T between its padding dots.
@@ -1921,7 +1932,8 @@ static u64 pack_text_groups(const std::vector<SeqView>& seqs, const std::vector<
 
 // Final (end-repaired) sequences: the text never reaches the device as bytes.  Host threads lay a piece of the text out in a
 // cache-resident buffer, pack it (K1 above) straight into a pinned slot, and whoever finishes a 64 MB chunk sends its 16 MB of
-// codes and 8 MB of mask bits: 0.375 bytes per base cross PCIe instead of 1 (config C: 183 MB in ~3.5 ms instead of 487 MB in ~9).
+// codes; the mask plane is derived on the device from the sequence table: 0.25 bytes per base cross PCIe instead of 1 (config C:
+// 122 MB instead of 487 MB).
 void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::vector<uint64_t>& off) {
     const uint32_t k = impl_->k;
     PackedText& loc = impl_->loc;
@@ -1929,12 +1941,10 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
     HostStager& st = HostStager::get();
     st.ensure();
     const u64 CH = upload_chunk_bytes(), SUB = (u64)1 << 20;      // text bytes per chunk (one pair of copies) / per work item
-    const u64 SLOT_BYTES = CH / 4 + CH / 8;                // codes + mask bits of one chunk
+    const u64 SLOT_BYTES = CH / 4;                         // the codes of one chunk (the mask plane is derived on the device)
     [[maybe_unused]] const int NSLOT = std::max(1, std::min((int)((HostStager::SLOT * HostStager::NS) / SLOT_BYTES), upload_slots()));
     [[maybe_unused]] const u64 n_chunks = (n + CH - 1) / CH, subs = CH / SUB;
     [[maybe_unused]] auto chunk_len = [&](u64 c) { return std::min(n, (c + 1) * CH) - c * CH; };
-    [[maybe_unused]] auto slot_bits = [&](int sl) { return (u64*)(st.slot(0) + (u64)sl * SLOT_BYTES); };
-    [[maybe_unused]] auto slot_mask = [&](int sl) { return (u32*)(st.slot(0) + (u64)sl * SLOT_BYTES + CH / 4); };
 #ifdef AC_EMU
     loc.pack_alloc();
     u64 nonbase = 0;
@@ -1964,14 +1974,12 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
     AC_HIP_CHECK(hipEventRecord(st.begin(), 0));
     AC_HIP_CHECK(hipStreamWaitEvent(job->pk, st.begin(), 0));
     loc.pack_alloc(job->pk);                               // zero codes / all-ones mask beyond the text (and under it, until the copies land)
-    job->send_mask = false;
-    if (!job->send_mask) {      // the mask plane from the sequence table, on the device (MaskTableFunctor): 0.25 instead of 0.375 bytes per base cross PCIe
-        AC_HIP_CHECK(hipMemsetAsync(loc.mask.ptr(), 0, (size_t)((n + 63) / 64) * 8, job->pk));
-        launch((u64)loc.n_seqs + 1, MaskTableFunctor{loc.seq_off.ptr(), loc.seq_len.ptr(), loc.seq_d1.ptr(), loc.seq_d2.ptr(), loc.n_seqs, (int)k, n, loc.mask.ptr()}, job->pk);
-    }
+    // the mask plane from the sequence table, on the device (MaskTableFunctor): 0.25 instead of 0.375 bytes per base cross PCIe
+    AC_HIP_CHECK(hipMemsetAsync(loc.mask.ptr(), 0, (size_t)((n + 63) / 64) * 8, job->pk));
+    launch((u64)loc.n_seqs + 1, MaskTableFunctor{loc.seq_off.ptr(), loc.seq_len.ptr(), loc.seq_d1.ptr(), loc.seq_d2.ptr(), loc.n_seqs, (int)k, n, loc.mask.ptr()}, job->pk);
     AC_HIP_CHECK(hipEventRecord(st.copied(), job->pk));
     AC_HIP_CHECK(hipStreamWaitEvent(job->up, st.copied(), 0));
-    job->d_bits = loc.bits.ptr(); job->d_mask = (u32*)loc.mask.ptr();
+    job->d_bits = loc.bits.ptr();
     job->done = std::vector<std::atomic<u32>>(n_chunks); job->slot_state = std::vector<std::atomic<u32>>(n_chunks);
     job->issued = std::vector<std::atomic<u32>>(n_chunks);
     for (u64 c = 0; c < n_chunks; c++) { job->done[c].store(0); job->slot_state[c].store(0); job->issued[c].store(0); }
@@ -1992,7 +2000,6 @@ void GraphBuilder::Impl::UploadJob::run() {
     const u64 subs = CH / SUB;
     auto chunk_len = [&](u64 c) { return std::min(n, (c + 1) * CH) - c * CH; };
     auto slot_bits = [&](int sl) { return (u64*)(st.slot(0) + (u64)sl * slot_bytes); };
-    auto slot_mask = [&](int sl) { return (u32*)(st.slot(0) + (u64)sl * slot_bytes + CH / 4); };
     try {
         AC_HIP_CHECK(hipSetDevice(dev));
         for (u64 item; (item = next.fetch_add(1)) < n_chunks * subs && !stop.load();) {
@@ -2012,21 +2019,14 @@ void GraphBuilder::Impl::UploadJob::run() {
                 if (stop.load()) break;
             }
             const u64 b = c * CH + sub * SUB, e = std::min(c * CH + clen, b + SUB);
-            nonbase.fetch_add(pack_text_groups(*seqs, off, k, n, b / 32, (e + 31) / 32, slot_bits(sl) + sub * SUB / 32, slot_mask(sl) + sub * SUB / 32),
+            nonbase.fetch_add(pack_text_groups(*seqs, off, k, n, b / 32, (e + 31) / 32, slot_bits(sl) + sub * SUB / 32, nullptr),
                               std::memory_order_relaxed);
             const u32 n_sub = (u32)((clen + SUB - 1) / SUB);
             if (done[c].fetch_add(1, std::memory_order_acq_rel) + 1 == n_sub) {      // the chunk is complete: send it
                 const u64 g0 = c * CH / 32, ng = (clen + 31) / 32;
                 std::lock_guard<std::mutex> lock(hip_mu);
-                // codes and mask bits of a chunk travel on two streams (two copy engines): the smaller copy no longer sits
-                // between two big ones on one queue.  The chunk has landed (and its slot is free again) when both have.
-                if (send_mask) {
-                    AC_HIP_CHECK(hipMemcpyAsync(d_mask + g0, slot_mask(sl), ng * 4, hipMemcpyHostToDevice, pk));
-                    AC_HIP_CHECK(hipEventRecord(st.copied(), pk));
-                }
                 AC_HIP_CHECK(hipMemcpyAsync(d_bits + g0, slot_bits(sl), ng * 8, hipMemcpyHostToDevice, up));
-                if (send_mask) AC_HIP_CHECK(hipStreamWaitEvent(up, st.copied(), 0));
-                AC_HIP_CHECK(hipEventRecord(landed[c], up));
+                AC_HIP_CHECK(hipEventRecord(landed[c], up));      // the chunk is on the device (and its slot free again)
                 issued[c].store(1, std::memory_order_release);
             }
         }

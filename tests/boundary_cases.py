@@ -179,12 +179,15 @@ def host_pack_simd_equals_scalar(lib_path):
         text = pool[rng.integers(0, len(pool), size=n)].copy()
         g = (n + 31) // 32
         outs = []
-        for scalar in (0, 1):
-            bits = np.zeros(g, dtype=np.uint64); mask = np.zeros(g, dtype=np.uint32)
+        for scalar in (0, 1, 0):      # the third output starts 8 bytes off a 16-byte boundary (the streaming stores' prologue)
+            bits = np.zeros(g + 3, dtype=np.uint64); mask = np.zeros(g, dtype=np.uint32)
+            shift = (bits.ctypes.data // 8 + len(outs) // 2) % 2
+            bits = bits[shift:shift + g]
             assert lib.ac_pack_text(text.ctypes.data_as(C.c_void_p), C.c_uint64(n), bits.ctypes.data_as(C.c_void_p), mask.ctypes.data_as(C.c_void_p),
                                     C.c_int(scalar)) == 0
             outs.append((bits, mask))
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        assert np.array_equal(outs[0][0], outs[2][0]) and np.array_equal(outs[0][1], outs[2][1])
         padded = np.concatenate([text, np.full(g * 32 - n, ord("$"), dtype=np.uint8)]).reshape(g, 32)
         good = np.isin(padded, np.frombuffer(b"ACGT", dtype=np.uint8))
         code = np.where(good, ((padded >> 1) ^ (padded >> 2)) & 3, 0).astype(np.uint64)

@@ -292,6 +292,23 @@ struct alignas(16) V16 { u32 a, b, c, d; };
 #include "kernels_tail.inc"      // K13 link order, K14 analysis, K15 renumbering, K17 expand_repeats, K16 finalisation, K12 sequences
 #include "kernels_shard.inc"      // fragments and reduce buffers of a sharded build
 // =============================================================================================================
+// The paths' final numbers, applied on the host.  The path entries are final — in SEED numbers — when the walk ends, the final numbers
+// exist only after expand_repeats and the second renumbering, and 4 bytes per entry over PCIe were the last thing a build waited for
+// (config C: 42 MB = 0.7 ms of 4.5).  A single-device build therefore sends the entries right after the walk, under the whole tail,
+// and the final number per seed index (4 bytes per unitig) as soon as it exists; host threads rewrite the entries in the pinned result
+// block while the remaining results (unitig records, links) are still crossing.  (unitig_graph.rs:renumber_unitigs only permutes.)
+struct PathRemapJob {
+    int32_t* path = nullptr; u64 n_ent = 0;
+    const u32* number = nullptr; u32 n_unitigs = 0;      // pinned: final number of seed index r at [r]
+    void* landed = nullptr;                              // event: entries and number table are in host memory
+    int dev = 0;
+    std::atomic<u64> next{0}; std::atomic<int> ready{0};      // ready: 0 nobody waits yet, 1 one thread waits for `landed`, 2 go, 3 failed
+    std::atomic<u32> bad{0};                             // entries that name no unitig (never, short of a bug: reported as an internal error)
+    u64 ticket = 0; bool started = false;
+};
+void path_remap_range(int32_t* p, u64 n, const u32* number, u32 n_unitigs, std::atomic<u32>* bad);
+void path_remap_start(PathRemapJob& j, int threads);      // returns at once; the work runs on the packing threads' pool
+void path_remap_finish(PathRemapJob& j) noexcept;         // until every thread is done (idempotent)
 #if AC_W_ONLY == 0
 std::vector<uint8_t> layout_text(const std::vector<SeqView>& seqs, uint32_t k, std::vector<uint64_t>* off,
                                  std::vector<uint32_t>* len, std::vector<uint16_t>* d1, std::vector<uint16_t>* d2) {
@@ -441,6 +458,11 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
     while (pc < 2048 && (u64)pc * 3 / 2 < want) pc *= 2;
     return pc;
 }
+// Path entries leave the device in seed numbers right after the walk and get their final numbers on the host (single-device builds):
+// 1 always, 0 never, otherwise when the number table (4 bytes per unitig) stays in the host's caches — up to 8 M unitigs — and there is
+// enough to hide.  Measured (r10p/q): config C 4.50 -> 3.93 ms, E' 18.5 -> 17.7, mini-E (6.5 M unitigs) 69.8 -> 64.5; with 26 M unitigs
+// (8 species) 277 -> 321 ms and with 82 M (configs[4]) 0.89 -> 1.29 s: random gathers from a table in DRAM are slower than the link.
+[[maybe_unused]] static int host_remap_mode() { const char* e = getenv("AC_HOST_REMAP"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }
 [[maybe_unused]] static u32 remap_block() { const char* e = getenv("AC_REMAP_BLOCK"); int v = e ? atoi(e) : 4096; v = v < 64 ? 64 : (v > 65536 ? 65536 : v); return (u32)(v & ~63); }
 [[maybe_unused]] static int minkey_prefix_bases() { const char* e = getenv("AC_MINKEY_PREFIX_BASES"); int v = e ? atoi(e) : 31; return v < 1 ? 1 : (v > 31 ? 31 : v); }      // tests: a shorter prefix takes the full-key path often
 [[maybe_unused]] static bool seed_prefix_sort() { const char* e = getenv("AC_SEED_PREFIX_SORT"); return e ? atoi(e) != 0 : true; }      // 0: seed order by the full-key sorts
@@ -559,6 +581,7 @@ struct GraphBuilder::Impl {
     DBuf<u8> fs0, fe0;
     // single-device builds: smallest positions beyond it are kept as a lower bound only (kernels_tail.inc exp_avoid_start_of_path); all ones = exact
     u32 pos_cap_now = 0xFFFFFFFFu; bool exact_positions = false;
+    bool host_remap_allowed = false;      // GraphBuilder::build only: the result block of the paths is this build's own
     DBuf<u8> maybe_dest; bool maybe_dest_valid = false;      // (unitig, side) that may become an expand_repeats destination (walk's position filter)
     // fragments of a sharded build
     DBuf<u8> frag_text; DBuf<u64> frag_meta, frag_fpos, frag_boff; u64 frag_bytes = 0, n_frags = 0;      // (frag_text: only when someone asks for bytes)
@@ -1249,6 +1272,19 @@ template <int W> void GraphBuilder::Impl::walk() {
 template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph, bool want_paths) {
     PackedText& g = *G;
     const u32 n_seqs = loc.n_seqs;
+    SideStream& side = SideStream::get();
+    SideStream::Guard side_guard;
+    // (see PathRemapJob) the entries go now, in seed numbers, under everything that follows
+    const bool host_remap = want_paths && host_remap_allowed && n_ent > 0 &&
+                            (host_remap_mode() == 1 || (host_remap_mode() < 0 && n_ent >= (1u << 18) && U <= (8u << 20)));
+    HostBlock number_block;
+    PathRemapJob remap_job;
+    struct RemapJoin { PathRemapJob& j; ~RemapJoin() { path_remap_finish(j); } } remap_join{remap_job};      // (before number_block goes)
+    if (host_remap) {
+        out->path_block = PinnedPool::get().alloc(n_ent * 4);
+        side.after_main();
+        copy_d2h_async(out->path_block.p, ent_val.ptr(), n_ent * 4, side.stream());
+    }
     // K12 sequences
     u64 total = N;   // sum of unitig lengths == number of distinct canonical k-mers
     DBuf<u8> useq(total);
@@ -1447,8 +1483,6 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     // sequences; K16 per-unitig outputs in final order, links in get_links_for_gfa order, paths in final numbers
     // D2H on a second stream, each array as soon as it is final, straight into pinned blocks owned by the result; the
     // paths go in four chunks, each copied while the next is still being renumbered.
-    SideStream& side = SideStream::get();
-    SideStream::Guard side_guard;
     if (want_graph) {
         out->seq_block = PinnedPool::get().alloc(final_total);
         side.after_main();     // sequences are final since the materialise step: their copy runs under the second renumbering
@@ -1458,6 +1492,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     copy_d2d(order2.ptr(), order1.ptr(), (size_t)U * 4);
     renumber_sort(order2, U, clen.ptr(), coff.ptr(), cur, depth.ptr(), renum_flag.ptr());
     DBuf<u64> number_len(U), lcount((u64)U + 1), loff((u64)U + 1);
+    DBuf<u32> number_only(host_remap ? U : 0);
     DBuf<u8> meta((size_t)U * 20);
     u64* d_seq_begin = (u64*)meta.ptr();
     double* d_depth = (double*)(meta.ptr() + (size_t)U * 8);
@@ -1467,7 +1502,19 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     out->n_kmers = 2 * (u64)N;
     out->n_unitigs = U;
     launch(U, FinalMetaFunctor{order2.ptr(), coff.ptr(), clen.ptr(), depth.ptr(), lcnt.ptr(), number_len.ptr(), d_seq_begin, d_depth,
-                               d_seq_len, lcount.ptr()});
+                               d_seq_len, lcount.ptr(), host_remap ? number_only.ptr() : nullptr});
+    if (host_remap) {      // the number table first: the host threads start on the entries while the rest is still crossing
+        number_block = PinnedPool::get().alloc((size_t)U * 4);
+        side.after_main();
+        copy_d2h_async(number_block.p, number_only.ptr(), (size_t)U * 4, side.stream());
+        remap_job.path = (int32_t*)out->path_block.p; remap_job.n_ent = n_ent;
+        remap_job.number = (const u32*)number_block.p; remap_job.n_unitigs = U;
+        remap_job.landed = side.mark();
+#ifndef AC_EMU
+        AC_HIP_CHECK(hipGetDevice(&remap_job.dev));
+        path_remap_start(remap_job, (int)upload_threads());
+#endif
+    }
     if (want_graph) {
         out->meta_block = PinnedPool::get().alloc((size_t)U * 20);
         side.after_main();
@@ -1484,8 +1531,12 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     }
     DBuf<u64> sums(n_seqs);
     sums.fill_bytes(0);
-    if (want_paths) out->path_block = PinnedPool::get().alloc(n_ent * 4);
-    {
+    if (host_remap) {      // the device only checks that every path spells its sequence's length (the sums), it stores nothing
+        const u64 RB = remap_block();
+        const u64 n_waves = (n_ent + RB - 1) / RB;
+        launch_full(n_waves * 64, RemapFunctor{ent_val.ptr(), number_len.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr(), 0, (u32)RB, nullptr, false});
+    } else {
+        if (want_paths) out->path_block = PinnedPool::get().alloc(n_ent * 4);
         const u64 RB = remap_block();
         const u64 n_waves = (n_ent + RB - 1) / RB;
         // Four chunks, each copied while the next is renumbered (the kernel storing straight into the pinned block measured equal, r08j:
@@ -1493,7 +1544,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         const u64 per_chunk = std::max<u64>((n_waves + 3) / 4, 64);
         for (u64 w = 0; w < n_waves; w += per_chunk) {
             u64 cnt = std::min<u64>(per_chunk, n_waves - w);
-            launch_full(cnt * 64, RemapFunctor{ent_val.ptr(), number_len.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr(), w, (u32)RB, nullptr});
+            launch_full(cnt * 64, RemapFunctor{ent_val.ptr(), number_len.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr(), w, (u32)RB, nullptr, true});
             if (want_paths) {
                 u64 b = w * RB, e2 = std::min<u64>((w + cnt) * RB, n_ent);
                 side.after_main();
@@ -1516,11 +1567,18 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         rb.run();                                   // synchronises stream 0 (once)
     }
     side.sync();                                    // ... and the copies: everything above has landed
+    if (host_remap) {
+#ifdef AC_EMU
+        path_remap_range(remap_job.path, n_ent, remap_job.number, U, &remap_job.bad);
+#endif
+        path_remap_finish(remap_job);
+    }
     if (loc.pack_bad.size()) loc.verify_alphabet(pack_bad);      // before any internal check: a text with foreign bytes explains them all
     if (errs[7] & 128u) throw NeedExactPositions();      // (before anything else: a repeat of the build settles it)
     if (errs[7]) throw DeviceError("internal error: expand_repeats pool overflow");
     if (errs[3] || errs[4])
         throw DeviceError("internal error: inconsistent unitig ends (codes " + std::to_string(errs[3]) + "/" + std::to_string(errs[4]) + ")");
+    if (remap_job.bad.load()) throw DeviceError("internal error: path entries without a unitig");
     if (want_graph) {
         out->seq_begin = (const u64*)out->meta_block.p;
         out->depth = (const double*)((const u8*)out->meta_block.p + (size_t)U * 8);
@@ -1699,6 +1757,7 @@ class UploadPool {
     u64 gen_ = 0; int want_ = 0, active_ = 0; bool stop_ = false;
 };
 #endif
+
 class HostStager {
   public:
     static const size_t SLOT = (size_t)16 << 20;     // 16 MB per copy: the SDMA path reaches 55 GB/s from 16 MB up (1-4 MB: 25-37 GB/s)
@@ -1869,6 +1928,71 @@ static u64 pack_groups(const u8* t, u64 n_groups, u64* bits, u32* mask) {
 #endif
     return pack_groups_scalar(t, n_groups, bits, mask);
 }
+
+// ---- PathRemapJob: seed numbers -> final numbers in the pinned result block ---------------------------------------------------
+static void path_remap_scalar(int32_t* p, u64 n, const u32* number, u32 n_unitigs, std::atomic<u32>* bad) {
+    u32 wrong = 0;
+    for (u64 i = 0; i < n; i++) {
+        const int32_t v = p[i];
+        const u32 r = (u32)(v > 0 ? v : -v) - 1u;
+        if (r >= n_unitigs) { wrong++; continue; }
+        const int32_t f = (int32_t)number[r];
+        p[i] = v > 0 ? f : -f;
+    }
+    if (wrong) bad->fetch_add(wrong);
+}
+#if defined(__x86_64__)
+// sixteen entries per step: |v| - 1 gathers the final number, the sign goes back on under a mask
+__attribute__((target("avx512f"))) static void path_remap_avx512(int32_t* p, u64 n, const u32* number, u32 n_unitigs, std::atomic<u32>* bad) {
+    const __m512i one = _mm512_set1_epi32(1), zero = _mm512_setzero_si512(), lim = _mm512_set1_epi32((int)n_unitigs);
+    u64 i = 0;
+    for (; i + 16 <= n; i += 16) {
+        const __m512i v = _mm512_loadu_si512((const void*)(p + i));
+        const __m512i r = _mm512_sub_epi32(_mm512_abs_epi32(v), one);
+        const __mmask16 ok = _mm512_cmplt_epu32_mask(r, lim);
+        if (ok != 0xFFFF) { path_remap_scalar(p + i, 16, number, n_unitigs, bad); continue; }
+        __m512i f = _mm512_i32gather_epi32(r, (const void*)number, 4);
+        f = _mm512_mask_sub_epi32(f, _mm512_cmplt_epi32_mask(v, zero), zero, f);
+        _mm512_storeu_si512((void*)(p + i), f);
+    }
+    path_remap_scalar(p + i, n - i, number, n_unitigs, bad);
+}
+#endif
+void path_remap_range(int32_t* p, u64 n, const u32* number, u32 n_unitigs, std::atomic<u32>* bad) {
+#if defined(__x86_64__)
+    static const bool wide = __builtin_cpu_supports("avx512f") && getenv("AC_PACK_SCALAR") == nullptr && getenv("AC_PACK_AVX2") == nullptr;
+    if (wide && n_unitigs < 0x7FFFFFFFu) { path_remap_avx512(p, n, number, n_unitigs, bad); return; }
+#endif
+    path_remap_scalar(p, n, number, n_unitigs, bad);
+}
+#ifndef AC_EMU
+void path_remap_start(PathRemapJob& j, int threads) {
+    const u64 BLOCK = (u64)1 << 15;
+    const int T = (int)std::max<u64>(1, std::min<u64>({(j.n_ent + BLOCK - 1) / BLOCK, (u64)std::max(threads, 1), (u64)std::max(1u, std::thread::hardware_concurrency())}));
+    PathRemapJob* job = &j;
+    j.started = true;
+    j.ticket = UploadPool::get().start(T, [job, BLOCK] {
+        int expect = 0;
+        if (job->ready.compare_exchange_strong(expect, 1)) {      // one thread waits for the copies, the others watch it
+            const bool ok = hipSetDevice(job->dev) == hipSuccess && hipEventSynchronize((hipEvent_t)job->landed) == hipSuccess;
+            job->ready.store(ok ? 2 : 3, std::memory_order_release);
+        } else {
+            while (job->ready.load(std::memory_order_acquire) < 2) std::this_thread::yield();
+        }
+        if (job->ready.load(std::memory_order_acquire) != 2) { job->bad.fetch_add(1); return; }
+        for (u64 b; (b = job->next.fetch_add(BLOCK)) < job->n_ent;)
+            path_remap_range(job->path + b, std::min(BLOCK, job->n_ent - b), job->number, job->n_unitigs, &job->bad);
+    });
+}
+void path_remap_finish(PathRemapJob& j) noexcept {
+    if (!j.started) return;
+    UploadPool::get().wait(j.ticket);
+    j.started = false;
+}
+#else
+void path_remap_start(PathRemapJob&, int) {}
+void path_remap_finish(PathRemapJob&) noexcept {}
+#endif
 
 void pack_text_host(const uint8_t* text, uint64_t n_text, uint64_t* bits, uint32_t* mask32, bool force_scalar) {
     const u64 full = n_text / 32;
@@ -2228,6 +2352,7 @@ void GraphBuilder::build(uint32_t assembly_count_hint, FinalGraph* out) {
     Impl& m = *impl_;
     m.begin(&tm_);
     m.G = &m.loc;
+    m.host_remap_allowed = true;
     m.check_sizes(m.loc);
     m.pack_overlapped(assembly_count_hint);
     m.lap(&tm_.pack);

@@ -589,7 +589,7 @@ struct GraphBuilder::Impl {
 
     void begin(BuildTimings* t) {
         tm = t; t_begin = t0 = now_s();
-
+        host_remap_allowed = false;      // (GraphBuilder::build switches it on for itself)
         counters.alloc(8); counters.fill_bytes(0);
     }
     void check_sizes(const PackedText& t) const {

@@ -307,6 +307,7 @@ struct PathRemapJob {
     u64 ticket = 0; bool started = false;
 };
 void path_remap_range(int32_t* p, u64 n, const u32* number, u32 n_unitigs, std::atomic<u32>* bad);
+bool path_remap_is_wide();      // the host has the 16-lane gather (without it a thread renumbers ~5x slower and the device keeps the job)
 void path_remap_start(PathRemapJob& j, int threads);      // returns at once; the work runs on the packing threads' pool
 void path_remap_finish(PathRemapJob& j) noexcept;         // until every thread is done (idempotent)
 #if AC_W_ONLY == 0
@@ -1276,7 +1277,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     SideStream::Guard side_guard;
     // (see PathRemapJob) the entries go now, in seed numbers, under everything that follows
     const bool host_remap = want_paths && host_remap_allowed && n_ent > 0 &&
-                            (host_remap_mode() == 1 || (host_remap_mode() < 0 && n_ent >= (1u << 18) && U <= (8u << 20)));
+                            (host_remap_mode() == 1 || (host_remap_mode() < 0 && n_ent >= (1u << 18) && U <= (8u << 20) && path_remap_is_wide()));
     HostBlock number_block;
     PathRemapJob remap_job;
     struct RemapJoin { PathRemapJob& j; ~RemapJoin() { path_remap_finish(j); } } remap_join{remap_job};      // (before number_block goes)
@@ -1936,8 +1937,8 @@ static void path_remap_scalar(int32_t* p, u64 n, const u32* number, u32 n_unitig
         const int32_t v = p[i];
         const u32 r = (u32)(v > 0 ? v : -v) - 1u;
         if (r >= n_unitigs) { wrong++; continue; }
-        const int32_t f = (int32_t)number[r];
-        p[i] = v > 0 ? f : -f;
+        const int32_t f = (int32_t)number[r], m = v >> 31;      // (the sign without a branch: strands alternate unpredictably)
+        p[i] = (f ^ m) - m;
     }
     if (wrong) bad->fetch_add(wrong);
 }
@@ -1958,10 +1959,17 @@ __attribute__((target("avx512f"))) static void path_remap_avx512(int32_t* p, u64
     path_remap_scalar(p + i, n - i, number, n_unitigs, bad);
 }
 #endif
-void path_remap_range(int32_t* p, u64 n, const u32* number, u32 n_unitigs, std::atomic<u32>* bad) {
+bool path_remap_is_wide() {
 #if defined(__x86_64__)
     static const bool wide = __builtin_cpu_supports("avx512f") && getenv("AC_PACK_SCALAR") == nullptr && getenv("AC_PACK_AVX2") == nullptr;
-    if (wide && n_unitigs < 0x7FFFFFFFu) { path_remap_avx512(p, n, number, n_unitigs, bad); return; }
+    return wide;
+#else
+    return false;
+#endif
+}
+void path_remap_range(int32_t* p, u64 n, const u32* number, u32 n_unitigs, std::atomic<u32>* bad) {
+#if defined(__x86_64__)
+    if (path_remap_is_wide() && n_unitigs < 0x7FFFFFFFu) { path_remap_avx512(p, n, number, n_unitigs, bad); return; }
 #endif
     path_remap_scalar(p, n, number, n_unitigs, bad);
 }

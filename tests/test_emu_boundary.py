@@ -58,6 +58,23 @@ def test_host_pack_avx2_equals_scalar(emu):
     assert out.returncode == 0 and "pack ok" in out.stdout, out.stderr[-2000:]
 
 
+def test_host_path_renumbering_portable_loop(emu):
+    """PathRemapJob with the portable loop forced (AC_PACK_SCALAR switches the AVX-512 gather off; read once per process: a fresh one):
+    paths renumbered on the host == the oracle's, positions included."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    here = Path(__file__).resolve().parent
+    code = (f"import sys; sys.path.insert(0, {str(here.parent)!r}); sys.path.insert(0, {str(here)!r}); "
+            "import boundary_cases as B, seqgen; "
+            "cases = [(k, *seqgen.make_case(seed, k)) for k, seed in ((9, 2), (21, 5), (51, 13))]; "
+            f"B.positions_match_the_oracle({str(emu)!r}, cases); print('remap ok')")
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, "AC_PACK_SCALAR": "1", "AC_HOST_REMAP": "1", "AC_NO_TORCH": "1"},
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "remap ok" in out.stdout, out.stderr[-2000:]
+
+
 def test_device_entry_rejects_a_bad_sequence_table(emu):
     """ac_compress_build_device / ac_shard_begin / ac_end_repair_device index the text with the caller's table — a table
     that does not describe the text must come back as an error (never a fault or a silent wrong graph)."""

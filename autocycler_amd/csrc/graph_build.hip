@@ -1274,13 +1274,13 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     PackedText& g = *G;
     const u32 n_seqs = loc.n_seqs;
     SideStream& side = SideStream::get();
+    HostBlock number_block;      // (declared before the guard: it goes after the side stream has drained, whatever ends this scope)
     SideStream::Guard side_guard;
     // (see PathRemapJob) the entries go now, in seed numbers, under everything that follows
     const bool host_remap = want_paths && host_remap_allowed && n_ent > 0 &&
                             (host_remap_mode() == 1 || (host_remap_mode() < 0 && n_ent >= (1u << 18) && U <= (8u << 20) && path_remap_is_wide()));
-    HostBlock number_block;
     PathRemapJob remap_job;
-    struct RemapJoin { PathRemapJob& j; ~RemapJoin() { path_remap_finish(j); } } remap_join{remap_job};      // (before number_block goes)
+    struct RemapJoin { PathRemapJob& j; ~RemapJoin() { path_remap_finish(j); } } remap_join{remap_job};      // (the threads are done before the guard and the table go)
     if (host_remap) {
         out->path_block = PinnedPool::get().alloc(n_ent * 4);
         side.after_main();

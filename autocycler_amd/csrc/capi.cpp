@@ -663,14 +663,15 @@ int ac_decompress_seq(const ac_graph* g, uint32_t seq_index, uint8_t* out) {
     });
 }
 
-int ac_random_access_ceilings(int device, double* cas_gops, double* read_gops) {
+int ac_random_access_ceilings_at(int device, uint64_t table_slots, double* cas_gops, double* read_gops) {
     return guarded([&] {
         std::lock_guard<std::mutex> lock(g_build_mutex);
         if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
         select_device(device);
-        random_access_ceilings(cas_gops, read_gops);
+        random_access_ceilings(cas_gops, read_gops, table_slots);
     });
 }
+int ac_random_access_ceilings(int device, double* cas_gops, double* read_gops) { return ac_random_access_ceilings_at(device, (uint64_t)1 << 24, cas_gops, read_gops); }
 
 // The whole `autocycler decompress` command (decompress.rs:27-39): GFA file -> the assemblies it was built from, one file per
 // original filename in out_dir (gzip when the name ends in .gz, decompress.rs:83-105) and / or all contigs in one FASTA file

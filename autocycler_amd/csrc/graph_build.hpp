@@ -153,7 +153,7 @@ void end_repair_device(uint32_t k, uint8_t* d_text, uint64_t n_text, const std::
 void pairwise_distances_device(const FinalGraph& g, uint32_t n_seqs, double* out);
 
 // Measured ceilings of the device for random atomicCAS / random 8-byte reads on a 134 MB table, in 10^9 operations per second.
-void random_access_ceilings(double* cas_gops, double* read_gops);
+void random_access_ceilings(double* cas_gops, double* read_gops, uint64_t table_slots = (uint64_t)1 << 24);
 
 // Brings the HIP context and this library's code objects up on `device` (first use costs ~0.2 s): callable from a helper
 // thread while the caller is still busy on the host.

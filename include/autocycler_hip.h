@@ -299,8 +299,11 @@ int ac_compress_dir_multi(const char* assemblies_dir, const char* autocycler_dir
                           const int* devices, int n_devices, ac_graph** graph_out, double* times);
 
 /* Measured ceilings of the device for the two access patterns the graph build is bound by: random atomicCAS and random 8-byte
- * reads on a 134 MB table, in 10^9 operations per second (a ~20 ms microbenchmark; bench.py prices its kernels against them). */
+ * reads on a 134 MB table, in 10^9 operations per second (a ~20 ms microbenchmark; bench.py prices its kernels against them).
+ * _at: on a table of table_slots 8-byte slots (rounded up to a power of two between 2^24 and 2^30) — the size of the k-mer table
+ * the workload in question builds (ac_timings.table_capacity): a table beyond the 256 MB Infinity Cache takes fewer claims per second. */
 int ac_random_access_ceilings(int device, double* cas_gops, double* read_gops);
+int ac_random_access_ceilings_at(int device, uint64_t table_slots, double* cas_gops, double* read_gops);
 void ac_set_stage_timing(int on);   /* off by default */
 int ac_release_memory(void);        /* frees the device arena and the pinned result pool kept between builds */
 const char* ac_last_error(void);

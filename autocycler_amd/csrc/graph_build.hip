@@ -471,6 +471,19 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static int seed_prefix_bits() { const char* e = getenv("AC_SEED_PREFIX_BITS"); int v = e ? atoi(e) : 64; return v < 1 ? 1 : (v > 64 ? 64 : v); }      // tests
 [[maybe_unused]] static u32 degree_region_cap() { const char* e = getenv("AC_DEGREE_REGION_CAP"); int v = e ? atoi(e) : 0; return (u32)(v < 0 ? 0 : v); }      // tests: entries per queue region (0 = sized from N)
 [[maybe_unused]] static u64 upload_chunk_bytes() { return (u64)64 << 20; }      // text bytes per upload chunk (16 MB of codes per copy; 8-32 MB chunks over 2-3 copy queues: 2.8 against 3.2 ms in tools/microbench/upload_probe.hip, nothing in the build: r10o)
+// The packers write the codes straight into device memory (through the PCIe BAR, write-combined) instead of into a pinned ring a copy
+// engine then reads: 1 / 0 forces / forbids, otherwise on when the device says its whole memory is host-visible (hipDeviceAttributeIsLargeBar).
+[[maybe_unused]] static int upload_direct_mode() { const char* e = getenv("AC_UPLOAD_DIRECT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }
+[[maybe_unused]] static bool upload_direct_for(int dev) {
+#ifndef AC_EMU
+    if (upload_direct_mode() >= 0) return upload_direct_mode() == 1;
+    int large_bar = 0;
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return large_bar != 0;
+#else
+    (void)dev; return false;
+#endif
+}
 [[maybe_unused]] static int upload_slots() { const char* e = getenv("AC_UPLOAD_SLOTS"); int v = e ? atoi(e) : 1 << 20; return v < 1 ? 1 : v; }      // tests: fewer staging slots, so that chunks wait for one
 [[maybe_unused]] static int degree_flags() { const char* e = getenv("AC_DEGREE_FLAGS"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }      // 0: every degree by probing (what sharded builds and k < 3 do)
 [[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); if (!e) return -1; int v = atoi(e); return v < 0 ? 0 : (v > 3 ? 3 : v); }      // -1 = automatic
@@ -617,7 +630,10 @@ struct GraphBuilder::Impl {
         uint32_t k = 0; u64 n = 0, CH = 0, SUB = 0, n_chunks = 0, slot_bytes = 0; int NSLOT = 0, dev = 0;
         hipStream_t up = nullptr, pk = nullptr;
         u64* d_bits = nullptr;
-        std::atomic<u64> next{0}, nonbase{0}; u64 expected_nonbase = 0;      // alphabet check: non-base bytes the packers met / the sequence table promises
+        bool direct = false;                                          // the packers store into d_bits themselves (no ring, no copies, no `landed` events)
+        double t_start = 0; std::atomic<u64> chunks_issued{0}; std::atomic<double> t_last{0};      // direct: host clock from the first store to the last flush
+        hipEvent_t fills_done = nullptr;                              // direct: the device has set the slack behind the last group (the last work item waits for it)
+        std::atomic<u64> next{0}, nonbase{0}, bar_sink{0}; u64 expected_nonbase = 0;      // alphabet check: non-base bytes the packers met / the sequence table promises
         std::vector<std::atomic<u32>> done, slot_state, issued;      // slot_state: 0 untouched, 1 someone is waiting for the slot, 2 free
         std::vector<hipEvent_t> landed;                               // per chunk: both of its copies are on the device
         std::mutex hip_mu; std::string fail; std::atomic<bool> stop{false};
@@ -1770,14 +1786,13 @@ class HostStager {
 #ifndef AC_EMU
         int dev = 0;
         AC_HIP_CHECK(hipGetDevice(&dev));
-        if (ring_ && dev == dev_) return;
+        if (created_ && dev == dev_) return;
         if (created_) {
             (void)hipStreamDestroy(s_); (void)hipStreamDestroy(pk_);
             for (auto& e : ev_) (void)hipEventDestroy(e);
             (void)hipEventDestroy(done_); (void)hipEventDestroy(begin_); (void)hipEventDestroy(copied_); (void)hipEventDestroy(first_);
             created_ = false;
         }
-        if (!ring_) AC_HIP_CHECK(hipHostMalloc((void**)&ring_, SLOT * NS, hipHostMallocDefault));
         AC_HIP_CHECK(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
         AC_HIP_CHECK(hipStreamCreateWithFlags(&pk_, hipStreamNonBlocking));
         for (auto& e : ev_) AC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1798,7 +1813,14 @@ class HostStager {
 #endif
         ring_ = nullptr;
     }
-    u8* slot(int i) { return ring_ + (size_t)i * SLOT; }
+    // the pinned ring: allocated when somebody stages through it (the direct upload never does)
+    u8* slot(int i) {
+#ifndef AC_EMU
+        if (!ring_) AC_HIP_CHECK(hipHostMalloc((void**)&ring_, SLOT * NS, hipHostMallocDefault));
+#endif
+        return ring_ + (size_t)i * SLOT;
+    }
+    void ensure_ring() { (void)slot(0); }
 #ifndef AC_EMU
     hipStream_t stream() { return s_; }            // the copies, back to back
     hipStream_t pack_stream() { return pk_; }      // K1 on each chunk, behind its copy (a kernel between two copies of ONE stream idles the link)
@@ -1808,6 +1830,7 @@ class HostStager {
     hipEvent_t& copied() { return copied_; }
     hipEvent_t& first() { return first_; }
     bool timed = false;                            // begin / done bracket an upload whose duration has not been read yet
+    double direct_ms = -1;                         // ... or the packers wrote device memory themselves: host clock, first store to last flush
 #else
     stream_t stream() { return 0; }
 #endif
@@ -1822,7 +1845,13 @@ class HostStager {
 #endif
 };
 void release_host_stager() { HostStager::get().release(); }
-[[maybe_unused]] static void ensure_host_stager() { HostStager::get().ensure(); }
+[[maybe_unused]] static void ensure_host_stager() {
+    HostStager::get().ensure();
+#ifndef AC_EMU
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && !(host_pack() && upload_direct_for(dev))) HostStager::get().ensure_ring();      // (the direct upload never stages)
+#endif
+}
 
 // Bytes [b, e) of the text layout of `seqs` (off[i] = first padded byte of sequence i; every padded sequence is followed by '$').
 static void fill_text_range(const std::vector<SeqView>& seqs, const std::vector<uint64_t>& off, uint32_t k, u64 b, u64 e, u8* dst) {
@@ -2112,11 +2141,18 @@ void GraphBuilder::upload_packed(const std::vector<SeqView>& seqs, const std::ve
     AC_HIP_CHECK(hipEventRecord(st.copied(), job->pk));
     AC_HIP_CHECK(hipStreamWaitEvent(job->up, st.copied(), 0));
     job->d_bits = loc.bits.ptr();
+    {
+        job->direct = upload_direct_for(job->dev);
+        if (!job->direct) st.ensure_ring();
+        job->fills_done = st.copied();
+        if (job->direct) AC_HIP_CHECK(hipStreamWaitEvent(0, st.copied(), 0));      // (no copies to order the insert behind the mask plane and the slack fills)
+        job->t_start = now_s();
+    }
     job->done = std::vector<std::atomic<u32>>(n_chunks); job->slot_state = std::vector<std::atomic<u32>>(n_chunks);
     job->issued = std::vector<std::atomic<u32>>(n_chunks);
     for (u64 c = 0; c < n_chunks; c++) { job->done[c].store(0); job->slot_state[c].store(0); job->issued[c].store(0); }
     job->landed.assign(n_chunks, nullptr);
-    for (auto& e : job->landed) AC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!job->direct) for (auto& e : job->landed) AC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const int T = (int)std::max<u64>(1, std::min<u64>({(n + SUB - 1) / SUB, upload_threads(), (u64)std::max(1u, std::thread::hardware_concurrency())}));
     job->ticket = UploadPool::get().start(T, [job] { job->run(); });
     // This thread goes on to the build: the insert waits for the chunks as it gets to them (Impl::need_text).  Without the overlap
@@ -2138,6 +2174,26 @@ void GraphBuilder::Impl::UploadJob::run() {
             const u64 c = item / subs, sub = item % subs;
             const u64 clen = chunk_len(c);
             if (sub * SUB >= clen) continue;
+            if (direct) {
+                // Straight into device memory: 16-byte stores in ascending order combine into full PCIe writes, nothing is ever read
+                // back from there by the packers.  A work item is on the device when its stores have left this core (sfence) and a
+                // read from the device has come back behind them (a PCIe read does not pass posted writes); only then does it count.
+                const u64 b = c * CH + sub * SUB, e = std::min(c * CH + clen, b + SUB);
+                if (e >= n) AC_HIP_CHECK(hipEventSynchronize(fills_done));      // (the text's last words share a 16-byte unit with the slack the device zeroes)
+                u64* dst = d_bits + b / 32;
+                const u64 ng = (e + 31) / 32 - b / 32;
+                nonbase.fetch_add(pack_text_groups(*seqs, off, k, n, b / 32, (e + 31) / 32, dst, nullptr), std::memory_order_relaxed);
+#if defined(__x86_64__)
+                _mm_sfence();
+#endif
+                if (ng) { const volatile u64* back = dst + (ng - 1); bar_sink.fetch_xor(*back, std::memory_order_relaxed); }
+                const u32 n_sub = (u32)((clen + SUB - 1) / SUB);
+                if (done[c].fetch_add(1, std::memory_order_acq_rel) + 1 == n_sub) {
+                    issued[c].store(1, std::memory_order_release);
+                    if (chunks_issued.fetch_add(1) + 1 == n_chunks) t_last.store(now_s());
+                }
+                continue;
+            }
             const int sl = (int)(c % (u64)NSLOT);
             if (c >= (u64)NSLOT) {      // the chunk that used this slot before must have left it: one thread waits, the others watch it
                 u32 expect = 0;
@@ -2174,8 +2230,10 @@ void GraphBuilder::Impl::need_text(u64 upto) {
         const u64 c = job->next_wait;
         while (!job->issued[c].load(std::memory_order_acquire) && !job->stop.load()) std::this_thread::yield();
         if (job->stop.load()) finish_upload();      // throws
-        flush_fills();
-        AC_HIP_CHECK(hipStreamWaitEvent(0, job->landed[c], 0));
+        if (!job->direct) {
+            flush_fills();
+            AC_HIP_CHECK(hipStreamWaitEvent(0, job->landed[c], 0));
+        }
         job->next_wait++;
     }
     if (job->next_wait == job->n_chunks) finish_upload();
@@ -2196,7 +2254,9 @@ void GraphBuilder::Impl::finish_upload() {
     UploadPool::get().wait(j->ticket);
     HostStager& st = HostStager::get();
     std::string fail = j->fail;
-    if (fail.empty()) {
+    if (fail.empty() && j->direct) {
+        st.direct_ms = j->t_last.load() > 0 ? (j->t_last.load() - j->t_start) * 1e3 : -1.0;
+    } else if (fail.empty()) {
         if (hipEventRecord(st.done(), j->up) != hipSuccess) fail = "hipEventRecord failed";
         st.timed = true;
     } else { (void)hipStreamSynchronize(j->up); (void)hipStreamSynchronize(j->pk); }
@@ -2249,6 +2309,7 @@ void GraphBuilder::set_sequences_host(const std::vector<SeqView>& seqs, bool pac
     loc.set_table(off, len, d1, d2);
     HostStager& st = HostStager::get();
     st.ensure();
+    st.ensure_ring();
     const u64 C = HostStager::SLOT;
     const u64 n_chunks = (n + C - 1) / C;
     u8* const d_text = impl_->text_owned.ptr();
@@ -2393,6 +2454,7 @@ void GraphBuilder::build(uint32_t assembly_count_hint, FinalGraph* out) {
         if (hipEventElapsedTime(&ms, HostStager::get().begin(), HostStager::get().done()) == hipSuccess) tm_.upload_device_ms = ms;
         HostStager::get().timed = false;
     }
+    if (HostStager::get().direct_ms >= 0) { tm_.upload_device_ms = HostStager::get().direct_ms; HostStager::get().direct_ms = -1; }      // (direct stores: the host's clock)
 #endif
 }
 

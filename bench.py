@@ -396,12 +396,13 @@ def main():
         t_hot = {"value": bases / 1e6 / (e_hot / args.steps), "unit": "Mbp/s", "ms_per_step": e_hot / args.steps * 1e3, "steps": args.steps,
                  "elapsed_s": e_hot, "step_ms_list": [round(x * 1e3, 2) for x in hs],
                  "timed_region": "padded+repaired sequences in pageable host RAM (one buffer per sequence view) -> final unitig graph in host "
-                                 "RAM through ac_compress_build: 2-bit pack on the host (16 background threads) into a pinned ring, 64 MB chunks "
-                                 "sent as 16 + 8 MB copies (0.375 B per base over PCIe), the insert issued chunk by chunk as they land, "
-                                 "device build, D2H of the results",
+                                 "RAM through ac_compress_build: 2-bit pack on the host (32 background threads) straight into device memory where the "
+                                 "device's memory is host-visible (large BAR; else into a pinned ring sent as 16 MB copies): 0.25 B per base over PCIe, "
+                                 "the mask plane derived on the device, the insert issued piece by piece as the 64 MB chunks land, device build, D2H "
+                                 "of the results",
                  "step_ms": {"min": min(hs) * 1e3, "median": sorted(hs)[len(hs) // 2] * 1e3, "max": max(hs) * 1e3},
                  "upload_ms": sum(hupd) / len(hupd), "upload_GBps": (n_text / (sum(hupd) / len(hupd) * 1e-3) / 1e9) if sum(hupd) else None,      # text bytes per second
-                 "upload_pcie_GBps": (0.375 * n_text / (sum(hupd) / len(hupd) * 1e-3) / 1e9) if sum(hupd) else None,      # what crosses the link: 2 bit + 1 mask bit per base
+                 "upload_pcie_GBps": (0.25 * n_text / (sum(hupd) / len(hupd) * 1e-3) / 1e9) if sum(hupd) else None,      # what crosses the link: 2 bits per base
                  "upload_host_side_ms": sum(hup) / len(hup) * 1e3,      # (until the build thread has the first chunk: the rest is sent in the background)
                  "first_call_ms": first_host_ms, "gfa_md5": md5_host, "same_graph_as_device_entry": True}
         del text_host

@@ -62,7 +62,8 @@ typedef struct {
     double fragments;           /* cutting this rank's novel runs out of its text */
     double union_pack, union_insert;   /* packing / inserting the union of all ranks' fragments */
     uint64_t n_local_distinct, n_fragments, fragment_bytes;
-    double upload_device_ms;    /* ac_compress_build only: first H2D copy issued -> last chunk landed and packed (HIP events) */
+    double upload_device_ms;    /* ac_compress_build only: the upload from its first byte to its last chunk on the device (host clock when the packers
+                                 * store into device memory themselves, HIP events around the copies of the pinned-ring path) */
     uint64_t path_runs_copied, path_entries_walked;   /* the copying path walk: runs whose entries were copied, entries really walked (0, 0: plain walk) */
     uint64_t position_retries;   /* builds repeated with exact smallest positions because expand_repeats met a common sequence longer than the bound kept (AC_POS_CAP) */
     uint32_t n_candidates_owned; /* the candidate junctions THIS rank ran (a job over several devices with a partitioned tail; else = n_candidates) */

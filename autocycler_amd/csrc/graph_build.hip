@@ -1845,12 +1845,9 @@ class HostStager {
 #endif
 };
 void release_host_stager() { HostStager::get().release(); }
-[[maybe_unused]] static void ensure_host_stager() {
+[[maybe_unused]] static void ensure_host_stager() {      // (device_warmup: the whole-command path uploads the text as BYTES for the end repair — through the ring)
     HostStager::get().ensure();
-#ifndef AC_EMU
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && !(host_pack() && upload_direct_for(dev))) HostStager::get().ensure_ring();      // (the direct upload never stages)
-#endif
+    HostStager::get().ensure_ring();
 }
 
 // Bytes [b, e) of the text layout of `seqs` (off[i] = first padded byte of sequence i; every padded sequence is followed by '$').

@@ -234,12 +234,14 @@ def test_config_c_digest_with_the_plain_path_walk():
     assert rows[0]["path_runs_copied"] == 0 and rows[1]["path_runs_copied"] > 0
 
 
-@pytest.mark.parametrize("variants", ["base", "AC_PATH_COPY=0", "AC_UPLOAD_OVERLAP=0", "AC_HOST_PACK=0", "AC_UPLOAD_THREADS=5", "AC_UPLOAD_SLOTS=2", "AC_UPLOAD_CHUNK_MB=16,AC_UPLOAD_SLOTS=3", "AC_UPLOAD_SLOTS=1,AC_UPLOAD_OVERLAP=0"])
+@pytest.mark.parametrize("variants", ["base", "AC_PATH_COPY=0", "AC_UPLOAD_OVERLAP=0", "AC_HOST_PACK=0", "AC_UPLOAD_THREADS=5", "AC_UPLOAD_DIRECT=0", "AC_UPLOAD_DIRECT=0,AC_UPLOAD_THREADS=5",
+                                      "AC_UPLOAD_DIRECT=0,AC_UPLOAD_SLOTS=2", "AC_UPLOAD_DIRECT=0,AC_UPLOAD_SLOTS=1,AC_UPLOAD_OVERLAP=0", "AC_UPLOAD_DIRECT=1,AC_UPLOAD_THREADS=64"])
 def test_host_entry_full_size_digest(variants):
-    """The HOST entry (ac_compress_build from pageable per-sequence buffers: host-side 2-bit pack, chunked upload through the pinned
-    ring by background threads, the insert issued chunk by chunk as they land) on the whole config C — 487 MB of text, eight 64 MB
-    chunks — gives the oracle's GFA digest: also with the overlap off, with the byte upload + device pack, with an odd number of
-    packing threads, and with so few staging slots (or such small chunks) that every chunk has to wait for an earlier one's slot."""
+    """The HOST entry (ac_compress_build from pageable per-sequence buffers: host-side 2-bit pack by background threads — straight into
+    device memory where it is host-visible, AC_UPLOAD_DIRECT=0: through the pinned ring in 16 MB copies —, the insert issued piece by
+    piece as the chunks land) on the whole config C — 487 MB of text, eight 64 MB chunks — gives the oracle's GFA digest: also with the
+    overlap off, with the byte upload + device pack, with an odd number of packing threads, and, through the ring, with so few staging
+    slots that every chunk has to wait for an earlier one's slot."""
     import json
     import os
     import subprocess

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Launch-by-launch timeline of the LAST build of a torch-free driver run (rocprofv3 --kernel-trace; tools/rocpd_launches.py).
 # Usage: tools/gpu_timeline.sh TAG [ab_knobs args...]   -> gpurun_out/TAG_timeline.txt, gpurun_out/TAG_kernel_stats.csv
+# (TIMELINE_MARKER = the kernel whose last launch begins the last build: PackFunctor for the device entry, MaskTableFunctor for --host-entry)
 TAG=$1; shift
 export TMPDIR=/tmp AC_NO_TORCH=1
 R=$PWD
@@ -11,12 +12,12 @@ cd $R
 DB=$(find gpurun_out/${TAG}_prof -name '*.db' | head -1)
 if [ -n "$DB" ]; then
   python tools/rocpd_stats.py $DB > gpurun_out/${TAG}_kernel_stats.csv
-  python - $DB > gpurun_out/${TAG}_timeline.txt <<'PY'
+  python - $DB ${TIMELINE_MARKER:-PackFunctor} > gpurun_out/${TAG}_timeline.txt <<'PY'
 import re, sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
 # the last build = everything after the last PackFunctor launch
-last = max(i for i, r in enumerate(rows) if "PackFunctor" in r[0])
+last = max(i for i, r in enumerate(rows) if sys.argv[2] in r[0])
 rows = rows[last:]
 t0 = rows[0][1]; prev = t0; busy = 0
 for i, (name, s, e) in enumerate(rows):

@@ -436,7 +436,7 @@ int ac_shard_links_export(ac_shard* s, void* d_links_i32, void* d_wlinks_i64) {
 int ac_shard_links_import(ac_shard* s, const void* d_links_i32, const void* d_wlinks_i64) {
     return guarded([&] {
         if (s->phase != 4) throw DeviceError("ac_shard_links_import: wrong phase");
-        if ((!d_links_i32 || !d_wlinks_i64) && s->n_shards > 1) throw DeviceError("ac_shard_links_import: the summed link words are required when there are several shards");
+        if (!d_links_i32 && s->n_shards > 1) throw DeviceError("ac_shard_links_import: the summed link words are required when there are several shards");
         std::lock_guard<std::mutex> lock(g_build_mutex);
         select_device(s->device);
         s->b->links_import(d_links_i32, d_wlinks_i64);

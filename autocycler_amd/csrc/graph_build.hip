@@ -503,6 +503,8 @@ static thread_local int tl_upload_threads_cap = 0;      // a rank of a multi-dev
 [[maybe_unused]] static bool seq_writer_forced() { const char* e = getenv("AC_SEQ_WRITER"); return e && atoi(e) == 1; }    // 1 = always the indexed / LDS-tiled writers
 [[maybe_unused]] static u64 seed_radix_limit() { const char* e = getenv("AC_SEED_RADIX_LIMIT"); return e ? (u64)atoll(e) : (1u << 19); }      // unitigs from which the seed order is a radix sort
 [[maybe_unused]] static bool upload_overlap() { const char* e = getenv("AC_UPLOAD_OVERLAP"); return e ? atoi(e) != 0 : true; }      // host entry: first insert phases while the upload's tail is in flight
+[[maybe_unused]] static bool shard_host_remap() { const char* e = getenv("AC_SHARD_HOST_REMAP"); return e ? atoi(e) != 0 : true; }      // 0 = sharded builds renumber their paths on the device (round 4)
+[[maybe_unused]] static bool shard_degree_flags() { const char* e = getenv("AC_SHARD_DEGREE_FLAGS"); return e ? atoi(e) != 0 : true; }      // 0 = sharded builds probe every degree (round 4)
 [[maybe_unused]] static bool insert_adaptive() { const char* e = getenv("AC_INSERT_ADAPT"); return e ? atoi(e) != 0 : true; }
 [[maybe_unused]] static u64 insert_growth() { const char* e = getenv("AC_INSERT_GROWTH"); long x = e ? atol(e) : 2; return (u64)(x < 2 ? 2 : x); }      // phase i+1 ends at growth x the end of phase i
 [[maybe_unused]] static u64 insert_waves_target() { const char* e = getenv("AC_INSERT_WAVES"); long x = e ? atol(e) : 16384; return (u64)(x < 1024 ? 1024 : x); }   // wavefronts a long phase is cut into
@@ -512,7 +514,7 @@ struct PackedText {
     const u8* d_text = nullptr;
     u64 n_text = 0, n_bases = 0;
     u32 n_seqs = 0;
-    int any_dots = 0;
+    int any_dots = 0; u64 n_dotted = 0;      // sequences (fragments) that kept a dot at either end
     DBuf<u64> seq_off; DBuf<u32> seq_len; DBuf<u16> seq_d1, seq_d2; DBuf<u8> seq_flags;
     bool has_flags = false;
     DBuf<u64> bits, mask;
@@ -533,8 +535,8 @@ struct PackedText {
         copy_h2d(seq_d2.ptr(), d2.data(), (size_t)n_seqs * 2);
         has_flags = flags != nullptr;
         if (flags) { seq_flags.alloc(n_seqs); copy_h2d(seq_flags.ptr(), flags->data(), n_seqs); }
-        n_bases = 0; any_dots = 0; expected_nonbase = (u64)n_seqs + 1;
-        for (u32 i = 0; i < n_seqs; i++) { n_bases += len[i]; if (d1[i] || d2[i]) any_dots = 1; expected_nonbase += (u64)d1[i] + d2[i]; }
+        n_bases = 0; any_dots = 0; n_dotted = 0; expected_nonbase = (u64)n_seqs + 1;
+        for (u32 i = 0; i < n_seqs; i++) { n_bases += len[i]; if (d1[i] || d2[i]) { any_dots = 1; n_dotted++; } expected_nonbase += (u64)d1[i] + d2[i]; }
         stream_sync();
     }
     TextCtx ctx(int k) const { return TextCtx{bits.ptr(), mask.ptr(), n_text, k, seq_off.ptr(), seq_len.ptr(), seq_d1.ptr(), seq_d2.ptr(), n_seqs}; }
@@ -595,7 +597,8 @@ struct GraphBuilder::Impl {
     DBuf<u8> fs0, fe0;
     // single-device builds: smallest positions beyond it are kept as a lower bound only (kernels_tail.inc exp_avoid_start_of_path); all ones = exact
     u32 pos_cap_now = 0xFFFFFFFFu; bool exact_positions = false;
-    bool host_remap_allowed = false;      // GraphBuilder::build only: the result block of the paths is this build's own
+    bool host_remap_allowed = false;      // GraphBuilder::build, and a rank of a sharded build that keeps its own paths: the result block of the paths is this build's own
+    bool paths_in_seed_numbers = false;   // the tail left ent_val in seed numbers (the host renumbered the copy it took)
     DBuf<u8> maybe_dest; bool maybe_dest_valid = false;      // (unitig, side) that may become an expand_repeats destination (walk's position filter)
     // fragments of a sharded build
     DBuf<u8> frag_text; DBuf<u64> frag_meta, frag_fpos, frag_boff; u64 frag_bytes = 0, n_frags = 0;      // (frag_text: only when someone asks for bytes)
@@ -616,6 +619,7 @@ struct GraphBuilder::Impl {
     void occupancy_bitmap(const DBuf<u64>& sl, u64 c, DBuf<u64>* occ_out, const u64* sflags_in, u64* sib_out);
     DBuf<u64> occ;             // slot-occupancy bitmap of the graph table
     DBuf<u64> sib;             // sibling bits of the graph table's real k-mers, two per text position (MarkFunctor); empty = not used
+    DBuf<u32> kcontrib;        // sharded builds with the light degree step: this rank's contributions to kinfo (degrees()); empty = kinfo itself
     DBuf<u64> endset, endset_bloom; u64 endset_mask = 0;      // sequence-end set (EndSetFunctor) and its two filters
     u32 n_owners = 1, my_owner = 0;      // sharded builds: which slice of the key space the graph table holds (§7)
     // host entry: stream 0 only waited for the FIRST chunk of the packed upload; positions below upload_avail are on the device, the
@@ -936,7 +940,9 @@ template <int W> void GraphBuilder::Impl::fragments() {
 template <int W> void GraphBuilder::Impl::table() {
     PackedText& g = *G;
     check_sizes(g);
-    const bool want_sib = n_owners <= 1 && k >= 3 && degree_flags();      // single device: the degree pass's shortcut (sharded builds probe)
+    // the degree pass's shortcut (sibling bits).  Sharded builds collect them too since round 5: all the k-mers of one middle have one owner,
+    // so an owner's table sees every sibling pair; the bits travel with the novel bitmap (bitmap_export)
+    const bool want_sib = k >= 3 && degree_flags() && (n_owners <= 1 || shard_degree_flags());
     insert<W>(g, tm->graph_hint, &slots, &cap, &N, &bm, want_sib);      // sharded builds: only the k-mers this rank owns (N = how many)
     tm->table_capacity = cap;
     tm->n_distinct = N;
@@ -979,9 +985,12 @@ inline void GraphBuilder::Impl::novel_list(u64 known_n) {
 template <int W> void GraphBuilder::Impl::degrees() {
     PackedText& g = *G;
     Table tb = graph_table();
+    kcontrib = DBuf<u32>();
+    u32* kout = kinfo.ptr();      // where probes and first flags add what they find
     EndSet es{nullptr, 0, nullptr, nullptr};
-    if (sib.size() && g.any_dots && !g.has_flags) {
-        endset_mask = next_pow2(4 * (u64)g.n_seqs + 16) - 1;
+    if (sib.size() && g.any_dots) {
+        // (a sharded build's "sequences" are fragments, most of them without a dot: the set is sized for those that have one)
+        endset_mask = next_pow2(4 * (g.has_flags ? g.n_dotted : (u64)g.n_seqs) + 16) - 1;
         endset.alloc((endset_mask + 1) * W);
         endset.fill_bytes(0xFF);
         endset_bloom.alloc(2 * ENDSET_BLOOM_WORDS);
@@ -990,6 +999,7 @@ template <int W> void GraphBuilder::Impl::degrees() {
         launch(2 * (u64)g.n_seqs, EndSetFunctor<W>{g.ctx((int)k), es});
     }
     if (sib.size() && degree_flags() == 1 && (!g.any_dots || es.keys)) {      // settle what the sibling bits settle, queue the rest, probe the queues
+        if (n_owners > 1) { kcontrib.alloc(N, true); kout = kcontrib.ptr(); }      // (outlives the stage: taken before its mark)
         const Arena::Mark deg_mark = Arena::device().mark();      // the queues below are the stage's own (8 B per distinct k-mer)
         DegWork wk;
         // a k-mer whose window holds dots starts within k - 1 positions of a sequence end: at most 2 (k - 1) per sequence
@@ -1001,8 +1011,11 @@ template <int W> void GraphBuilder::Impl::degrees() {
         counts.fill_bytes(0);
         wk.items = items.ptr(); wk.counts = counts.ptr();
         const u64 n_thr = (((N + DEG_BATCH - 1) / DEG_BATCH) + 63) & ~63ULL;
+        // Sharded builds: the light step is the same on every rank (it reads the text and the summed bitmaps only) and stays in kinfo;
+        // what the probes and the first flags find is a rank's CONTRIBUTION (only the owner of a probe cluster finds anything in it) and goes
+        // to kcontrib, which is what degrees_export sends — a byte per k-mer that is zero for the 97-99 % the light step settled
         launch_full(n_thr, DegreeLightFunctor<W>{g.ctx((int)k), npos.ptr(), kinfo.ptr(), g.any_dots, bm.ptr(), sib.ptr(), es, wk, N, n_thr});
-        launch((u64)DEG_LISTS * DEG_REGIONS * DEG_PROBE_THREADS, DegreeProbeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kinfo.ptr(), g.any_dots, wk, es});
+        launch((u64)DEG_LISTS * DEG_REGIONS * DEG_PROBE_THREADS, DegreeProbeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kout, g.any_dots, wk, es});
 #ifdef AC_EMU
         if (getenv("AC_DEGREE_DIAG")) {
             u64 c0 = 0, c1 = 0, sx = 0;
@@ -1015,9 +1028,9 @@ template <int W> void GraphBuilder::Impl::degrees() {
         items = DBuf<u64>(); counts = DBuf<u32>();
         Arena::device().rewind(deg_mark);
     } else
-        launch(N, DegreeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kinfo.ptr(), g.any_dots, 0, bm.ptr(), sib.size() ? sib.ptr() : nullptr, es});
+        launch(N, DegreeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kinfo.ptr(), g.any_dots, 0, bm.ptr(), sib.size() && n_owners <= 1 ? sib.ptr() : nullptr, es});
     Novel nv{bm.ptr(), wprefix.ptr()};
-    launch(g.n_seqs, FirstFunctor<W>{g.ctx((int)k), tb, nv, kinfo.ptr(), g.has_flags ? g.seq_flags.ptr() : nullptr});
+    launch(g.n_seqs, FirstFunctor<W>{g.ctx((int)k), tb, nv, kout, g.has_flags ? g.seq_flags.ptr() : nullptr});
     lap(&tm->degree);
 }
 
@@ -1297,6 +1310,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                             (host_remap_mode() == 1 || (host_remap_mode() < 0 && n_ent >= (1u << 18) && U <= (8u << 20) && path_remap_is_wide()));
     PathRemapJob remap_job;
     struct RemapJoin { PathRemapJob& j; ~RemapJoin() { path_remap_finish(j); } } remap_join{remap_job};      // (the threads are done before the guard and the table go)
+    paths_in_seed_numbers = host_remap;
     if (host_remap) {
         out->path_block = PinnedPool::get().alloc(n_ent * 4);
         side.after_main();
@@ -2503,6 +2517,7 @@ void GraphBuilder::shard_build_union(uint32_t rank, uint32_t n_shards, const uin
 void GraphBuilder::build_union_impl(uint32_t rank, uint32_t n_shards, const uint8_t* d_union_text, const void* d_staged_words, const uint64_t* first_word,
                                     const uint64_t* n_words, uint64_t n_union_text, const void* d_meta, uint64_t n_frags_total) {
     if (n_shards == 0 || rank >= n_shards) throw DeviceError("invalid rank / shard count");
+    if (n_shards > 255) throw DeviceError("a sharded build takes at most 255 ranks (junction and field owners are bytes)");
     Impl& m = *impl_;
     m.t0 = now_s();
     if (n_frags_total == 0 || n_frags_total >= 0xFFFFFFF0ULL) throw DeviceError("invalid fragment count");
@@ -2547,45 +2562,57 @@ void GraphBuilder::build_union_impl(uint32_t rank, uint32_t n_shards, const uint
     m.n_owners = n_shards; m.my_owner = rank;      // this rank's table holds the k-mers whose home hash it owns
     AC_DISPATCH_W(table, (*impl_))
 }
-uint64_t GraphBuilder::bitmap_words() const { return impl_->uni.n_text / 64 + 2; }
+// The bit planes a rank contributes after its insert: the novel bitmap (1 bit per union-text position) and — round 5 — the sibling bits
+// of the k-mers it owns (2 bits per position, at the position the slot ended up holding: MarkFunctor).  A position's k-mer has one owner,
+// so the ranks' planes are disjoint and one SUM all-reduce completes both.
+uint64_t GraphBuilder::bitmap_words() const { return (impl_->uni.n_text / 64 + 2) + impl_->sib.size(); }
 void GraphBuilder::bitmap_export(void* d_out) {      // this rank's novel bits (disjoint from every other rank's: the owners partition the keys)
-    copy_d2d(d_out, impl_->bm.ptr(), bitmap_words() * 8);
+    const u64 w1 = impl_->uni.n_text / 64 + 2;
+    copy_d2d(d_out, impl_->bm.ptr(), w1 * 8);
+    if (impl_->sib.size()) copy_d2d((u64*)d_out + w1, impl_->sib.ptr(), impl_->sib.size() * 8);
     stream_sync();
 }
 void GraphBuilder::shard_build_novel(const void* d_bitmap_sum) {
     Impl& m = *impl_;
     m.t0 = now_s();
-    if (d_bitmap_sum) copy_d2d(m.bm.ptr(), d_bitmap_sum, bitmap_words() * 8);
-    else if (m.n_owners > 1) throw DeviceError("the novel bitmaps of the other ranks are missing");
-    m.novel_list(0);
+    const u64 w1 = m.uni.n_text / 64 + 2;
+    if (d_bitmap_sum) {
+        copy_d2d(m.bm.ptr(), d_bitmap_sum, w1 * 8);
+        if (m.sib.size()) copy_d2d(m.sib.ptr(), (const u64*)d_bitmap_sum + w1, m.sib.size() * 8);
+    } else if (m.n_owners > 1) throw DeviceError("the novel bitmaps of the other ranks are missing");
+    if (m.n_owners > 1) m.novel_list(0);      // (one owner: table() has made the list already)
     AC_DISPATCH_W(degrees, (*impl_))
 }
 uint64_t GraphBuilder::distinct_count() const { return impl_->N; }
 void GraphBuilder::degrees_export(void* d_out) {      // one byte per k-mer: [first(rc T):1][first(T):1][in:3][out:3]
     Impl& m = *impl_;
-    launch(m.N, KinfoPackFunctor{m.kinfo.ptr(), (u8*)d_out});
+    launch(m.N, KinfoPackFunctor{m.kcontrib.size() ? m.kcontrib.ptr() : m.kinfo.ptr(), (u8*)d_out});      // (with the light degree step: the contributions only)
     stream_sync();
 }
 void GraphBuilder::shard_build_graph(const void* d_kinfo_sum) {
     Impl& m = *impl_;
     m.t0 = now_s();
-    if (d_kinfo_sum) launch(m.N, KinfoUnpackFunctor{(const u8*)d_kinfo_sum, m.kinfo.ptr(), m.counters.ptr() + 3});
+    if (d_kinfo_sum) launch(m.N, KinfoUnpackFunctor{(const u8*)d_kinfo_sum, m.kinfo.ptr(), m.counters.ptr() + 3, m.kcontrib.size() != 0});
     else if (m.n_owners > 1) throw DeviceError("the degree words of the other ranks are missing");
+    else if (m.kcontrib.size()) throw DeviceError("internal error: degree contributions without a sum");
+    m.kcontrib = DBuf<u32>();
     AC_DISPATCH_W(unitigs, (*impl_))
 }
 void GraphBuilder::links_export(void* d_links_i32, void* d_wlinks_i64) {
     Impl& m = *impl_;
     copy_d2d(d_links_i32, m.links.ptr(), (size_t)m.U * 10 * 4);
-    copy_d2d(d_wlinks_i64, m.wlinks.ptr(), (size_t)m.U * 10 * 8);
+    if (d_wlinks_i64) copy_d2d(d_wlinks_i64, m.wlinks.ptr(), (size_t)m.U * 10 * 8);      // (optional: the walk words follow from the link words)
     stream_sync();
 }
 void GraphBuilder::links_import(const void* d_links_i32, const void* d_wlinks_i64) {
     Impl& m = *impl_;
     m.t0 = now_s();
-    if (d_links_i32 && d_wlinks_i64) {
+    if (d_links_i32) {
+        // the walk words are a function of the link words and the unitig lengths every rank holds: only the 40 bytes of link words per
+        // unitig cross between the ranks, not the 80 bytes of walk words as well (round 5)
         copy_d2d(m.links.ptr(), d_links_i32, (size_t)m.U * 10 * 4);
-        copy_d2d(m.wlinks.ptr(), d_wlinks_i64, (size_t)m.U * 10 * 8);
-        launch((u64)m.U * 10, LinkSumCheckFunctor{m.links.ptr(), m.U, m.counters.ptr() + 3});
+        if (d_wlinks_i64) copy_d2d(m.wlinks.ptr(), d_wlinks_i64, (size_t)m.U * 10 * 8);
+        launch((u64)m.U * 10, LinkSumCheckFunctor{m.links.ptr(), m.U, m.counters.ptr() + 3, d_wlinks_i64 ? nullptr : m.wlinks.ptr(), m.ulen.ptr()});
     } else if (m.n_owners > 1) throw DeviceError("the link words of the other ranks are missing");
     AC_DISPATCH_W(walk_queries, (*impl_))
 }
@@ -2634,10 +2661,14 @@ void GraphBuilder::reduce_import(const int32_t* d_sum, const int32_t* d_min) {
 void GraphBuilder::set_tail_exchange(std::function<void(void*, uint64_t, int, int)> all_reduce) { impl_->tail_xchg = std::move(all_reduce); }
 void GraphBuilder::shard_finish(FinalGraph* out, bool want_graph, bool want_paths) {
     impl_->t0 = now_s();
+    // a rank that keeps the paths of its own sequences lets the host give them their final numbers, like a single-device build (round 5:
+    // PathRemapJob — the entries cross PCIe under the tail instead of behind it); the device copy then stays in seed numbers
+    impl_->host_remap_allowed = want_paths && shard_host_remap();
     AC_DISPATCH_W(tail, (*impl_, out, want_graph, want_paths))
 }
 uint64_t GraphBuilder::path_entry_count() const { return impl_->n_ent; }
 void GraphBuilder::paths_export(void* d_out) {
+    if (impl_->paths_in_seed_numbers) throw DeviceError("paths_export: this rank kept its own paths (they were renumbered on the host)");
     copy_d2d(d_out, impl_->ent_val.ptr(), impl_->n_ent * 4);
     stream_sync();
 }

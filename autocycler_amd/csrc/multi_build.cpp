@@ -4,9 +4,9 @@
 // shard_begin .. shard_finish); what used to be the caller's job — the collectives between them — happens here:
 //
 //   fragments + records     all-gather (variable sizes), straight into their places in the union text / record table
-//   novel bitmaps           all-reduce SUM (uint64; the owners partition the keys: disjoint bits)
-//   degree bytes            all-reduce SUM (uint8)
-//   link words              all-reduce SUM (int32, int64)
+//   novel bitmaps + sibling bits   all-reduce SUM (uint64; the owners partition the keys: disjoint bits; 3 bits per union-text position)
+//   degree bytes            all-reduce SUM (uint8): what the owners' probes found for the 1-3 % of the k-mers the sibling bits do not settle
+//   link words              all-reduce SUM (int32; the walk words are derived from them on arrival)
 //   walk-start keys         ROUTED BY OWNER: every rank sorts its queries by owner = home hash mod N (queries_route) and one all-to-all
 //   + their answers         sends each key to the one rank whose table can answer it; the answers come back by the reverse all-to-all —
 //                           a rank receives ~1/N of the keys instead of all of them (north_star's bucket exchange)
@@ -348,10 +348,10 @@ void rank_main(Shared& S, int rank) {
     const uint64_t U = b.unitig_count();
     {
         const Arena::Mark mk = rc.xarena.mark();
-        void* lk = xalloc(U * 10 * 4); void* wl = xalloc(U * 10 * 8);
-        b.links_export(lk, wl);
-        timed([&] { X.all_reduce(rank, lk, U * 10, X_I32, X_SUM); X.all_reduce(rank, wl, U * 10, X_I64, X_SUM); });
-        b.links_import(lk, wl);
+        void* lk = xalloc(U * 10 * 4);      // (the walk words follow from these: links_import derives them — 40 instead of 120 bytes per unitig cross)
+        b.links_export(lk, nullptr);
+        timed([&] { X.all_reduce(rank, lk, U * 10, X_I32, X_SUM); });
+        b.links_import(lk, nullptr);
         rc.xarena.rewind(mk);
     }
 
@@ -416,7 +416,7 @@ void rank_main(Shared& S, int rank) {
         st.bytes_fragments += others_frag;
         st.bytes_bitmap += b.bitmap_words() * 8 * (uint64_t)(R - 1) / (uint64_t)R * 2;      // reduce-scatter + all-gather of an all-reduce: 2 (R - 1) / R of the buffer per rank
         st.bytes_degrees += N * (uint64_t)(R - 1) / (uint64_t)R * 2;
-        st.bytes_links += U * 120 * (uint64_t)(R - 1) / (uint64_t)R * 2;
+        st.bytes_links += U * 40 * (uint64_t)(R - 1) / (uint64_t)R * 2;
         st.bytes_reduce += U * 20 * (uint64_t)(R - 1) / (uint64_t)R * 2;
         st.bytes_queries += q_recv_total * kw * 8; st.bytes_answers += sent_away * 8;
         st.queries_total += nq; st.queries_sent_away += sent_away;
@@ -471,6 +471,24 @@ void build_multi(uint32_t k, uint32_t assembly_count, const std::vector<SeqView>
         }
     }
     for (int r = 0; r < R; r++) if (S.first[r + 1] <= S.first[r]) throw DeviceError("internal error: a rank of the multi-device build got no sequence");
+    // One device (or one sequence): there is nothing to exchange and nobody to dedup against — the job IS a single-device build, and it
+    // takes that path (round 5: the protocol at world size 1 cost 1.7x the build it stands for).  A transport named explicitly
+    // (AC_MULTI_TRANSPORT: the device suite's RCCL-in-a-world-of-one tests) still runs every phase and every collective.
+    if (R == 1 && transport == MULTI_AUTO) {
+        select_device_checked(devices[0]);
+        GraphBuilder b(k);
+        b.set_sequences_host(seqs);
+        b.build(assembly_count, out);
+        *tm = b.timings();
+        MultiStats st;
+        st.n_ranks = 1; st.transport = MULTI_DIRECT;
+        st.table_capacity_max = st.table_capacity_sum = tm->table_capacity;
+        st.distinct = tm->n_distinct;
+        st.candidates_total = st.candidates_owned_max = tm->n_candidates;
+        st.seconds_total = now_s() - t_begin;
+        if (st_out) *st_out = st;
+        return;
+    }
     [[maybe_unused]] bool distinct = true;
     for (int a = 0; a < R; a++) for (int c = a + 1; c < R; c++) if (devices[a] == devices[c]) distinct = false;
 #ifdef AC_EMU

@@ -11,11 +11,11 @@
 
 namespace ac {
 
-enum MultiTransport { MULTI_AUTO = 0, MULTI_HOST_STAGED = 1, MULTI_RCCL = 2 };
+enum MultiTransport { MULTI_AUTO = 0, MULTI_HOST_STAGED = 1, MULTI_RCCL = 2, MULTI_DIRECT = 3 };      // DIRECT: one rank, built as a single-device job (no protocol)
 
 struct MultiStats {
     uint32_t n_ranks = 0;
-    int transport = 0;                      // MULTI_HOST_STAGED or MULTI_RCCL: what ran
+    int transport = 0;                      // MULTI_HOST_STAGED, MULTI_RCCL or MULTI_DIRECT: what ran
     // bytes this build moved between ranks, summed over all ranks (what every rank RECEIVED from others)
     uint64_t bytes_fragments = 0, bytes_bitmap = 0, bytes_degrees = 0, bytes_links = 0, bytes_queries = 0, bytes_answers = 0, bytes_reduce = 0;
     uint64_t queries_total = 0, queries_sent_away = 0;      // walk-start queries of all ranks / those answered by another rank

@@ -9,11 +9,12 @@ the GPU box, "gloo" in the CPU test-suite):
       all-gather            fragment text (2-bit codes) + 8-byte records of every rank  (∝ distinct content, not ∝ input; 0.25 B per base)
     ac_shard_build_union    this rank inserts the union-text k-mers it OWNS (owner = hash of the canonical middle mod world):
                             a table of ~1/world of the job's k-mers
-      all-reduce SUM        the ranks' novel bitmaps (disjoint)                     (1 bit per union-text position)
-    ac_shard_build_novel    novel list; degrees + first flags of all novel k-mers, probing owned groups only
-      all-reduce SUM        degree bytes                                            (1 B per distinct k-mer)
+      all-reduce SUM        the ranks' novel bitmaps + sibling bits (disjoint)      (3 bits per union-text position)
+    ac_shard_build_novel    novel list; degrees: what the sibling bits settle is settled on every rank alike, the rest (1-3 %) and the
+                            first flags by probing owned groups only
+      all-reduce SUM        the probes' contributions                               (1 B per distinct k-mer, zero for the settled ones)
     ac_shard_build_graph    unitigs (identical everywhere); links, probing owned groups only
-      all-reduce SUM        link words                                              (120 B per unitig)
+      all-reduce SUM        link words                                              (40 B per unitig; the walk words are derived on arrival)
     ac_shard_links_import   the keys this rank's path walkers start from
     ac_shard_queries_route  ... ordered by owner rank
       all-to-all            each key to the ONE rank whose table holds it; ac_shard_answer looks them up   (~1/world of the keys per rank)
@@ -155,12 +156,26 @@ def _check(lib, rc):
         raise _capi.AutocyclerError(lib.ac_last_error().decode(errors="replace"))
 
 
-def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False, partition_tail=True):
+def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False, partition_tail=True, direct_when_alone=True):
     """Runs one sharded compress build.  Returns (Graph, info).  On `root` the Graph holds unitigs, links and
     statistics; every rank's Graph holds the paths of its own sequences (Graph.gfa(parts=2) -> its P lines), unless
     gather_paths: then root's Graph holds the paths of ALL sequences (Graph.gfa() is the whole file) and the other
-    ranks keep statistics only."""
+    ranks keep statistics only.
+
+    direct_when_alone: a world of ONE rank has nobody to exchange with or to dedup against — the job is a single-device build and
+    takes that entry (ac_compress_build_device: no fragments, no union text, no second insert; round 5 — the protocol at world size 1
+    cost 1.7x the build it stands for).  False runs every phase of the protocol anyway (the test-suite's coverage of it)."""
     dev = comm.device
+    if comm.local_only and direct_when_alone:
+        g = C.c_void_p()
+        _check(lib, lib.ac_compress_build_device(C.c_uint32(shard.k), C.c_uint32(shard.local_assembly_count), C.c_void_p(shard.d_text.data_ptr()),
+                                                 C.c_uint64(shard.n_text), shard.off, shard.lens, shard.ids, shard.d1, shard.d2,
+                                                 C.c_uint32(shard.n_seqs), C.c_int(device_index), C.byref(g)))
+        graph = _capi.Graph(lib, g, shard.n_seqs)
+        tmg = graph.timings()
+        return graph, {"fragments": 0, "union_text_bytes": 0, "distinct": tmg["n_distinct"], "unitigs": graph.stats_post["unitigs"], "comm_s": 0.0,
+                       "table_capacity": tmg["table_capacity"], "walk_queries": 0, "walk_queries_sent_away": 0,
+                       "candidates": tmg["n_candidates"], "candidates_owned": tmg["n_candidates"], "direct": True}
     h = C.c_void_p()
     _check(lib, lib.ac_shard_begin(C.c_uint32(shard.k), C.c_uint32(shard.local_assembly_count), C.c_void_p(shard.d_text.data_ptr()),
                                    C.c_uint64(shard.n_text), shard.off, shard.lens, shard.ids, shard.d1, shard.d2,
@@ -218,12 +233,10 @@ def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False, 
             _check(lib, lib.ac_shard_links_import(h, None, None))
         else:
             lk = torch.empty(10 * U, dtype=torch.int32, device=dev)
-            wl = torch.empty(10 * U, dtype=torch.int64, device=dev)
-            _check(lib, lib.ac_shard_links_export(h, ptr(lk), ptr(wl)))
+            _check(lib, lib.ac_shard_links_export(h, ptr(lk), None))      # (the walk words follow from the link words on arrival: 40 B per unitig cross, not 120)
             comm.all_reduce(lk, "SUM")
-            comm.all_reduce(wl, "SUM")
-            _check(lib, lib.ac_shard_links_import(h, ptr(lk), ptr(wl)))
-            del lk, wl
+            _check(lib, lib.ac_shard_links_import(h, ptr(lk), None))
+            del lk
         # where this rank's walkers start: every key goes to the ONE rank that owns it (all-to-all), the answers come back the same way
         nq = lib.ac_shard_query_count(h)
         kw = lib.ac_shard_query_key_words(h)

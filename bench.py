@@ -175,6 +175,9 @@ def main():
     ap.add_argument("--species", choices=["per-gpu", "one"], default="per-gpu",
                     help="sharded mode at N > 1: one species per GPU (mixed-species job, fixed work and output per GPU) or all "
                          "N x A assemblies of one species (path output grows with N^2)")
+    ap.add_argument("--protocol-always", action="store_true",
+                    help="sharded mode at N = 1: run every phase of the N-rank protocol (fragments, union text, second insert, ...) instead of handing "
+                         "the job to the single-device build — what the protocol itself costs before a byte moves")
     ap.add_argument("--gather-paths", action="store_true",
                     help="sharded mode: gather the paths of all sequences to rank 0 (default: every rank keeps its own P lines)")
     args = ap.parse_args()
@@ -286,7 +289,7 @@ def main():
     def step():
         if shard is not None:
             g, info = sharded.sharded_build(lib, shard, sharded.Comm(dev), device_index=local_rank, root=0,
-                                            gather_paths=args.gather_paths)
+                                            gather_paths=args.gather_paths, direct_when_alone=not args.protocol_always)
             last_info.update(info)
             return g
         h = C.c_void_p()

@@ -34,7 +34,7 @@ def local_shard(lib, k, loaded, lo, hi, assembly_count, device):
                               [q["id"] for q in part], list(d1), list(d2))
 
 
-def run_case(lib_path, k, seqs, filenames, headers, comm, device, repair=True, device_index=0, gather_paths=True):
+def run_case(lib_path, k, seqs, filenames, headers, comm, device, repair=True, device_index=0, gather_paths=True, direct_when_alone=False):
     """All ranks call this with the same inputs.  Returns the whole GFA text on the root, None elsewhere.
     gather_paths=False: every rank keeps the P lines of its own sequences; the test stitches the parts together."""
     lib = _capi.load_library(lib_path)
@@ -45,7 +45,8 @@ def run_case(lib_path, k, seqs, filenames, headers, comm, device, repair=True, d
     assert hi > lo, "fewer sequences than ranks"
     local_assemblies = max(1, len({q["filename"] for q in loaded[lo:hi]}))
     shard = local_shard(lib, k, loaded, lo, hi, local_assemblies, device)
-    g, info = sharded.sharded_build(lib, shard, comm, device_index=device_index, root=0, gather_paths=gather_paths)
+    # (direct_when_alone=False: a world of one rank still runs every phase of the protocol — that is what these tests are for)
+    g, info = sharded.sharded_build(lib, shard, comm, device_index=device_index, root=0, gather_paths=gather_paths, direct_when_alone=direct_when_alone)
     assert g.stats_post["unitigs"] == info["unitigs"]
     # the tail is partitioned: a rank runs the junctions of its own conflict components only (about 1 / world of them)
     # (whole components: a small graph whose largest component is a good part of it balances less well)

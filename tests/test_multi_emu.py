@@ -30,7 +30,7 @@ def test_fixed_seqs_more_ranks_than_sequences(emu, k):
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
-def test_synthetic_and_mixed_species_jobs(emu, world):
+def test_synthetic_and_mixed_species_jobs(emu, world, monkeypatch):
     seqs, fn, hd = M.synth_case(9, 30_000, 2_000, 1e-3, 1e-4, 11)
     gfa1, _ = M.run_case(emu, 51, seqs, fn, hd, [0])
     gfa, info = M.run_case(emu, 51, seqs, fn, hd, [0] * world)
@@ -39,7 +39,10 @@ def test_synthetic_and_mixed_species_jobs(emu, world):
     seqs, fn, hd = M.mixed_case(world, 3, 12_000)
     gfa, info = M.run_case(emu, 21, seqs, fn, hd, [0] * world)
     # the table is partitioned: every rank's share is well below the whole job's table, and the shares add up to about one table
+    monkeypatch.setenv("AC_MULTI_TRANSPORT", "host")      # (a named transport: one rank runs the protocol too — its table is sized the way the ranks' shares are)
     _, one = M.run_case(emu, 21, seqs, fn, hd, [0])
+    monkeypatch.delenv("AC_MULTI_TRANSPORT")
+    assert one["transport"] == 1
     assert info["table_capacity_max"] * world <= 4 * one["table_capacity_max"] and info["table_capacity_max"] < one["table_capacity_max"] or world == 1
     # owner routing: a rank's queries go to the rank that owns them — about (world - 1) / world of them leave, none is broadcast
     assert info["queries_sent_away"] <= info["queries_total"]
@@ -101,3 +104,34 @@ def _capi_lib(emu):
 def test_whole_command_over_several_ranks(emu, tmp_path, world):
     import boundary_cases as B
     B.compress_dir_multi_matches_the_oracle(_capi_lib(emu), tmp_path, 13, [0] * world)
+
+
+def test_one_device_is_a_single_device_build(emu, monkeypatch):
+    """Round 5: ac_compress_build_multi over ONE device has nobody to exchange with — it takes the single-device build (transport 3 =
+    direct); naming a transport keeps every phase of the protocol (what the device suite's RCCL-in-a-world-of-one tests rely on)."""
+    seqs, fn, hd = M.synth_case(6, 30_000, 2_000, 1e-3, 1e-4, 3)
+    gfa_d, direct = M.run_case(emu, 51, seqs, fn, hd, [0])
+    assert direct["transport"] == 3 and direct["n_ranks"] == 1 and direct["fragments"] == 0 and direct["bytes_links"] == 0
+    monkeypatch.setenv("AC_MULTI_TRANSPORT", "host")
+    gfa_p, proto = M.run_case(emu, 51, seqs, fn, hd, [0])
+    assert gfa_p == gfa_d and proto["transport"] == 1 and proto["fragments"] > 0
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_round5_protocol_knobs(emu, world, monkeypatch):
+    """The three things round 5 gave the N-rank protocol, each switched off again: the sibling bits travelling with the novel bitmap and
+    the probe-free degree step (AC_SHARD_DEGREE_FLAGS=0: every degree by probing, a full byte per k-mer), the host-side renumbering of a
+    rank's own paths (AC_SHARD_HOST_REMAP=0).  Same graph either way; the bitmap exchange carries three planes instead of one."""
+    for seqs, fn, hd, k in (M.synth_case(8, 40_000, 2_000, 1e-3, 1e-4, 7) + (51,), M.mixed_case(3, 3, 20_000) + (21,)):
+        gfa, info = M.run_case(emu, k, seqs, fn, hd, [0] * world)
+        monkeypatch.setenv("AC_SHARD_DEGREE_FLAGS", "0")
+        gfa_probe, info_probe = M.run_case(emu, k, seqs, fn, hd, [0] * world)
+        monkeypatch.delenv("AC_SHARD_DEGREE_FLAGS")
+        monkeypatch.setenv("AC_SHARD_HOST_REMAP", "0")
+        gfa_dev, _ = M.run_case(emu, k, seqs, fn, hd, [0] * world)
+        monkeypatch.delenv("AC_SHARD_HOST_REMAP")
+        assert gfa == gfa_probe == gfa_dev
+        assert 2.5 * info_probe["bytes_bitmap"] <= info["bytes_bitmap"] <= 3.0 * info_probe["bytes_bitmap"] + 64
+        assert info["bytes_links"] * 3 == info_probe["bytes_links"] * 3      # (40 B per unitig either way since the walk words stay at home)
+    M.adversarial(emu, [0] * world, ks=(11, 51), seeds=range(6))
+

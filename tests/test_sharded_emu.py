@@ -40,6 +40,15 @@ def test_single_rank_adversarial(emu, k):
             sharded_util.run_case(emu, k, seqs, fn, hd, comm, torch.device("cpu"), repair=repair)
 
 
+def test_single_rank_takes_the_single_device_build(emu):
+    # round 5: a world of one rank has nobody to exchange with — sharded_build() hands the job to the single-device entry
+    comm = sharded.Comm(torch.device("cpu"))
+    for seed in (1, 5, 9):
+        seqs, fn, hd = seqgen.make_case(seed, 11)
+        assert sharded_util.run_case(emu, 11, seqs, fn, hd, comm, torch.device("cpu"), direct_when_alone=True) == \
+            sharded_util.run_case(emu, 11, seqs, fn, hd, comm, torch.device("cpu"), direct_when_alone=False)
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return str(p)

@@ -44,7 +44,8 @@ class Timings(C.Structure):
                 ("analysis", C.c_double), ("finalize", C.c_double), ("n_candidates", C.c_uint32), ("n_levels", C.c_uint32),
                 ("fragments", C.c_double), ("union_pack", C.c_double), ("union_insert", C.c_double),
                 ("n_local_distinct", C.c_uint64), ("n_fragments", C.c_uint64), ("fragment_bytes", C.c_uint64),
-                ("upload_device_ms", C.c_double), ("path_runs_copied", C.c_uint64), ("path_entries_walked", C.c_uint64), ("position_retries", C.c_uint64), ("n_candidates_owned", C.c_uint32)]
+                ("upload_device_ms", C.c_double), ("path_runs_copied", C.c_uint64), ("path_entries_walked", C.c_uint64), ("position_retries", C.c_uint64), ("n_candidates_owned", C.c_uint32),
+                ("launches", C.c_uint32), ("readbacks", C.c_uint32), ("n_degrees_open", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -55,9 +56,10 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,
 EXPORTS = ["ac_compress_build", "ac_compress_build_multi", "ac_multi_info_get", "ac_compress_build_device", "ac_pack_text", "ac_text_size", "ac_layout_text", "ac_kmer_count",
            "ac_stats_pre", "ac_stats_post", "ac_unitig_count", "ac_unitig", "ac_unitigs_bulk", "ac_paths_bulk", "ac_unitig_positions", "ac_links",
            "ac_path", "ac_timings_get", "ac_timings_get_sized", "ac_free", "ac_gfa_string", "ac_string_free", "ac_last_error",
-           "ac_device_count", "ac_max_kmer", "ac_version", "ac_source_hash", "ac_set_stage_timing", "ac_random_access_ceilings", "ac_random_access_ceilings_at", "ac_release_memory", "ac_end_repair_device", "ac_pairwise_distances", "ac_graph_from_gfa", "ac_graph_kmer_size", "ac_graph_seq_info", "ac_decompress_seq", "ac_decompress",
+           "ac_device_count", "ac_max_kmer", "ac_version", "ac_source_hash", "ac_set_stage_timing", "ac_random_access_ceilings", "ac_random_access_ceilings_at", "ac_release_memory", "ac_end_repair_device", "ac_pairwise_distances", "ac_verify_graph", "ac_verify_graph_device", "ac_graph_from_gfa", "ac_graph_kmer_size", "ac_graph_seq_info", "ac_decompress_seq", "ac_decompress",
            "ac_shard_begin", "ac_shard_fragment_sizes", "ac_shard_fragments_export", "ac_shard_build_union", "ac_shard_fragment_packed_words", "ac_shard_fragments_export_packed", "ac_shard_build_union_packed",
-           "ac_shard_unitig_count", "ac_shard_table_capacity", "ac_shard_bitmap_words", "ac_shard_bitmap_export", "ac_shard_build_novel", "ac_shard_links_export", "ac_shard_links_import",
+           "ac_shard_unitig_count", "ac_shard_table_capacity", "ac_shard_bitmap_words", "ac_shard_bitmap_export", "ac_shard_build_novel", "ac_shard_sib_words", "ac_shard_sib_export", "ac_shard_degrees",
+           "ac_shard_degree_bytes", "ac_multi_info_get_sized", "ac_shard_links_export", "ac_shard_links_import",
            "ac_shard_query_count", "ac_shard_query_key_words", "ac_shard_queries_export", "ac_shard_answer", "ac_shard_walk", "ac_shard_queries_route", "ac_shard_walk_routed", "ac_shard_local_distinct", "ac_shard_set_distinct_upper_bound", "ac_shard_distinct_count", "ac_shard_degrees_export", "ac_shard_build_graph", "ac_gfa_string_parts", "ac_shard_reduce_export", "ac_shard_reduce_import", "ac_shard_finish", "ac_shard_set_allreduce", "ac_device_copy",
            "ac_shard_path_entries", "ac_shard_paths_export", "ac_shard_free", "ac_graph_set_paths", "ac_graph_seq_count", "ac_path_counts",
            "ac_seqs_load", "ac_seqs_from_raw", "ac_seqs_count", "ac_seqs_assembly_count", "ac_seqs_views", "ac_seqs_get",
@@ -116,7 +118,7 @@ def load_library(path=None):
     lib.ac_shard_path_entries.restype = C.c_uint64
     lib.ac_shard_path_entries.argtypes = [C.c_void_p]
     lib.ac_shard_free.argtypes = [C.c_void_p]
-    for name in ("ac_shard_table_capacity", "ac_shard_bitmap_words", "ac_shard_query_count"):
+    for name in ("ac_shard_table_capacity", "ac_shard_bitmap_words", "ac_shard_query_count", "ac_shard_sib_words", "ac_shard_degree_bytes"):
         getattr(lib, name).restype = C.c_uint64
         getattr(lib, name).argtypes = [C.c_void_p]
     lib.ac_shard_query_key_words.restype = C.c_uint32
@@ -231,6 +233,28 @@ class Graph:
         _check(self._lib, self._lib.ac_pairwise_distances(self._h, C.c_int(device), out))
         return [[out[a * S + b] for b in range(S)] for a in range(S)]
 
+    def verify(self, seqs, device=0):
+        """ac_verify_graph: the round-trip verifier on the device (decompress identity, check_links, depth, renumber order, statistics).
+        seqs: [(padded forward bytes, unpadded length, id)] as for compress_build.  Returns the report as a dict; report["failed"] == 0
+        means the graph holds."""
+        n = len(seqs)
+        views = (SeqView * n)()
+        keep = []
+        for i, (fwd, length, sid) in enumerate(seqs):
+            b = bytes(fwd); keep.append(b)
+            views[i].fwd, views[i].length, views[i].id = b, length, sid
+        rep = VerifyReport()
+        _check(self._lib, self._lib.ac_verify_graph(self._h, views, C.c_uint32(n), C.c_int(device), C.byref(rep)))
+        return rep.as_dict()
+
+    def verify_device(self, d_text_ptr, n_text, off, lens, device=0):
+        """The same against a text resident on the device (off / lens: ctypes arrays or sequences)."""
+        n = len(lens)
+        rep = VerifyReport()
+        _check(self._lib, self._lib.ac_verify_graph_device(self._h, C.c_void_p(d_text_ptr), C.c_uint64(n_text), (C.c_uint64 * n)(*list(off)),
+                                                           (C.c_uint32 * n)(*list(lens)), C.c_uint32(n), C.c_int(device), C.byref(rep)))
+        return rep.as_dict()
+
     def timings(self):
         t = Timings()
         _check(self._lib, self._lib.ac_timings_get(self._h, C.byref(t)))
@@ -264,12 +288,22 @@ def graph_from_gfa(gfa_text, lib_path=None):
     return g, fns, hds
 
 
+class VerifyReport(C.Structure):
+    _fields_ = [("failed", C.c_uint32)] + [(n, C.c_uint64) for n in ("first_bad_unitig", "first_bad_link", "first_bad_path_entry", "first_bad_sequence",
+                                                                      "first_bad_base", "unitigs", "links", "path_entries", "bases_checked",
+                                                                      "self_mirror_links")] + [("seconds", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 class MultiInfo(C.Structure):
     _fields_ = [("n_ranks", C.c_uint32), ("transport", C.c_int)] + \
                [(n, C.c_uint64) for n in ("bytes_fragments", "bytes_bitmap", "bytes_degrees", "bytes_links", "bytes_queries", "bytes_answers",
                                           "bytes_reduce", "queries_total", "queries_sent_away", "table_capacity_max", "table_capacity_sum",
                                           "union_text_bytes", "fragments", "distinct")] + \
-               [("seconds_total", C.c_double), ("seconds_exchange_max", C.c_double), ("candidates_total", C.c_uint64), ("candidates_owned_max", C.c_uint64)]
+               [("seconds_total", C.c_double), ("seconds_exchange_max", C.c_double), ("candidates_total", C.c_uint64), ("candidates_owned_max", C.c_uint64),
+                ("bytes_sibling", C.c_uint64), ("bytes_tail", C.c_uint64), ("degrees_open", C.c_uint64), ("bytes_received_max", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

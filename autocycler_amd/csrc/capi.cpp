@@ -274,7 +274,15 @@ int ac_multi_info_get(const ac_graph* g, ac_multi_info* o) {
     o->union_text_bytes = m.union_text_bytes; o->fragments = m.fragments; o->distinct = m.distinct;
     o->seconds_total = m.seconds_total; o->seconds_exchange_max = m.seconds_exchange_max;
     o->candidates_total = m.candidates_total; o->candidates_owned_max = m.candidates_owned_max;
+    o->bytes_sibling = m.bytes_sibling; o->bytes_tail = m.bytes_tail; o->degrees_open = m.degrees_open; o->bytes_received_max = m.bytes_received_max;
     return 0;
+}
+size_t ac_multi_info_get_sized(const ac_graph* g, ac_multi_info* out, size_t out_size) {
+    ac_multi_info t;
+    if (!g || !out) { g_err = "null pointer"; return sizeof t; }
+    ac_multi_info_get(g, &t);
+    memcpy(out, &t, out_size < sizeof t ? out_size : sizeof t);
+    return sizeof t;
 }
 
 int ac_compress_build_device(uint32_t k, uint32_t assembly_count, const void* d_text, uint64_t n_text,
@@ -404,6 +412,29 @@ int ac_shard_build_novel(ac_shard* s, const void* d_bitmap_sum_u64) {
         s->phase = 3;
     });
 }
+// round 5: the sibling bits (2 per distinct k-mer, by novel index).  ac_shard_sib_words() > 0 after ac_shard_build_novel: the degree stage
+// waits for their sum — ac_shard_sib_export -> all-reduce SUM (uint64) -> ac_shard_degrees; 0: it has run already.
+uint64_t ac_shard_sib_words(const ac_shard* s) { return s->phase == 3 ? s->b->sib_words() : 0; }
+int ac_shard_sib_export(ac_shard* s, void* d_out_u64) {
+    return guarded([&] {
+        if (s->phase != 3) throw DeviceError("ac_shard_sib_export: wrong phase");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->sib_export(d_out_u64);
+    });
+}
+int ac_shard_degrees(ac_shard* s, const void* d_sib_sum_u64) {
+    return guarded([&] {
+        if (s->phase != 3) throw DeviceError("ac_shard_degrees: wrong phase");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        select_device(s->device);
+        s->b->shard_degrees(d_sib_sum_u64);
+    });
+}
+uint64_t ac_shard_degree_bytes(const ac_shard* s) {
+    if (s->phase != 3) return 0;
+    try { return s->b->degree_bytes(); } catch (const std::exception& e) { g_err = e.what(); return 0; }
+}
 uint64_t ac_shard_distinct_count(const ac_shard* s) { return s->b->distinct_count(); }
 uint64_t ac_shard_table_capacity(const ac_shard* s) { return s->b->timings().table_capacity; }
 int ac_shard_degrees_export(ac_shard* s, void* d_out_u32) {
@@ -417,7 +448,7 @@ int ac_shard_degrees_export(ac_shard* s, void* d_out_u32) {
 int ac_shard_build_graph(ac_shard* s, const void* d_degrees_sum_u32) {
     return guarded([&] {
         if (s->phase != 3) throw DeviceError("ac_shard_build_graph: wrong phase");
-        if (!d_degrees_sum_u32 && s->n_shards > 1) throw DeviceError("ac_shard_build_graph: the summed degree words are required when there are several shards");
+        if (!d_degrees_sum_u32 && s->n_shards > 1) throw DeviceError("ac_shard_build_graph: the summed degree bytes are required when there are several shards");
         std::lock_guard<std::mutex> lock(g_build_mutex);
         select_device(s->device);
         s->b->shard_build_graph(d_degrees_sum_u32);
@@ -663,6 +694,61 @@ int ac_decompress_seq(const ac_graph* g, uint32_t seq_index, uint8_t* out) {
     });
 }
 
+// ---- the round-trip verifier behind the ABI (kernels_verify.inc) ------------------------------------------------------------------
+static void fill_report(const VerifyReport& r, ac_verify_report* o) {
+    memset(o, 0, sizeof *o);
+    o->failed = r.failed;
+    o->first_bad_unitig = r.first_bad_unitig; o->first_bad_link = r.first_bad_link; o->first_bad_path_entry = r.first_bad_path_entry;
+    o->first_bad_sequence = r.first_bad_sequence; o->first_bad_base = r.first_bad_base;
+    o->unitigs = r.unitigs; o->links = r.links; o->path_entries = r.path_entries; o->bases_checked = r.bases_checked;
+    o->self_mirror_links = r.self_mirror_links; o->seconds = r.seconds;
+}
+int ac_verify_graph_device(const ac_graph* g, const void* d_text, uint64_t n_text, const uint64_t* seq_off, const uint32_t* seq_len,
+                           uint32_t n_seqs, int device, ac_verify_report* report) {
+    return guarded([&] {
+        if (!g || !d_text || !seq_off || !seq_len || !report) throw DeviceError("null pointer");
+        if (!g->host_arrays || !g->host_paths) throw DeviceError("this rank kept no host arrays (sharded build, not the writing rank)");
+        if (n_seqs != g->seq_lens.size()) throw DeviceError("ac_verify_graph: the graph was built from " + std::to_string(g->seq_lens.size()) + " sequences, not " + std::to_string(n_seqs));
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
+        select_device(device);
+        std::vector<uint64_t> off(seq_off, seq_off + n_seqs);
+        std::vector<uint32_t> len(seq_len, seq_len + n_seqs);
+        VerifyReport r;
+        verify_graph_device(g->g, (const uint8_t*)d_text, n_text, off, len, &r);
+        fill_report(r, report);
+    });
+}
+int ac_verify_graph(const ac_graph* g, const ac_seq_view* seqs, uint32_t n_seqs, int device, ac_verify_report* report) {
+    return guarded([&] {
+        if (!g || !seqs || !report) throw DeviceError("null pointer");
+        if (!g->host_arrays || !g->host_paths) throw DeviceError("this rank kept no host arrays (sharded build, not the writing rank)");
+        if (n_seqs != g->seq_lens.size()) throw DeviceError("ac_verify_graph: the graph was built from " + std::to_string(g->seq_lens.size()) + " sequences, not " + std::to_string(n_seqs));
+        std::vector<SeqView> v(n_seqs);
+        for (uint32_t i = 0; i < n_seqs; i++) {
+            if (!seqs[i].fwd) throw DeviceError("null sequence");
+            v[i] = SeqView{seqs[i].fwd, seqs[i].length};
+        }
+        std::vector<uint64_t> off; std::vector<uint32_t> len; std::vector<uint16_t> d1, d2;
+        std::vector<uint8_t> text = layout_text(v, g->g.k, &off, &len, &d1, &d2);
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
+        select_device(device);
+        VerifyReport r;
+        // (the text goes up through an allocation of its own: the verifier resets the arena for its working set)
+#ifdef AC_EMU
+        verify_graph_device(g->g, text.data(), text.size(), off, len, &r);
+#else
+        void* d_text = nullptr;
+        AC_HIP_CHECK(hipMalloc(&d_text, text.size() + 64));
+        struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{d_text};
+        AC_HIP_CHECK(hipMemcpy(d_text, text.data(), text.size(), hipMemcpyHostToDevice));
+        verify_graph_device(g->g, (const uint8_t*)d_text, text.size(), off, len, &r);
+#endif
+        fill_report(r, report);
+    });
+}
+
 int ac_random_access_ceilings_at(int device, uint64_t table_slots, double* cas_gops, double* read_gops) {
     return guarded([&] {
         std::lock_guard<std::mutex> lock(g_build_mutex);
@@ -805,6 +891,7 @@ int ac_timings_get(const ac_graph* g, ac_timings* o) {
     o->upload_device_ms = t.upload_device_ms;
     o->path_runs_copied = t.path_runs_copied; o->path_entries_walked = t.path_entries_walked; o->position_retries = t.position_retries;
     o->n_candidates_owned = t.n_candidates_owned;
+    o->launches = t.launches; o->readbacks = t.readbacks; o->n_degrees_open = t.n_degrees_open;
     return 0;
 }
 // The same for a caller that was compiled against another version of the header: at most out_size bytes are written (the struct only

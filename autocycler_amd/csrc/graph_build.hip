@@ -619,7 +619,10 @@ struct GraphBuilder::Impl {
     void occupancy_bitmap(const DBuf<u64>& sl, u64 c, DBuf<u64>* occ_out, const u64* sflags_in, u64* sib_out);
     DBuf<u64> occ;             // slot-occupancy bitmap of the graph table
     DBuf<u64> sib;             // sibling bits of the graph table's real k-mers, two per text position (MarkFunctor); empty = not used
-    DBuf<u32> kcontrib;        // sharded builds with the light degree step: this rank's contributions to kinfo (degrees()); empty = kinfo itself
+    DBuf<u64> sibn; bool sib_pending = false;      // sharded builds: the sibling bits by NOVEL INDEX (SibByRankFunctor) — this rank's, then the ranks' sum; pending = not summed yet
+    // sharded builds with the light degree step: this rank's contributions to the k-mers that step left open, compact (degrees()):
+    // [n_pending degree words | n_first first-flag words]; pend / pidx: which k-mers, and where in that array
+    DBuf<u32> kcontrib, pend, pidx; u64 n_pending = 0, n_first = 0;
     DBuf<u64> endset, endset_bloom; u64 endset_mask = 0;      // sequence-end set (EndSetFunctor) and its two filters
     u32 n_owners = 1, my_owner = 0;      // sharded builds: which slice of the key space the graph table holds (§7)
     // host entry: stream 0 only waited for the FIRST chunk of the packed upload; positions below upload_avail are on the device, the
@@ -941,16 +944,19 @@ template <int W> void GraphBuilder::Impl::table() {
     PackedText& g = *G;
     check_sizes(g);
     // the degree pass's shortcut (sibling bits).  Sharded builds collect them too since round 5: all the k-mers of one middle have one owner,
-    // so an owner's table sees every sibling pair; the bits travel with the novel bitmap (bitmap_export)
+    // so an owner's table sees every sibling pair; the bits cross between the ranks by novel index (sib_export)
     const bool want_sib = k >= 3 && degree_flags() && (n_owners <= 1 || shard_degree_flags());
     insert<W>(g, tm->graph_hint, &slots, &cap, &N, &bm, want_sib);      // sharded builds: only the k-mers this rank owns (N = how many)
     tm->table_capacity = cap;
     tm->n_distinct = N;
     lap(G == &loc ? &tm->insert : &tm->union_insert);
-    // the scan moves the sibling bits the insert left per slot to the text positions the slots ended up holding
-    if (want_sib) { sib.alloc(2 * (g.n_text / 64 + 2)); sib.fill_bytes(0); }
+    // the scan moves the sibling bits the insert left per slot to the text positions the slots ended up holding (a sharded build moves
+    // them to NOVEL INDICES once the ranks' bitmaps are summed: shard_build_novel)
+    const bool sib_by_pos = want_sib && n_owners <= 1;
+    if (sib_by_pos) { sib.alloc(2 * (g.n_text / 64 + 2)); sib.fill_bytes(0); }
     else sib = DBuf<u64>();
-    occupancy_bitmap(slots, cap, &occ, want_sib ? sflags.ptr() : nullptr, want_sib ? sib.ptr() : nullptr);
+    sibn = DBuf<u64>(); sib_pending = false;
+    occupancy_bitmap(slots, cap, &occ, sib_by_pos ? sflags.ptr() : nullptr, sib_by_pos ? sib.ptr() : nullptr);
     if (n_owners <= 1) novel_list(N);      // a sharded build first sums the ranks' (disjoint) bitmaps: bitmap_import
 }
 // K3: novel-position bitmap -> sorted novel list + rank support.  known_n = the number of set bits if the caller knows it (the
@@ -985,10 +991,13 @@ inline void GraphBuilder::Impl::novel_list(u64 known_n) {
 template <int W> void GraphBuilder::Impl::degrees() {
     PackedText& g = *G;
     Table tb = graph_table();
-    kcontrib = DBuf<u32>();
+    Novel nv{bm.ptr(), wprefix.ptr()};
+    kcontrib = DBuf<u32>(); pend = DBuf<u32>(); pidx = DBuf<u32>(); n_pending = n_first = 0;
     u32* kout = kinfo.ptr();      // where probes and first flags add what they find
+    const bool by_index = n_owners > 1 && sibn.size() != 0;      // sharded: the summed sibling bits, by novel index
+    const u64* sib_ptr = by_index ? sibn.ptr() : (sib.size() ? sib.ptr() : nullptr);
     EndSet es{nullptr, 0, nullptr, nullptr};
-    if (sib.size() && g.any_dots) {
+    if (sib_ptr && g.any_dots) {
         // (a sharded build's "sequences" are fragments, most of them without a dot: the set is sized for those that have one)
         endset_mask = next_pow2(4 * (g.has_flags ? g.n_dotted : (u64)g.n_seqs) + 16) - 1;
         endset.alloc((endset_mask + 1) * W);
@@ -998,8 +1007,22 @@ template <int W> void GraphBuilder::Impl::degrees() {
         es = EndSet{endset.ptr(), endset_mask, endset_bloom.ptr(), endset_bloom.ptr() + ENDSET_BLOOM_WORDS};
         launch(2 * (u64)g.n_seqs, EndSetFunctor<W>{g.ctx((int)k), es});
     }
-    if (sib.size() && degree_flags() == 1 && (!g.any_dots || es.keys)) {      // settle what the sibling bits settle, queue the rest, probe the queues
-        if (n_owners > 1) { kcontrib.alloc(N, true); kout = kcontrib.ptr(); }      // (outlives the stage: taken before its mark)
+    const u8* fflags = g.has_flags ? g.seq_flags.ptr() : nullptr;
+    if (sib_ptr && degree_flags() == 1 && (!g.any_dots || es.keys)) {      // settle what the sibling bits settle, queue the rest, probe the queues
+        // Sharded builds (round 5): the light step is the same on every rank (it reads the text and the summed bit planes only) and its
+        // results stay in kinfo; what the probes and the first-flag lookups find is a rank's CONTRIBUTION — only the owner of a probe cluster
+        // finds anything in it — and goes to a COMPACT array: a byte for each of the P k-mers the light step left open (1-3 % of them), in
+        // novel order (the flags the light step raises, scanned: the same on every rank), and a word for each flagged fragment end.  That
+        // array is what degrees_export sends (P + 4 F bytes instead of a byte per distinct k-mer).
+        DBuf<u32> fslot;
+        if (by_index) {
+            pend.alloc(N + 1); pidx.alloc(N + 1);
+            pend.fill_bytes_from(N * 4, 0);
+            fslot.alloc((u64)g.n_seqs + 1);
+            DBuf<u32> fcnt((u64)g.n_seqs + 1);
+            launch((u64)g.n_seqs + 1, FirstSlotCountFunctor{fflags, g.n_seqs, fcnt.ptr()});
+            exclusive_scan_u32(fcnt.ptr(), fslot.ptr(), (u64)g.n_seqs + 1);
+        }
         const Arena::Mark deg_mark = Arena::device().mark();      // the queues below are the stage's own (8 B per distinct k-mer)
         DegWork wk;
         // a k-mer whose window holds dots starts within k - 1 positions of a sequence end: at most 2 (k - 1) per sequence
@@ -1011,26 +1034,41 @@ template <int W> void GraphBuilder::Impl::degrees() {
         counts.fill_bytes(0);
         wk.items = items.ptr(); wk.counts = counts.ptr();
         const u64 n_thr = (((N + DEG_BATCH - 1) / DEG_BATCH) + 63) & ~63ULL;
-        // Sharded builds: the light step is the same on every rank (it reads the text and the summed bitmaps only) and stays in kinfo;
-        // what the probes and the first flags find is a rank's CONTRIBUTION (only the owner of a probe cluster finds anything in it) and goes
-        // to kcontrib, which is what degrees_export sends — a byte per k-mer that is zero for the 97-99 % the light step settled
-        launch_full(n_thr, DegreeLightFunctor<W>{g.ctx((int)k), npos.ptr(), kinfo.ptr(), g.any_dots, bm.ptr(), sib.ptr(), es, wk, N, n_thr});
-        launch((u64)DEG_LISTS * DEG_REGIONS * DEG_PROBE_THREADS, DegreeProbeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kout, g.any_dots, wk, es});
+        launch_full(n_thr, DegreeLightFunctor<W>{g.ctx((int)k), npos.ptr(), kinfo.ptr(), g.any_dots, bm.ptr(), sib_ptr, es, wk, N, n_thr, by_index ? 1 : 0,
+                                                 by_index ? pend.ptr() : nullptr});
+        DBuf<u32> kc_tmp;
+        if (by_index) {
+            exclusive_scan_u32(pend.ptr(), pidx.ptr(), N + 1);
+            u32 hp[2];
+            { ReadBatch rb; rb.add(&hp[0], pidx.ptr() + N, 4); rb.add(&hp[1], fslot.ptr() + g.n_seqs, 4); rb.run(); }
+            n_pending = hp[0]; n_first = hp[1];
+            kc_tmp.alloc(n_pending + n_first + 1); kc_tmp.fill_bytes(0);
+            kout = kc_tmp.ptr();
+        }
+        launch((u64)DEG_LISTS * DEG_REGIONS * DEG_PROBE_THREADS, DegreeProbeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kout, g.any_dots, wk, es, by_index ? pidx.ptr() : nullptr});
 #ifdef AC_EMU
         if (getenv("AC_DEGREE_DIAG")) {
-            u64 c0 = 0, c1 = 0, sx = 0;
+            u64 c0 = 0, c1 = 0;
             for (u32 r = 0; r <= DEG_REGIONS; r++) { c0 += wk.count(0)[r]; c1 += wk.count(1)[r]; }
-            for (u64 w = 0; w < sib.size(); w++) sx += (u64)__builtin_popcountll(sib.ptr()[w]);
-            fprintf(stderr, "degree diag: N %llu, queued real %llu, generic %llu, sibling bits set %llu, any_dots %d\n", (unsigned long long)N,
-                    (unsigned long long)c0, (unsigned long long)c1, (unsigned long long)sx, (int)g.any_dots);
+            fprintf(stderr, "degree diag: N %llu, queued real %llu, generic %llu, left open %llu, any_dots %d\n", (unsigned long long)N,
+                    (unsigned long long)c0, (unsigned long long)c1, (unsigned long long)n_pending, (int)g.any_dots);
         }
 #endif
+        if (by_index) launch(g.n_seqs, FirstFunctor<W>{g.ctx((int)k), tb, nv, kinfo.ptr(), fflags, fslot.ptr(), kc_tmp.ptr() + n_pending});
         items = DBuf<u64>(); counts = DBuf<u32>();
+        const u32* kc_src = kc_tmp.ptr();
+        kc_tmp = DBuf<u32>();
         Arena::device().rewind(deg_mark);
+        if (by_index) {      // the compact array moves to where the queues began (it lay behind them; 4 (P + F) bytes against >= 8 N of queues: no overlap)
+            kcontrib.alloc(n_pending + n_first + 1);
+            if (kcontrib.ptr() != kc_src) copy_d2d(kcontrib.ptr(), kc_src, (n_pending + n_first + 1) * 4);
+            tm->n_degrees_open = n_pending;
+            lap(&tm->degree);
+            return;
+        }
     } else
         launch(N, DegreeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kinfo.ptr(), g.any_dots, 0, bm.ptr(), sib.size() && n_owners <= 1 ? sib.ptr() : nullptr, es});
-    Novel nv{bm.ptr(), wprefix.ptr()};
-    launch(g.n_seqs, FirstFunctor<W>{g.ctx((int)k), tb, nv, kout, g.has_flags ? g.seq_flags.ptr() : nullptr});
+    launch(g.n_seqs, FirstFunctor<W>{g.ctx((int)k), tb, nv, kout, fflags, nullptr, nullptr});
     lap(&tm->degree);
 }
 
@@ -2562,39 +2600,68 @@ void GraphBuilder::build_union_impl(uint32_t rank, uint32_t n_shards, const uint
     m.n_owners = n_shards; m.my_owner = rank;      // this rank's table holds the k-mers whose home hash it owns
     AC_DISPATCH_W(table, (*impl_))
 }
-// The bit planes a rank contributes after its insert: the novel bitmap (1 bit per union-text position) and — round 5 — the sibling bits
-// of the k-mers it owns (2 bits per position, at the position the slot ended up holding: MarkFunctor).  A position's k-mer has one owner,
-// so the ranks' planes are disjoint and one SUM all-reduce completes both.
-uint64_t GraphBuilder::bitmap_words() const { return (impl_->uni.n_text / 64 + 2) + impl_->sib.size(); }
+uint64_t GraphBuilder::bitmap_words() const { return impl_->uni.n_text / 64 + 2; }
 void GraphBuilder::bitmap_export(void* d_out) {      // this rank's novel bits (disjoint from every other rank's: the owners partition the keys)
-    const u64 w1 = impl_->uni.n_text / 64 + 2;
-    copy_d2d(d_out, impl_->bm.ptr(), w1 * 8);
-    if (impl_->sib.size()) copy_d2d((u64*)d_out + w1, impl_->sib.ptr(), impl_->sib.size() * 8);
+    copy_d2d(d_out, impl_->bm.ptr(), bitmap_words() * 8);
     stream_sync();
 }
+// Novel list from the summed bitmap.  With the sibling bits in use (round 5) the degree stage waits for their sum: sib_words() > 0 then,
+// and the caller goes sib_export -> all-reduce SUM -> shard_degrees before degrees_export.  Otherwise the degree stage runs here.
 void GraphBuilder::shard_build_novel(const void* d_bitmap_sum) {
     Impl& m = *impl_;
     m.t0 = now_s();
-    const u64 w1 = m.uni.n_text / 64 + 2;
-    if (d_bitmap_sum) {
-        copy_d2d(m.bm.ptr(), d_bitmap_sum, w1 * 8);
-        if (m.sib.size()) copy_d2d(m.sib.ptr(), (const u64*)d_bitmap_sum + w1, m.sib.size() * 8);
-    } else if (m.n_owners > 1) throw DeviceError("the novel bitmaps of the other ranks are missing");
+    if (d_bitmap_sum) copy_d2d(m.bm.ptr(), d_bitmap_sum, bitmap_words() * 8);
+    else if (m.n_owners > 1) throw DeviceError("the novel bitmaps of the other ranks are missing");
     if (m.n_owners > 1) m.novel_list(0);      // (one owner: table() has made the list already)
+    if (m.n_owners > 1 && m.sflags.size()) {
+        // this rank's sibling bits, two per distinct k-mer, at the novel index of the position their slot ended up holding
+        m.sibn.alloc(2 * (m.N / 64 + 2)); m.sibn.fill_bytes(0);
+        launch(m.cap, SibByRankFunctor{m.slots.ptr(), m.sflags.ptr(), Novel{m.bm.ptr(), m.wprefix.ptr()}, m.sibn.ptr()});
+        m.sib_pending = true;
+        m.lap(&tm_.collect_sort);
+        return;
+    }
+    AC_DISPATCH_W(degrees, (*impl_))
+}
+uint64_t GraphBuilder::sib_words() const { return impl_->sib_pending ? impl_->sibn.size() : 0; }
+void GraphBuilder::sib_export(void* d_out) {
+    if (!impl_->sib_pending) throw DeviceError("sib_export: no sibling bits to exchange");
+    copy_d2d(d_out, impl_->sibn.ptr(), impl_->sibn.size() * 8);
+    stream_sync();
+}
+void GraphBuilder::shard_degrees(const void* d_sib_sum) {
+    Impl& m = *impl_;
+    m.t0 = now_s();
+    if (!m.sib_pending) throw DeviceError("shard_degrees: nothing pending (the degree stage ran in shard_build_novel)");
+    if (!d_sib_sum) throw DeviceError("the sibling bits of the other ranks are missing");
+    copy_d2d(m.sibn.ptr(), d_sib_sum, m.sibn.size() * 8);
+    m.sib_pending = false;
     AC_DISPATCH_W(degrees, (*impl_))
 }
 uint64_t GraphBuilder::distinct_count() const { return impl_->N; }
-void GraphBuilder::degrees_export(void* d_out) {      // one byte per k-mer: [first(rc T):1][first(T):1][in:3][out:3]
+// What the degree exchange moves: one byte per k-mer the light degree step left open + four per flagged fragment end (compact form), or a
+// byte per distinct k-mer: [first(rc T):1][first(T):1][in:3][out:3] (every degree by probing: AC_SHARD_DEGREE_FLAGS=0, k < 3).
+uint64_t GraphBuilder::degree_bytes() const {
+    if (impl_->sib_pending) throw DeviceError("degree_bytes: the degree stage has not run (shard_degrees)");
+    return impl_->kcontrib.size() ? impl_->n_pending + 4 * impl_->n_first : impl_->N;
+}
+void GraphBuilder::degrees_export(void* d_out) {
     Impl& m = *impl_;
-    launch(m.N, KinfoPackFunctor{m.kcontrib.size() ? m.kcontrib.ptr() : m.kinfo.ptr(), (u8*)d_out});      // (with the light degree step: the contributions only)
+    if (m.sib_pending) throw DeviceError("degrees_export: the degree stage has not run (shard_degrees)");
+    if (m.kcontrib.size()) { const u64 nb = degree_bytes(); if (nb) launch(nb, DegPackFunctor{m.kcontrib.ptr(), m.n_pending, m.kcontrib.ptr() + m.n_pending, m.n_first, (u8*)d_out}); }
+    else launch(m.N, KinfoPackFunctor{m.kinfo.ptr(), (u8*)d_out});
     stream_sync();
 }
 void GraphBuilder::shard_build_graph(const void* d_kinfo_sum) {
     Impl& m = *impl_;
     m.t0 = now_s();
-    if (d_kinfo_sum) launch(m.N, KinfoUnpackFunctor{(const u8*)d_kinfo_sum, m.kinfo.ptr(), m.counters.ptr() + 3, m.kcontrib.size() != 0});
+    if (m.sib_pending) throw DeviceError("shard_build_graph: the degree stage has not run (shard_degrees)");
+    if (m.kcontrib.size()) {
+        if (!d_kinfo_sum) throw DeviceError("the degree contributions of the other ranks are missing");
+        launch(m.N, DegUnpackFunctor{(const u8*)d_kinfo_sum, m.pend.ptr(), m.pidx.ptr(), m.kinfo.ptr(), m.counters.ptr() + 3});
+        launch(m.n_first, FirstWordsApplyFunctor{(const u8*)d_kinfo_sum, m.n_pending, m.N, m.kinfo.ptr(), m.counters.ptr() + 3});
+    } else if (d_kinfo_sum) launch(m.N, KinfoUnpackFunctor{(const u8*)d_kinfo_sum, m.kinfo.ptr(), m.counters.ptr() + 3});
     else if (m.n_owners > 1) throw DeviceError("the degree words of the other ranks are missing");
-    else if (m.kcontrib.size()) throw DeviceError("internal error: degree contributions without a sum");
     m.kcontrib = DBuf<u32>();
     AC_DISPATCH_W(unitigs, (*impl_))
 }
@@ -2674,6 +2741,7 @@ void GraphBuilder::paths_export(void* d_out) {
 }
 
 #include "neighbours.inc"      // device end repair (f-1) and pairwise contig distances (f-3)
+#include "kernels_verify.inc"  // ac_verify_graph: the round-trip verifier at scale (f-4)
 #endif   // AC_W_ONLY == 0
 
 }  // namespace ac

@@ -42,6 +42,8 @@ struct BuildTimings {                   // seconds; device stages are bracketed 
     uint64_t n_local_distinct = 0, n_fragments = 0, fragment_bytes = 0;
     double upload_device_ms = 0;        // host entry: first copy issued -> last chunk landed and packed (HIP events)
     uint32_t position_retries = 0;      // builds repeated with exact smallest positions (AC_POS_CAP; kernels_tail.inc exp_avoid_start_of_path)
+    uint32_t launches = 0, readbacks = 0;   // kernel / fill launches and host round trips (mailbox, synchronising copies) of this build on its main stream
+    uint64_t n_degrees_open = 0;        // sharded builds: k-mers the light degree step left to the probes (the compact degree exchange's size)
     uint64_t path_runs_copied = 0, path_entries_walked = 0;   // K10c: followed runs whose path entries were copied / entries that were really walked (0 / 0: the plain walk)
 };
 
@@ -102,9 +104,14 @@ class GraphBuilder {
     uint64_t bitmap_words() const;                                  // u64 words of the union text's novel bitmap
     void bitmap_export(void* d_out);
     void shard_build_novel(const void* d_bitmap_sum);               // nullptr: single rank
+    // round 5: this rank's sibling bits by novel index (2 bits per distinct k-mer); sib_words() == 0: not in use, the degree stage has run
+    uint64_t sib_words() const;
+    void sib_export(void* d_out);
+    void shard_degrees(const void* d_sib_sum);                      // the degree stage, with the ranks' summed sibling bits
+    uint64_t degree_bytes() const;                                  // size of the degree exchange (compact: the k-mers the light step left open)
     uint64_t distinct_count() const;                                // N: distinct canonical k-mers of the whole job
-    void degrees_export(void* d_out);                               // N bytes: this rank's contributions
-    void shard_build_graph(const void* d_kinfo_sum);                // N bytes (nullptr: single rank)
+    void degrees_export(void* d_out);                               // degree_bytes() bytes: this rank's contributions
+    void shard_build_graph(const void* d_kinfo_sum);                // degree_bytes() bytes (nullptr: single rank)
     uint32_t unitig_count() const;
     void links_export(void* d_links_i32, void* d_wlinks_i64);       // 10 U words each: this rank's contributions
     void links_import(const void* d_links_i32, const void* d_wlinks_i64);   // summed (nullptr, nullptr: single rank)
@@ -151,6 +158,16 @@ void end_repair_device(uint32_t k, uint8_t* d_text, uint64_t n_text, const std::
 
 // pairwise_contig_distances (cluster.rs:132-157) on the final graph: out[a * n_seqs + b], sequences in path order.
 void pairwise_distances_device(const FinalGraph& g, uint32_t n_seqs, double* out);
+
+// ac_verify_graph (kernels_verify.inc): the size-independent properties of a finished graph, checked on the device against the job's text.
+struct VerifyReport {
+    uint32_t failed = 0;                                   // bit mask of the checks that failed (VerifyFlag); 0 = the graph holds
+    uint64_t first_bad_unitig = ~0ULL, first_bad_link = ~0ULL, first_bad_path_entry = ~0ULL, first_bad_sequence = ~0ULL, first_bad_base = ~0ULL;
+    uint64_t unitigs = 0, links = 0, path_entries = 0, bases_checked = 0, self_mirror_links = 0;
+    double seconds = 0;
+};
+void verify_graph_device(const FinalGraph& g, const uint8_t* d_text, uint64_t n_text, const std::vector<uint64_t>& off,
+                         const std::vector<uint32_t>& len, VerifyReport* rep);
 
 // Measured ceilings of the device for random atomicCAS / random 8-byte reads on a 134 MB table, in 10^9 operations per second.
 void random_access_ceilings(double* cas_gops, double* read_gops, uint64_t table_slots = (uint64_t)1 << 24);

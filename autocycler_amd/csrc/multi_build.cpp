@@ -4,8 +4,9 @@
 // shard_begin .. shard_finish); what used to be the caller's job — the collectives between them — happens here:
 //
 //   fragments + records     all-gather (variable sizes), straight into their places in the union text / record table
-//   novel bitmaps + sibling bits   all-reduce SUM (uint64; the owners partition the keys: disjoint bits; 3 bits per union-text position)
-//   degree bytes            all-reduce SUM (uint8): what the owners' probes found for the 1-3 % of the k-mers the sibling bits do not settle
+//   novel bitmaps           all-reduce SUM (uint64; the owners partition the keys: disjoint bits)
+//   sibling bits            all-reduce SUM (uint64; 2 bits per distinct k-mer, by novel index)
+//   degree bytes            all-reduce SUM (uint8), compact: what the owners' probes found for the 1-3 % of the k-mers the sibling bits do not settle
 //   link words              all-reduce SUM (int32; the walk words are derived from them on arrival)
 //   walk-start keys         ROUTED BY OWNER: every rank sorts its queries by owner = home hash mod N (queries_route) and one all-to-all
 //   + their answers         sends each key to the one rank whose table can answer it; the answers come back by the reverse all-to-all —
@@ -336,11 +337,22 @@ void rank_main(Shared& S, int rank) {
     }
     lapmsg("bitmap + build_novel");
     const uint64_t N = b.distinct_count();
+    const uint64_t sib_words = b.sib_words();
+    if (sib_words) {      // the sibling bits, 2 per distinct k-mer by novel index: their sum lets every rank settle 97-99 % of the degrees without a probe
+        const Arena::Mark mk = rc.xarena.mark();
+        void* sb = xalloc(sib_words * 8);
+        b.sib_export(sb);
+        timed([&] { X.all_reduce(rank, sb, sib_words, X_U64, X_SUM); });
+        b.shard_degrees(sb);
+        rc.xarena.rewind(mk);
+    }
+    lapmsg("sibling bits + degrees");
+    const uint64_t deg_bytes = b.degree_bytes();
     {
         const Arena::Mark mk = rc.xarena.mark();
-        void* deg = xalloc(N);
+        void* deg = xalloc(deg_bytes + 8);
         b.degrees_export(deg);
-        timed([&] { X.all_reduce(rank, deg, N, X_U8, X_SUM); });
+        timed([&] { X.all_reduce(rank, deg, deg_bytes, X_U8, X_SUM); });
         b.shard_build_graph(deg);
         rc.xarena.rewind(mk);
     }
@@ -415,7 +427,9 @@ void rank_main(Shared& S, int rank) {
         const uint64_t others_frag = frag_text_received + (nf_total * 8 - mb[rank]);
         st.bytes_fragments += others_frag;
         st.bytes_bitmap += b.bitmap_words() * 8 * (uint64_t)(R - 1) / (uint64_t)R * 2;      // reduce-scatter + all-gather of an all-reduce: 2 (R - 1) / R of the buffer per rank
-        st.bytes_degrees += N * (uint64_t)(R - 1) / (uint64_t)R * 2;
+        st.bytes_degrees += deg_bytes * (uint64_t)(R - 1) / (uint64_t)R * 2;
+        st.bytes_sibling += sib_words * 8 * (uint64_t)(R - 1) / (uint64_t)R * 2;
+        st.degrees_open = b.timings().n_degrees_open;
         st.bytes_links += U * 40 * (uint64_t)(R - 1) / (uint64_t)R * 2;
         st.bytes_reduce += U * 20 * (uint64_t)(R - 1) / (uint64_t)R * 2;
         st.bytes_queries += q_recv_total * kw * 8; st.bytes_answers += sent_away * 8;
@@ -426,6 +440,10 @@ void rank_main(Shared& S, int rank) {
         st.candidates_total = b.timings().n_candidates;
         st.candidates_owned_max = std::max<uint64_t>(st.candidates_owned_max, b.timings().n_candidates_owned);
         st.bytes_tail += tail_bytes * (uint64_t)(R - 1) / (uint64_t)R * 2;
+        // what THIS rank received over the whole build (an all-reduce of S bytes: 2 (R - 1) / R x S on a ring)
+        const uint64_t ar = (b.bitmap_words() * 8 + sib_words * 8 + deg_bytes + U * 40 + U * 20 + tail_bytes) * (uint64_t)(R - 1) / (uint64_t)R * 2;
+        const uint64_t mine = others_frag + ar + q_recv_total * kw * 8 + sent_away * 8;
+        st.bytes_received_max = std::max(st.bytes_received_max, mine);
     }
 }
 

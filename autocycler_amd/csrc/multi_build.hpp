@@ -24,6 +24,8 @@ struct MultiStats {
     double seconds_total = 0, seconds_exchange_max = 0;      // wall clock of the call / the slowest rank's time inside exchanges
     uint64_t candidates_total = 0, candidates_owned_max = 0; // expand_repeats: candidate junctions of the job / the most one rank ran (its conflict components)
     uint64_t bytes_tail = 0;                                 // the tail's merge: field lengths + sequence bytes (all-reduces)
+    uint64_t bytes_sibling = 0, degrees_open = 0;            // round 5: the sibling bits' exchange; k-mers the light degree step left to the probes
+    uint64_t bytes_received_max = 0;                         // the most any one rank received over the whole build
 };
 
 // seqs: all sequences of the job in input order; devices[r] = HIP ordinal of rank r (an ordinal may appear more than once: those ranks

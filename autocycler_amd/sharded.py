@@ -9,10 +9,12 @@ the GPU box, "gloo" in the CPU test-suite):
       all-gather            fragment text (2-bit codes) + 8-byte records of every rank  (∝ distinct content, not ∝ input; 0.25 B per base)
     ac_shard_build_union    this rank inserts the union-text k-mers it OWNS (owner = hash of the canonical middle mod world):
                             a table of ~1/world of the job's k-mers
-      all-reduce SUM        the ranks' novel bitmaps + sibling bits (disjoint)      (3 bits per union-text position)
-    ac_shard_build_novel    novel list; degrees: what the sibling bits settle is settled on every rank alike, the rest (1-3 %) and the
-                            first flags by probing owned groups only
-      all-reduce SUM        the probes' contributions                               (1 B per distinct k-mer, zero for the settled ones)
+      all-reduce SUM        the ranks' novel bitmaps (disjoint)                     (1 bit per union-text position)
+    ac_shard_build_novel    novel list; this rank's sibling bits by novel index
+      all-reduce SUM        sibling bits (disjoint)                                 (2 bits per distinct k-mer)
+    ac_shard_degrees        degrees: what the sibling bits settle is settled on every rank alike (97-99 %), the rest and the first flags by
+                            probing owned groups only
+      all-reduce SUM        the probes' contributions, compact                      (1 B per k-mer left open + 4 B per sequence end)
     ac_shard_build_graph    unitigs (identical everywhere); links, probing owned groups only
       all-reduce SUM        link words                                              (40 B per unitig; the walk words are derived on arrival)
     ac_shard_links_import   the keys this rank's path walkers start from
@@ -217,12 +219,21 @@ def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False, 
             comm.all_reduce(bm, "SUM")          # disjoint bits: the sum is the OR
             _check(lib, lib.ac_shard_build_novel(h, ptr(bm)))
         del bm
-        # degrees + first flags: contributions of the owners
+        # the sibling bits (2 per distinct k-mer, by novel index): with their sum every rank settles 97-99 % of the degrees without a probe
         N = lib.ac_shard_distinct_count(h)
+        sw = lib.ac_shard_sib_words(h)
+        if sw:
+            sib = torch.empty(sw, dtype=torch.int64, device=dev)
+            _check(lib, lib.ac_shard_sib_export(h, ptr(sib)))
+            comm.all_reduce(sib, "SUM")         # disjoint bits again
+            _check(lib, lib.ac_shard_degrees(h, ptr(sib)))
+            del sib
+        # degrees + first flags: what the owners' probes found for the k-mers left open (compact: a byte each), or for all of them
         if solo:
             _check(lib, lib.ac_shard_build_graph(h, None))
         else:
-            deg = torch.empty(N, dtype=torch.uint8, device=dev)
+            nb = lib.ac_shard_degree_bytes(h)
+            deg = torch.zeros(max(nb, 1), dtype=torch.uint8, device=dev)
             _check(lib, lib.ac_shard_degrees_export(h, ptr(deg)))
             comm.all_reduce(deg, "SUM")
             _check(lib, lib.ac_shard_build_graph(h, ptr(deg)))

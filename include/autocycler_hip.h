@@ -67,6 +67,9 @@ typedef struct {
     uint64_t path_runs_copied, path_entries_walked;   /* the copying path walk: runs whose entries were copied, entries really walked (0, 0: plain walk) */
     uint64_t position_retries;   /* builds repeated with exact smallest positions because expand_repeats met a common sequence longer than the bound kept (AC_POS_CAP) */
     uint32_t n_candidates_owned; /* the candidate junctions THIS rank ran (a job over several devices with a partitioned tail; else = n_candidates) */
+    uint32_t launches;           /* kernel launches of this build on its main stream (fused fills count once per batch) */
+    uint32_t readbacks;          /* host round trips of this build: small device -> host reads the host waited for */
+    uint64_t n_degrees_open;     /* sharded builds: k-mers whose degrees the sibling bits did not settle (= bytes of the compact degree exchange) */
 } ac_timings;
 
 /* Replaces compress.rs:42-44.  k: --kmer (odd).  assembly_count: the reference's capacity hint
@@ -85,7 +88,7 @@ int ac_compress_build_multi(uint32_t k, uint32_t assembly_count, const ac_seq_vi
                             int n_devices, ac_graph** out);
 /* What the multi-device build behind a graph moved between its ranks (n_ranks = 0: a single-device build). */
 typedef struct {
-    uint32_t n_ranks; int transport;   /* transport: 1 = staged through host memory, 2 = RCCL */
+    uint32_t n_ranks; int transport;   /* transport: 1 = staged through host memory, 2 = RCCL, 3 = one rank: built as a single-device job */
     uint64_t bytes_fragments, bytes_bitmap, bytes_degrees, bytes_links, bytes_queries, bytes_answers, bytes_reduce;   /* received, all ranks */
     uint64_t queries_total, queries_sent_away;        /* walk-start queries of all ranks / those another rank answered */
     uint64_t table_capacity_max, table_capacity_sum;  /* slots of the ranks' shares of the job's k-mer table */
@@ -93,8 +96,38 @@ typedef struct {
     double seconds_total, seconds_exchange_max;
     /* expand_repeats partitioned by conflict component: candidate junctions of the job / the most any one rank ran */
     uint64_t candidates_total, candidates_owned_max;
+    /* round 5 */
+    uint64_t bytes_sibling;      /* the sibling bits (2 per distinct k-mer), received, all ranks */
+    uint64_t bytes_tail;         /* the partitioned tail's merges (field lengths, sequence bytes) */
+    uint64_t degrees_open;       /* k-mers the light degree step left to the probes (bytes_degrees is their exchange) */
+    uint64_t bytes_received_max; /* the most any ONE rank received from the others over the whole build */
 } ac_multi_info;
 int ac_multi_info_get(const ac_graph*, ac_multi_info* out);
+/* The same for a caller compiled against an older header: at most out_size bytes are written (the struct only grows at its end); returns
+ * the library's own sizeof(ac_multi_info). */
+size_t ac_multi_info_get_sized(const ac_graph*, ac_multi_info* out, size_t out_size);
+
+/* ---- the round-trip verifier: what the reference's own tests hold a compress result to (tests.rs:108-127), as device
+ * kernels over the result arrays of `graph` and the job's sequences — for inputs no CPU oracle can hold:
+ *   every path spells its input sequence base for base (reconstruct_original_sequences, unitig_graph.rs:362-400; decompress.rs:83-105);
+ *   every step of every path is a link, links are unique and come in reverse-complement pairs (check_links, unitig_graph.rs:752-793);
+ *   depth == number of path occurrences (unitig.rs:149-156); unitigs are in renumber_unitigs order (unitig_graph.rs:295-315);
+ *   the statistics are consistent (total_length, link_count().1, kmers.len() == 2 x pre-simplification length).
+ * Returns 0 when the checks RAN (report->failed says what they found: 0 = the graph holds), non-zero on a usage error (ac_last_error).
+ * `failed` bits: 1 unitig length / range, 2 renumber order, 4 link endpoint out of range, 8 duplicate link, 16 link without mirror,
+ * 32 path entry out of range, 64 path step that is no link, 128 path length != sequence length, 256 a path does not spell its sequence,
+ * 512 depth != occurrences, 1024 statistics.  first_bad_*: the smallest offending index of each kind (all ones: none). */
+typedef struct {
+    uint32_t failed;
+    uint64_t first_bad_unitig, first_bad_link, first_bad_path_entry, first_bad_sequence, first_bad_base;
+    uint64_t unitigs, links, path_entries, bases_checked, self_mirror_links;
+    double seconds;
+} ac_verify_report;
+/* seqs: the sequences the graph was built from, as for ac_compress_build (host memory; they are laid out and uploaded as text) */
+int ac_verify_graph(const ac_graph* graph, const ac_seq_view* seqs, uint32_t n_seqs, int device, ac_verify_report* report);
+/* the same against a text that is resident on the device (the layout ac_compress_build_device takes) */
+int ac_verify_graph_device(const ac_graph* graph, const void* d_text, uint64_t n_text, const uint64_t* seq_off, const uint32_t* seq_len,
+                           uint32_t n_seqs, int device, ac_verify_report* report);
 
 /* The 2-bit packing the host entry applies before the upload (sequence.rs:39-48 validates the same alphabet): n_text bytes ->
  * (n_text + 31) / 32 words of 2-bit codes (A, C, G, T = 0..3, first base most significant) and as many 32-bit mask words
@@ -125,12 +158,19 @@ int ac_compress_build_device(uint32_t k, uint32_t assembly_count, const void* d_
  *                             n_shards — the four successors of a k-mer share the middle, hence the owner — into a table of about
  *                             1/n_shards of the job's k-mers                          -> ac_shard_bitmap_export (novel positions)
  *   [all-reduce SUM int64]    the novel bitmaps (disjoint bits: the sum is the OR)
- *   ac_shard_build_novel      sorted novel list (identical on every rank); next_kmers / prev_kmers counts (kmer_graph.rs:136-166) and
- *                             first flags of ALL novel k-mers, probing only the groups this rank owns  -> ac_shard_degrees_export
- *   [all-reduce SUM uint8]    the N degree bytes, N = ac_shard_distinct_count()
+ *   ac_shard_build_novel      sorted novel list (identical on every rank).  If ac_shard_sib_words() > 0 afterwards (round 5; k >= 3):
+ *   [all-reduce SUM uint64]     ac_shard_sib_export: the sibling bits this rank's insert collected, 2 per distinct k-mer by novel index
+ *                               (two k-mers of one canonical middle that share their first or last base: the only way a k-mer's
+ *                               text neighbour can have a second successor / predecessor; all k-mers of a middle have one owner)
+ *   ac_shard_degrees            next_kmers / prev_kmers counts (kmer_graph.rs:136-166): with the summed sibling bits 97-99 % are settled
+ *                               without a table access, the same on every rank; the rest, and the first flags, by probing the groups
+ *                               this rank owns                                                       -> ac_shard_degrees_export
+ *                             (ac_shard_sib_words() == 0: ac_shard_build_novel has run the degree stage itself, every degree by probing)
+ *   [all-reduce SUM uint8]    ac_shard_degree_bytes() bytes: one per k-mer left open + four per flagged fragment end (compact), or
+ *                             one per distinct k-mer
  *   ac_shard_build_graph      unitigs in seed order (identical on every rank); links (create_links, unitig_graph.rs:234-287),
  *                             probing only owned groups                                                   -> ac_shard_links_export
- *   [all-reduce SUM]          10 U int32 link words + 10 U int64 walk words, U = ac_shard_unitig_count()
+ *   [all-reduce SUM int32]    10 U link words, U = ac_shard_unitig_count() (the 10 U walk words are derived from them on import)
  *   ac_shard_links_import     the complete links; the keys this rank's path walkers start from      -> ac_shard_queries_export
  *   [all-gather]              the query keys of all ranks (ac_shard_query_count() x ac_shard_query_key_words() u64 per rank)
  *   ac_shard_answer           looks the owned ones among ALL ranks' keys up in this rank's table
@@ -170,11 +210,15 @@ uint64_t ac_shard_bitmap_words(const ac_shard*);       /* u64 words of the union
 int ac_shard_bitmap_export(ac_shard*, void* d_out_u64);
 int ac_shard_build_novel(ac_shard*, const void* d_bitmap_sum_u64 /* or NULL */);
 uint64_t ac_shard_distinct_count(const ac_shard*);     /* N: distinct canonical k-mers of the whole job */
-int ac_shard_degrees_export(ac_shard*, void* d_out_u8 /* N bytes: out (3 bits), in (3 bits), the two first flags */);
-int ac_shard_build_graph(ac_shard*, const void* d_degrees_sum_u8 /* N bytes, or NULL */);
+uint64_t ac_shard_sib_words(const ac_shard*);          /* after ac_shard_build_novel: u64 words of the sibling bits to sum (0: none, the degree stage has run) */
+int ac_shard_sib_export(ac_shard*, void* d_out_u64 /* ac_shard_sib_words() */);
+int ac_shard_degrees(ac_shard*, const void* d_sib_sum_u64);
+uint64_t ac_shard_degree_bytes(const ac_shard*);       /* size of the degree exchange (after the degree stage) */
+int ac_shard_degrees_export(ac_shard*, void* d_out_u8 /* ac_shard_degree_bytes() */);
+int ac_shard_build_graph(ac_shard*, const void* d_degrees_sum_u8 /* ac_shard_degree_bytes(), or NULL */);
 uint32_t ac_shard_unitig_count(const ac_shard*);       /* U: sizes the link and reduce buffers */
-int ac_shard_links_export(ac_shard*, void* d_links_i32 /* 10 U */, void* d_wlinks_i64 /* 10 U */);
-int ac_shard_links_import(ac_shard*, const void* d_links_sum_i32, const void* d_wlinks_sum_i64 /* or NULL, NULL */);
+int ac_shard_links_export(ac_shard*, void* d_links_i32 /* 10 U */, void* d_wlinks_i64 /* 10 U, or NULL: not wanted */);
+int ac_shard_links_import(ac_shard*, const void* d_links_sum_i32 /* or NULL: one rank */, const void* d_wlinks_sum_i64 /* or NULL: derived from the link words */);
 uint64_t ac_shard_query_count(const ac_shard*);        /* walk queries of this rank */
 uint32_t ac_shard_query_key_words(const ac_shard*);    /* u64 words per query key (depends on k only) */
 int ac_shard_queries_export(ac_shard*, void* d_out_u64 /* query_count * query_key_words */);

@@ -150,3 +150,13 @@ def test_config_e_checker_on_a_small_mixed_species_job(emu):
     assert broken(b["path_entries"], 5, -b["path_entries"][5])
     assert broken(b["seq_bytes"], 100, ord("A") if b["seq_bytes"][100] != ord("A") else ord("C"))
     assert broken(b["depth"], 3, b["depth"][3] + 1)
+
+
+def test_verify_graph_accepts_oracle_equal_graphs(emu):
+    import verify_cases
+    assert verify_cases.accepts_oracle_equal_graphs(emu, ks=(5, 11, 51), seeds=range(8)) == 24
+
+
+def test_verify_graph_names_the_damage(emu):
+    import verify_cases
+    verify_cases.names_the_damage(emu)

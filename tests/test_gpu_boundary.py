@@ -108,3 +108,15 @@ def test_library_is_built_from_this_tree():
     spec = importlib.util.spec_from_file_location("source_hash", Path(__file__).resolve().parent.parent / "tools" / "source_hash.py")
     m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
     assert autocycler_amd.load_library().ac_source_hash().decode() == m.source_hash()
+
+
+def test_verify_graph_accepts_oracle_equal_graphs(lib):
+    # ac_verify_graph: every oracle-equal graph holds, built or reloaded from its GFA
+    import verify_cases
+    assert verify_cases.accepts_oracle_equal_graphs(None, ks=(5, 11, 51), seeds=range(12)) == 36
+
+
+def test_verify_graph_names_the_damage(lib):
+    # one flipped base, one dropped link, one swapped path entry, ... : each reported with its class; the graph holds again once restored
+    import verify_cases
+    verify_cases.names_the_damage(None)

@@ -9,6 +9,7 @@ the reference, needs minutes to hours at these sizes): config B = 12 x 5 Mbp and
   * config B only: GFA save -> load -> save is the identity (tests.rs:108-112) through the oracle's loader/writer, and a
     scaled-down replica of the same generator is byte-identical to the oracle (test_gpu_parity)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -53,7 +54,22 @@ def build(n_assemblies, k=51, genome=5_000_000, pieces=1, device_repair=False, p
                                       off, lens, ids, d1, d2, C.c_uint32(n), C.c_int(0), C.byref(g))
     assert rc == 0, lib.ac_last_error()
     lib.ac_seqs_free(h)
+    build.last = dict(d_text=d_text, n_text=n_text, off=off, lens=lens)      # (the job's text stays on the device for verify_on_device)
     return _capi.Graph(lib, g, n), seqs, fn, hd
+
+
+def verify_on_device(g, seqs):
+    """ac_verify_graph_device (round 5): the property list of check_properties as device kernels behind the ABI, against the
+    text the graph was built from (end repair only rewrites padding dots; the bases between them are the inputs)."""
+    import time
+    j = build.last
+    t0 = time.time()
+    rep = g.verify_device(j["d_text"].data_ptr(), j["n_text"], j["off"], j["lens"])
+    assert rep["failed"] == 0, rep
+    assert rep["bases_checked"] == sum(len(s) for s in seqs) and rep["unitigs"] == g.unitig_count
+    print(f"ac_verify_graph_device: {rep['unitigs']} unitigs, {rep['links']} links, {rep['path_entries']} path entries, {rep['bases_checked']} bases in "
+          f"{rep['seconds'] * 1e3:.1f} ms on the device ({(time.time() - t0) * 1e3:.1f} ms with the call)")
+    return rep["unitigs"]
 
 
 def check_properties(g, seqs, k):
@@ -108,7 +124,7 @@ def test_config_b_12_assemblies():
     import oracle_lib as O
     g, seqs, fn, hd = build(12)
     U = check_properties(g, seqs, 51)
-    assert U > 1000
+    assert U > 1000 and verify_on_device(g, seqs) == U      # the numpy restatement of the properties and the device verifier agree
     gfa = g.gfa(fn, hd)
     assert O.gfa_resave(gfa) == gfa          # save -> load -> save identity (tests.rs:108-112)
     dec = O.decompress(gfa)                  # decompress.rs through the oracle: (filename, header, sequence) per contig
@@ -120,7 +136,7 @@ def test_config_c_96_assemblies():
     import time
     g, seqs, fn, hd = build(96)
     U = check_properties(g, seqs, 51)
-    assert U > 10000
+    assert U > 10000 and verify_on_device(g, seqs) == U
     assert g.stats_post["total_length"] < g.stats_pre["total_length"]
     # pairwise_contig_distances (cluster.rs:132-157) on the device against a numpy restatement, every 7th row
     t0 = time.time()
@@ -143,6 +159,7 @@ def test_fragmented_assemblies_many_sequences():
     g, seqs, fn, hd = build(30, genome=1_000_000, pieces=400, device_repair=True)
     assert len(seqs) > 12_000
     U = check_properties(g, seqs, 51)
+    assert verify_on_device(g, seqs) == U
     assert U > 1000
 
 
@@ -158,7 +175,7 @@ def test_config_d_full_size_k101():
     # oracle cannot hold it, so the device result is checked through the size-independent properties.
     g, seqs, fn, hd = build(24, k=101, genome=100_000_000, device_repair=True, plasmid=0, seed=101_000)
     assert sum(len(s) for s in seqs) > 2_390_000_000
-    U = check_properties(g, seqs, 101)
+    U = verify_on_device(g, seqs)      # (round 5: the device verifier behind the ABI instead of the numpy restatement — 2.4 G bases spelled back on the device)
     assert U > 100_000
     assert g.kmer_count > 240_000_000
 
@@ -179,7 +196,13 @@ def test_config_e_full_size_k51():
     d_text = torch.from_numpy(job["text"]).to("cuda:0")
     g, times, _ = fullsize_e.build_device(lib, job, d_text.data_ptr(), repair=True, builds=1)
     lib.ac_release_memory()
-    r = fullsize_e.check_on_device(g, job, d_text, log=print)
+    # round 5: ac_verify_graph_device — the decompress identity, check_links, depth, renumber order and the statistics as device kernels
+    # behind the ABI (tests/fullsize_e.py::check_on_device is the torch restatement rounds 3-4 used; AC_TEST_TORCH_CHECK=1 runs it as well)
+    r = g.verify_device(d_text.data_ptr(), job["n_text"], job["off"], job["lens"])
+    assert r["failed"] == 0 and r["bases_checked"] == job["bases"], r
+    if os.environ.get("AC_TEST_TORCH_CHECK"):
+        lib.ac_release_memory()
+        fullsize_e.check_on_device(g, job, d_text, log=print)
     print("config E full size:", times, g.stats_post, "kmers", g.kmer_count, r)
     assert r["unitigs"] > 50_000_000 and r["path_entries"] > 1_000_000_000
     assert g.kmer_count > 4_000_000_000

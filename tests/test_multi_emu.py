@@ -119,9 +119,9 @@ def test_one_device_is_a_single_device_build(emu, monkeypatch):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_round5_protocol_knobs(emu, world, monkeypatch):
-    """The three things round 5 gave the N-rank protocol, each switched off again: the sibling bits travelling with the novel bitmap and
-    the probe-free degree step (AC_SHARD_DEGREE_FLAGS=0: every degree by probing, a full byte per k-mer), the host-side renumbering of a
-    rank's own paths (AC_SHARD_HOST_REMAP=0).  Same graph either way; the bitmap exchange carries three planes instead of one."""
+    """The things round 5 gave the N-rank protocol, each switched off again: the sibling bits (exchanged by novel index) with the probe-free
+    degree step and its compact exchange (AC_SHARD_DEGREE_FLAGS=0: every degree by probing, a full byte per k-mer), the host-side
+    renumbering of a rank's own paths (AC_SHARD_HOST_REMAP=0).  Same graph either way."""
     for seqs, fn, hd, k in (M.synth_case(8, 40_000, 2_000, 1e-3, 1e-4, 7) + (51,), M.mixed_case(3, 3, 20_000) + (21,)):
         gfa, info = M.run_case(emu, k, seqs, fn, hd, [0] * world)
         monkeypatch.setenv("AC_SHARD_DEGREE_FLAGS", "0")
@@ -131,7 +131,15 @@ def test_round5_protocol_knobs(emu, world, monkeypatch):
         gfa_dev, _ = M.run_case(emu, k, seqs, fn, hd, [0] * world)
         monkeypatch.delenv("AC_SHARD_HOST_REMAP")
         assert gfa == gfa_probe == gfa_dev
-        assert 2.5 * info_probe["bytes_bitmap"] <= info["bytes_bitmap"] <= 3.0 * info_probe["bytes_bitmap"] + 64
-        assert info["bytes_links"] * 3 == info_probe["bytes_links"] * 3      # (40 B per unitig either way since the walk words stay at home)
+        # the bitmap exchange is the same; the sibling bits are 2 per DISTINCT k-mer; the degree exchange is a byte per k-mer the light step
+        # left open (+ 4 per sequence end) instead of a byte per distinct k-mer
+        ring = lambda nbytes: nbytes * (world - 1) // world * 2 * world      # an all-reduce of nbytes as every rank's received bytes, summed
+        assert info["bytes_bitmap"] == info_probe["bytes_bitmap"] and info_probe["bytes_sibling"] == 0
+        assert 0 < info["bytes_sibling"] <= ring(2 * (info["distinct"] // 64 + 2) * 8) + 64
+        assert info_probe["bytes_degrees"] >= ring(info["distinct"]) - 64 and info_probe["degrees_open"] == 0
+        assert 0 < info["degrees_open"] < info["distinct"] // 3
+        assert info["bytes_degrees"] <= ring(info["degrees_open"] + 8 * len(seqs)) + 64 < info_probe["bytes_degrees"]
+        assert info["bytes_links"] == info_probe["bytes_links"]      # (40 B per unitig either way since the walk words stay at home)
+        assert 0 < info["bytes_received_max"] * world <= 2 * sum(info[x] for x in info if x.startswith("bytes_") and x != "bytes_received_max")
     M.adversarial(emu, [0] * world, ks=(11, 51), seeds=range(6))
 

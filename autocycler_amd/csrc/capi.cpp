@@ -179,6 +179,7 @@ int ac_release_memory(void) {
         release_multi_contexts();
         PinnedPool::get().trim();
         release_host_stager();
+        scan_pool().release();
 #ifndef AC_EMU
         Mailbox::get().release();
 #endif
@@ -746,6 +747,17 @@ int ac_verify_graph(const ac_graph* g, const ac_seq_view* seqs, uint32_t n_seqs,
         verify_graph_device(g->g, (const uint8_t*)d_text, text.size(), off, len, &r);
 #endif
         fill_report(r, report);
+    });
+}
+
+// The hand-written scan / radix sort / comparator sort (device_prims.hpp) against the host's std:: algorithms — test hook.
+int ac_selftest_primitives(int device, uint64_t n, uint64_t seed, int end_bit, int key_kind) {
+    return guarded([&] {
+        if (end_bit < 1 || end_bit > 64) throw DeviceError("end_bit out of range");
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
+        select_device(device);
+        primitives_selftest(n, seed, end_bit, key_kind);
     });
 }
 

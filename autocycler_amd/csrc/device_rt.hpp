@@ -1,7 +1,7 @@
-// Thin device runtime used by the graph-build pipeline: buffers, copies, a functor launcher and the
-// plain device primitives (radix sort, scan, reduce-by-key, merge sort) from rocPRIM.
-// HIP build: hipMalloc / hipLaunchKernelGGL / rocPRIM on one stream of one gfx950 device.
-// AC_EMU build (tests only): malloc / serial loops / std:: algorithms.
+// Thin device runtime used by the graph-build pipeline: buffers, copies, a functor launcher and (device_prims.hpp) the plain device
+// primitives — radix sort, scans, comparator sort, segmented reduce — hand-written since round 5.
+// HIP build: hipMalloc / hipLaunchKernelGGL on one stream of one gfx950 device.
+// AC_EMU build (tests only): malloc / the same kernels under the lockstep emulation of wave_rt.hpp.
 #pragma once
 #include <cstdio>
 #include <cstdlib>
@@ -21,7 +21,6 @@
 
 #ifndef AC_EMU
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 #endif
 
 namespace ac {
@@ -72,6 +71,10 @@ __device__ inline void atomic_max32(u32* p, u32 v) { atomicMax(p, v); }
 __device__ inline u32 atomic_cas32(u32* p, u32 expected, u32 desired) { return atomicCAS(p, expected, desired); }
 __device__ inline u32 atomic_load32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }      // (past this CU's L1: another CU's store is seen)
 #endif
+
+// ---- per-thread counters of what a build asks of the runtime (ac_timings.launches / .readbacks) ---------------------------------------
+struct RtCounters { u32 launches = 0, readbacks = 0; };
+inline RtCounters& rt_counters() { static thread_local RtCounters c; return c; }
 
 // ---- device context ------------------------------------------------------------------------------------------------------------
 // Everything a build keeps between its stages and between builds — the device arena, the fill queue, the read-back mailbox, the side
@@ -332,6 +335,7 @@ class FillQueue {
         a_.n = n_;
         n_ = 0;
         for (u64 t0 = 0; t0 < tiles; t0 += FILL_MAX_TILES) {      // (2^32 threads per launch at most: 64 GB of fills)
+            rt_counters().launches++;
             hipLaunchKernelGGL(fill_many_kernel<0>, dim3((unsigned)std::min(FILL_MAX_TILES, tiles - t0)), dim3(256), 0, 0, a_, t0);
             AC_HIP_CHECK(hipGetLastError());
         }
@@ -478,6 +482,7 @@ class Mailbox {
         MailArgs a;
         a.n = n; a.box = d_; a.seq = ++seq_;
         for (int i = 0; i < n; i++) a.it[i] = items[i];
+        rt_counters().launches++; rt_counters().readbacks++;
         hipLaunchKernelGGL(mailbox_publish_kernel<0>, dim3(1), dim3(256), 0, s, a);
         AC_HIP_CHECK(hipGetLastError());
         volatile u64* flag = (volatile u64*)h_;
@@ -530,6 +535,7 @@ inline void copy_d2h(void* h, const void* d, size_t bytes, stream_t s = 0) {
     static const bool use_scratch = getenv("AC_NO_PINNED_SCRATCH") == nullptr;
     if (use_scratch && bytes <= (64 << 10)) {
         void* p = pinned_scratch(bytes);
+        rt_counters().readbacks++;
         AC_HIP_CHECK(hipMemcpyAsync(p, d, bytes, hipMemcpyDeviceToHost, s));
         AC_HIP_CHECK(hipStreamSynchronize(s));
         memcpy(h, p, bytes);
@@ -563,6 +569,7 @@ class ReadBatch {
             return;
         }
         char* p = (char*)pinned_scratch(total);
+        rt_counters().readbacks++;
         size_t o = 0;
         for (auto& it : items_) { AC_HIP_CHECK(hipMemcpyAsync(p + o, it.d, it.bytes, hipMemcpyDeviceToHost, s)); o += (it.bytes + 63) & ~(size_t)63; }
         AC_HIP_CHECK(hipStreamSynchronize(s));
@@ -716,6 +723,7 @@ template <class F> void launch(u64 n, const F& f, stream_t s = 0) {
     if (s == 0) flush_fills();
     if (debug_launch()) debug_launch_note<F>(n, false);
     for (u64 b0 = 0; b0 < blocks; b0 += MAX_LAUNCH_BLOCKS) {
+        rt_counters().launches++;
         hipLaunchKernelGGL(functor_kernel<F>, dim3((unsigned)std::min(MAX_LAUNCH_BLOCKS, blocks - b0)), dim3(256), 0, s, n, f, b0 * 256);
         AC_HIP_CHECK(hipGetLastError());
     }
@@ -747,6 +755,7 @@ template <class F> void launch_full(u64 n, const F& f, stream_t s = 0) {
     if (s == 0) flush_fills();
     if (debug_launch()) debug_launch_note<F>(n, false);
     for (u64 b0 = 0; b0 < blocks; b0 += MAX_LAUNCH_BLOCKS) {
+        rt_counters().launches++;
         hipLaunchKernelGGL(functor_kernel_full<F>, dim3((unsigned)std::min(MAX_LAUNCH_BLOCKS, blocks - b0)), dim3(256), 0, s, n, f, b0 * 256);
         AC_HIP_CHECK(hipGetLastError());
     }
@@ -763,6 +772,7 @@ template <class K, class... A> void launch_wave_kernel(K kernel, u64 blocks, str
     wv::launch_kernel(kernel, (unsigned)blocks, 256u, args...);
 #else
     if (s == 0) flush_fills();
+    rt_counters().launches++;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), 0, s, args...);
     AC_HIP_CHECK(hipGetLastError());
 #endif
@@ -788,207 +798,6 @@ AC_D void wave_add64(u64* counter, u32 v) {
     if (wv::lane() == 0 && t) atomic_add64(counter, (u64)t);
 }
 
-// ---- device primitives ----------------------------------------------------------------------------
-// Stable LSD radix sort of (u64 key, u32 value) pairs on key bits [0, end_bit).
-inline void sort_pairs_u64_u32(DBuf<u64>& keys, DBuf<u32>& vals, size_t n, int end_bit, stream_t s = 0) {
-    if (n <= 1) return;
-#ifdef AC_EMU
-    std::vector<size_t> idx(n);
-    for (size_t i = 0; i < n; i++) idx[i] = i;
-    u64* k = keys.ptr(); u32* v = vals.ptr();
-    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return k[a] < k[b]; });
-    std::vector<u64> k2(n); std::vector<u32> v2(n);
-    for (size_t i = 0; i < n; i++) { k2[i] = k[idx[i]]; v2[i] = v[idx[i]]; }
-    memcpy(k, k2.data(), n * 8); memcpy(v, v2.data(), n * 4);
-    (void)end_bit;
-#else
-    if (s == 0) flush_fills();
-    DBuf<u64> k2(n); DBuf<u32> v2(n);
-    size_t tmp_bytes = 0;
-    AC_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, 0, end_bit, s));
-    DBuf<u8> tmp(tmp_bytes);
-    AC_HIP_CHECK(rocprim::radix_sort_pairs(tmp.ptr(), tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, 0, end_bit, s));
-    keys = std::move(k2);
-    vals = std::move(v2);
-#endif
-}
-inline void sort_pairs_u64_i32(DBuf<u64>& keys, DBuf<int32_t>& vals, size_t n, int end_bit, stream_t s = 0) {
-    if (n <= 1) return;
-#ifdef AC_EMU
-    std::vector<size_t> idx(n);
-    for (size_t i = 0; i < n; i++) idx[i] = i;
-    u64* k = keys.ptr(); int32_t* v = vals.ptr();
-    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return k[a] < k[b]; });
-    std::vector<u64> k2(n); std::vector<int32_t> v2(n);
-    for (size_t i = 0; i < n; i++) { k2[i] = k[idx[i]]; v2[i] = v[idx[i]]; }
-    memcpy(k, k2.data(), n * 8); memcpy(v, v2.data(), n * 4);
-    (void)end_bit;
-#else
-    if (s == 0) flush_fills();
-    DBuf<u64> k2(n); DBuf<int32_t> v2(n);
-    size_t tmp_bytes = 0;
-    AC_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, 0, end_bit, s));
-    DBuf<u8> tmp(tmp_bytes);
-    AC_HIP_CHECK(rocprim::radix_sort_pairs(tmp.ptr(), tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, 0, end_bit, s));
-    keys = std::move(k2);
-    vals = std::move(v2);
-#endif
-}
-
-inline void inclusive_scan_u32(const u32* in, u32* out, size_t n, stream_t s = 0) {
-    if (!n) return;
-#ifdef AC_EMU
-    u32 acc = 0;
-    for (size_t i = 0; i < n; i++) { acc += in[i]; out[i] = acc; }
-#else
-    if (s == 0) flush_fills();
-    size_t tmp_bytes = 0;
-    AC_HIP_CHECK(rocprim::inclusive_scan(nullptr, tmp_bytes, in, out, n, rocprim::plus<u32>(), s));
-    DBuf<u8> tmp(tmp_bytes);
-    AC_HIP_CHECK(rocprim::inclusive_scan(tmp.ptr(), tmp_bytes, in, out, n, rocprim::plus<u32>(), s));
-#endif
-}
-inline void inclusive_max_scan_u32(const u32* in, u32* out, size_t n, stream_t s = 0) {
-    if (!n) return;
-#ifdef AC_EMU
-    u32 acc = 0;
-    for (size_t i = 0; i < n; i++) { acc = in[i] > acc ? in[i] : acc; out[i] = acc; }
-#else
-    if (s == 0) flush_fills();
-    size_t tmp_bytes = 0;
-    AC_HIP_CHECK(rocprim::inclusive_scan(nullptr, tmp_bytes, in, out, n, rocprim::maximum<u32>(), s));
-    DBuf<u8> tmp(tmp_bytes);
-    AC_HIP_CHECK(rocprim::inclusive_scan(tmp.ptr(), tmp_bytes, in, out, n, rocprim::maximum<u32>(), s));
-#endif
-}
-inline void exclusive_scan_u32(const u32* in, u32* out, size_t n, stream_t s = 0) {
-    if (!n) return;
-#ifdef AC_EMU
-    u32 acc = 0;
-    for (size_t i = 0; i < n; i++) { u32 v = in[i]; out[i] = acc; acc += v; }
-#else
-    if (s == 0) flush_fills();
-    size_t tmp_bytes = 0;
-    AC_HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, (u32)0, n, rocprim::plus<u32>(), s));
-    DBuf<u8> tmp(tmp_bytes);
-    AC_HIP_CHECK(rocprim::exclusive_scan(tmp.ptr(), tmp_bytes, in, out, (u32)0, n, rocprim::plus<u32>(), s));
-#endif
-}
-inline void exclusive_scan_u64(const u64* in, u64* out, size_t n, stream_t s = 0) {
-    if (!n) return;
-#ifdef AC_EMU
-    u64 acc = 0;
-    for (size_t i = 0; i < n; i++) { u64 v = in[i]; out[i] = acc; acc += v; }
-#else
-    if (s == 0) flush_fills();
-    size_t tmp_bytes = 0;
-    AC_HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, (u64)0, n, rocprim::plus<u64>(), s));
-    DBuf<u8> tmp(tmp_bytes);
-    AC_HIP_CHECK(rocprim::exclusive_scan(tmp.ptr(), tmp_bytes, in, out, (u64)0, n, rocprim::plus<u64>(), s));
-#endif
-}
-
-// Segmented reduction of `vals` over runs of equal consecutive `seg` ids (ids are 0,1,2,... in order,
-// so run r reduces into out[r]).
-struct CountCheckFunctor {    // sets an error bit instead of making the host wait for the segment count
-    const u32* cnt; u32 expected; u32* err; u32 bit;
-    AC_D void operator()(u64) const { if (*cnt != expected) atomic_or32(err, bit); }
-};
-template <class V, class Op>
-inline void reduce_by_segment(const u32* seg, const V* vals, size_t n, V* out, size_t n_segments, Op op, u32* err = nullptr, stream_t s = 0) {
-    if (!n) return;
-#ifdef AC_EMU
-    size_t r = 0;
-    for (size_t i = 0; i < n;) {
-        V acc = vals[i];
-        size_t j = i + 1;
-        while (j < n && seg[j] == seg[i]) { acc = op(acc, vals[j]); j++; }
-        out[r++] = acc;
-        i = j;
-    }
-    if (r != n_segments) throw DeviceError("reduce_by_segment: segment count mismatch");
-#else
-    if (s == 0) flush_fills();
-    DBuf<u32> uniq(n_segments);
-    DBuf<u32> cnt(1);
-    size_t tmp_bytes = 0;
-    AC_HIP_CHECK(rocprim::reduce_by_key(nullptr, tmp_bytes, seg, vals, n, uniq.ptr(), out, cnt.ptr(), op, rocprim::equal_to<u32>(), s));
-    DBuf<u8> tmp(tmp_bytes);
-    AC_HIP_CHECK(rocprim::reduce_by_key(tmp.ptr(), tmp_bytes, seg, vals, n, uniq.ptr(), out, cnt.ptr(), op, rocprim::equal_to<u32>(), s));
-    if (err) launch(1, CountCheckFunctor{cnt.ptr(), (u32)n_segments, err, 128u}, s);
-    else if (read_scalar(cnt.ptr(), s) != n_segments) throw DeviceError("reduce_by_segment: segment count mismatch");
-#endif
-}
-
-// Arg-min per segment: `seg` holds non-decreasing segment ids (any values; a new id starts a new segment), the candidates of
-// position i is the index i itself, `op(a, b)` returns whichever of two indices wins.  No value array is materialised: the
-// indices come from a counting iterator and the operator looks at whatever the indices stand for.
-template <class Op>
-inline void segment_argmin(const u32* seg, size_t n, u32* out, size_t n_segments, Op op, u32* err = nullptr, stream_t s = 0) {
-    if (!n) return;
-#ifdef AC_EMU
-    size_t r = 0;
-    for (size_t i = 0; i < n;) {
-        u32 acc = (u32)i;
-        size_t j = i + 1;
-        while (j < n && seg[j] == seg[i]) { acc = op(acc, (u32)j); j++; }
-        out[r++] = acc;
-        i = j;
-    }
-    if (r != n_segments) throw DeviceError("segment_argmin: segment count mismatch");
-#else
-    if (s == 0) flush_fills();
-    DBuf<u32> uniq(n_segments);
-    DBuf<u32> cnt(1);
-    rocprim::counting_iterator<u32> idx(0);
-    size_t tmp_bytes = 0;
-    AC_HIP_CHECK(rocprim::reduce_by_key(nullptr, tmp_bytes, seg, idx, n, uniq.ptr(), out, cnt.ptr(), op, rocprim::equal_to<u32>(), s));
-    DBuf<u8> tmp(tmp_bytes);
-    AC_HIP_CHECK(rocprim::reduce_by_key(tmp.ptr(), tmp_bytes, seg, idx, n, uniq.ptr(), out, cnt.ptr(), op, rocprim::equal_to<u32>(), s));
-    if (err) launch(1, CountCheckFunctor{cnt.ptr(), (u32)n_segments, err, 128u}, s);
-    else if (read_scalar(cnt.ptr(), s) != n_segments) throw DeviceError("segment_argmin: segment count mismatch");
-#endif
-}
-
-// Sort (key struct, u32 value) pairs with a comparator.
-template <class K, class Cmp>
-inline void sort_by_key_cmp(DBuf<K>& keys, DBuf<u32>& vals, size_t n, Cmp cmp, stream_t s = 0) {
-    if (n <= 1) return;
-#ifdef AC_EMU
-    std::vector<size_t> idx(n);
-    for (size_t i = 0; i < n; i++) idx[i] = i;
-    K* k = keys.ptr(); u32* v = vals.ptr();
-    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return cmp(k[a], k[b]); });
-    std::vector<K> k2(n); std::vector<u32> v2(n);
-    for (size_t i = 0; i < n; i++) { k2[i] = k[idx[i]]; v2[i] = v[idx[i]]; }
-    memcpy(k, k2.data(), n * sizeof(K)); memcpy(v, v2.data(), n * 4);
-#else
-    if (s == 0) flush_fills();
-    DBuf<K> k2(n); DBuf<u32> v2(n);
-    size_t tmp_bytes = 0;
-    AC_HIP_CHECK(rocprim::merge_sort(nullptr, tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, cmp, s));
-    DBuf<u8> tmp(tmp_bytes);
-    AC_HIP_CHECK(rocprim::merge_sort(tmp.ptr(), tmp_bytes, keys.ptr(), k2.ptr(), vals.ptr(), v2.ptr(), n, cmp, s));
-    keys = std::move(k2);
-    vals = std::move(v2);
-#endif
-}
-
-// Stable sort of u32 keys with a comparator (the comparator usually dereferences per-key device arrays).
-template <class Cmp>
-inline void sort_keys_cmp(DBuf<u32>& keys, size_t n, Cmp cmp, stream_t s = 0) {
-    if (n <= 1) return;
-#ifdef AC_EMU
-    std::stable_sort(keys.ptr(), keys.ptr() + n, cmp);
-#else
-    if (s == 0) flush_fills();
-    DBuf<u32> k2(n);
-    size_t tmp_bytes = 0;
-    AC_HIP_CHECK(rocprim::merge_sort(nullptr, tmp_bytes, keys.ptr(), k2.ptr(), n, cmp, s));
-    DBuf<u8> tmp(tmp_bytes);
-    AC_HIP_CHECK(rocprim::merge_sort(tmp.ptr(), tmp_bytes, keys.ptr(), k2.ptr(), n, cmp, s));
-    keys = std::move(k2);
-#endif
-}
-
 }  // namespace ac
+
+#include "device_prims.hpp"      // scan, radix sort, comparator sort, segmented reduce: hand-written (round 5)

@@ -468,7 +468,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 [[maybe_unused]] static int minkey_prefix_bases() { const char* e = getenv("AC_MINKEY_PREFIX_BASES"); int v = e ? atoi(e) : 31; return v < 1 ? 1 : (v > 31 ? 31 : v); }      // tests: a shorter prefix takes the full-key path often
 [[maybe_unused]] static bool seed_prefix_sort() { const char* e = getenv("AC_SEED_PREFIX_SORT"); return e ? atoi(e) != 0 : true; }      // 0: seed order by the full-key sorts
 [[maybe_unused]] static u32 seed_max_group() { const char* e = getenv("AC_SEED_MAX_GROUP"); int v = e ? atoi(e) : 1024; return (u32)(v < 1 ? 1 : v); }      // tests: smaller groups take the fallback
-[[maybe_unused]] static int seed_prefix_bits() { const char* e = getenv("AC_SEED_PREFIX_BITS"); int v = e ? atoi(e) : 64; return v < 1 ? 1 : (v > 64 ? 64 : v); }      // tests
+[[maybe_unused]] static int seed_prefix_bits() { const char* e = getenv("AC_SEED_PREFIX_BITS"); if (!e) return 0; int v = atoi(e); return v < 1 ? 1 : (v > 64 ? 64 : v); }      // tests; unset = 0 = automatic
 [[maybe_unused]] static u32 degree_region_cap() { const char* e = getenv("AC_DEGREE_REGION_CAP"); int v = e ? atoi(e) : 0; return (u32)(v < 0 ? 0 : v); }      // tests: entries per queue region (0 = sized from N)
 [[maybe_unused]] static u64 upload_chunk_bytes() { return (u64)64 << 20; }      // text bytes per upload chunk (16 MB of codes per copy; 8-32 MB chunks over 2-3 copy queues: 2.8 against 3.2 ms in tools/microbench/upload_probe.hip, nothing in the build: r10o)
 // The packers write the codes straight into device memory (through the PCIe BAR, write-combined) instead of into a pinned ring a copy
@@ -606,6 +606,7 @@ struct GraphBuilder::Impl {
 
     void begin(BuildTimings* t) {
         tm = t; t_begin = t0 = now_s();
+        rt_counters() = RtCounters();
         host_remap_allowed = false;      // (GraphBuilder::build switches it on for itself)
         counters.alloc(8); counters.fill_bytes(0);
     }
@@ -1125,10 +1126,14 @@ template <int W> void GraphBuilder::Impl::unitigs() {
     bool seeds_ordered = false;
     if (seed_prefix_sort()) {      // one sort on a 64-bit prefix of the seed keys, ties on full keys: any key width, any number of unitigs
         DBuf<u64> wkey(U);
-        launch(U, SeedPrefixFunctor<W>{umin.ptr(), (int)k, wkey.ptr(), seed_prefix_bits()});
+        // as many leading bits of the prefix as tell U seeds apart with a few ties to spare (twice log2 U, and a byte for the bias of a
+        // MINIMUM towards small values): the ties are ranked on full keys anyway (SeedTieFunctor), and every digit less is a pass less
+        int keep = seed_prefix_bits();
+        if (keep <= 0) { int lg = 1; while ((1ULL << lg) < (u64)U) lg++; keep = std::min(64, ((2 * lg + 8 + 7) / 8) * 8); }
+        launch(U, SeedPrefixFunctor<W>{umin.ptr(), (int)k, wkey.ptr(), keep});
         DBuf<u32> by_prefix(U);
         copy_d2d(by_prefix.ptr(), order.ptr(), (size_t)U * 4);
-        sort_pairs_u64_u32(wkey, by_prefix, U, 64);
+        sort_pairs_u64_u32(wkey, by_prefix, U, 64, 0, 64 - keep);
         DBuf<u32> settled(U), big(1, true);
         launch(U, SeedTieFunctor<W>{by_prefix.ptr(), wkey.ptr(), U, umin.ptr(), settled.ptr(), seed_max_group(), big.ptr()});
         if (read_scalar(big.ptr()) == 0) {
@@ -1426,7 +1431,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             prio.fill_bytes(0xFF);
             launch(J, CandListFunctor{order1.ptr(), cflag.ptr(), cpos.ptr(), clist.ptr(), prio.ptr()});
             launch(C, FillU32Functor{level.ptr(), 1u});
-            DBuf<u32> changed(8), preds(C * MAX_PREDS); DBuf<u8> npred(C);
+            DBuf<u32> changed(9), preds(C * MAX_PREDS); DBuf<u8> npred(C);
             launch(C, LevelPredsFunctor{L, cand.ptr(), clist.ptr(), prio.ptr(), C, preds.ptr(), npred.ptr()});
             if (partitioned) {      // this rank's share of the junctions: the conflict components it owns
                 DBuf<u32> parent(C);
@@ -1437,15 +1442,20 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                 launch_full((J + 63) & ~63ULL, OwnedDirtyFunctor{cand.ptr(), prio.ptr(), jowner.ptr(), my_owner, dirty.ptr(), owned_count.ptr(), J});
                 gpre.alloc(U, true); gpost.alloc(U, true);
             }
+            u32 max_level = 1;
             for (;;) {   // longest-path levels of the conflict DAG by relaxation (monotone, so stale reads only delay); eight
                 changed.fill_bytes(0);       // sweeps per host check, converged when the last of them changed nothing
                 for (int it = 0; it < 8; it++)
-                    launch(C, LevelRelaxFunctor{preds.ptr(), npred.ptr(), C, level.ptr(), changed.ptr() + it, it ? changed.ptr() + it - 1 : nullptr});
-                if (to_host(changed, 8)[7] == 0) break;
+                    launch(C, LevelRelaxFunctor{preds.ptr(), npred.ptr(), C, level.ptr(), changed.ptr() + it, it ? changed.ptr() + it - 1 : nullptr, changed.ptr() + 8});
+                const std::vector<u32> hc = to_host(changed, 9);
+                max_level = std::max(max_level, hc[8]);
+                if (hc[7] == 0) break;
             }
             DBuf<u64> lkey(C);
             launch(C, LevelKeyFunctor{level.ptr(), lkey.ptr()});
-            sort_pairs_u64_u32(lkey, clist, C, 32);      // (a radix sort of many candidates does four passes instead of eight)
+            int level_bits = 1;
+            while (level_bits < 32 && (max_level >> level_bits)) level_bits++;
+            sort_pairs_u64_u32(lkey, clist, C, level_bits);      // (the highest level came back with the convergence flags: one or two digits)
             // first index of every level; [0] = number of levels (levels beyond the table: a second, exact read)
             const u32 LV_TABLE = 1024;
             DBuf<u32> bstart((u64)LV_TABLE + 2);
@@ -1669,6 +1679,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             throw DeviceError("internal error: path length mismatch for sequence " + std::to_string(s + 1));
     lap(&tm->d2h);
     tm->total_device = now_s() - t_begin;
+    tm->launches = rt_counters().launches; tm->readbacks = rt_counters().readbacks;
     if (getenv("AC_DEBUG_ARENA"))
         fprintf(stderr, "arena: used %.1f MB (peak %.1f) of %.1f MB (n_text %.1f MB), %.3f s in hipMalloc / hipFree so far\n", Arena::device().total_used() / 1e6,
                 Arena::device().peak() / 1e6, Arena::device().capacity() / 1e6, loc.n_text / 1e6, Arena::device().alloc_seconds());
@@ -2737,6 +2748,70 @@ uint64_t GraphBuilder::path_entry_count() const { return impl_->n_ent; }
 void GraphBuilder::paths_export(void* d_out) {
     if (impl_->paths_in_seed_numbers) throw DeviceError("paths_export: this rank kept its own paths (they were renumbered on the host)");
     copy_d2d(d_out, impl_->ent_val.ptr(), impl_->n_ent * 4);
+    stream_sync();
+}
+
+// Self-test of the hand-written primitives of device_prims.hpp against the host's std:: algorithms on n pseudo-random items (what the
+// CPU suite runs under the emulation and the device suite on the GPU: tile boundaries, duplicate-heavy keys for stability, end bits
+// that are not a multiple of eight, millions of tiles' worth of look-back).  Throws on the first mismatch.
+void primitives_selftest(uint64_t n, uint64_t seed, int end_bit, int key_kind) {
+    Arena::device().reset();
+    std::vector<u64> hk(n), hk64(n + 1); std::vector<u32> hv(n), h32(n + 1);
+    u64 st = seed * 0x9E3779B97F4A7C15ULL + 0xD1B54A32D192ED03ULL;
+    auto rnd = [&] { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    const u64 kmask = end_bit >= 64 ? ~0ULL : ((1ULL << end_bit) - 1);
+    for (u64 i = 0; i < n; i++) {
+        const u64 r = rnd();
+        // key kinds: 0 uniform, 1 few distinct values (long runs of equal keys: stability), 2 already sorted, 3 reverse sorted, 4 one hot digit
+        hk[i] = key_kind == 0 ? r : (key_kind == 1 ? (r % 7) * 0x0101010101010101ULL : (key_kind == 2 ? i * 3 : (key_kind == 3 ? (n - i) * 5 : ((r & 0xFF00FFULL) | 0xAB00ULL))));
+        hv[i] = (u32)i; h32[i] = (u32)(r >> 40) & 1023u; hk64[i] = (r >> 20) & 0x3FFFFFULL;      // (running totals below 2^46: device_prims.hpp)
+    }
+    h32[n] = 0; hk64[n] = 0;
+    if (n) {
+        DBuf<u64> dk(n); DBuf<u32> dv(n);
+        copy_h2d(dk.ptr(), hk.data(), n * 8); copy_h2d(dv.ptr(), hv.data(), n * 4);
+        sort_pairs_u64_u32(dk, dv, n, end_bit);
+        std::vector<u64> gk = to_host(dk, n); std::vector<u32> gv = to_host(dv, n);
+        std::vector<u32> idx(n);
+        for (u64 i = 0; i < n; i++) idx[i] = (u32)i;
+        std::stable_sort(idx.begin(), idx.end(), [&](u32 a, u32 b) { return (hk[a] & kmask) < (hk[b] & kmask); });
+        for (u64 i = 0; i < n; i++)
+            if (gk[i] != hk[idx[i]] || gv[i] != idx[i]) throw DeviceError("primitives self-test: radix sort differs from std::stable_sort at " + std::to_string(i) + " of " + std::to_string(n));
+        // comparator sorts (fallback paths): the same order from the merge sort by ranks
+        DBuf<u32> order(n);
+        copy_h2d(order.ptr(), hv.data(), n * 4);
+        DBuf<u64> dk2(n);
+        copy_h2d(dk2.ptr(), hk.data(), n * 8);
+        struct Less { const u64* k; u64 m; AC_HD bool operator()(u32 a, u32 b) const { return (k[a] & m) < (k[b] & m); } };
+        if (n <= (1u << 18)) {
+            sort_keys_cmp(order, n, Less{dk2.ptr(), kmask});
+            std::vector<u32> go = to_host(order, n);
+            for (u64 i = 0; i < n; i++) if (go[i] != idx[i]) throw DeviceError("primitives self-test: comparator sort differs at " + std::to_string(i));
+        }
+    }
+    {   // scans over n + 1 items (the pipeline's "sentinel" form) and over n
+        DBuf<u32> a(n + 1), o(n + 1); DBuf<u64> a64(n + 1), o64(n + 1);
+        copy_h2d(a.ptr(), h32.data(), (n + 1) * 4); copy_h2d(a64.ptr(), hk64.data(), (n + 1) * 8);
+        exclusive_scan_u32(a.ptr(), o.ptr(), n + 1);
+        std::vector<u32> g = to_host(o, n + 1);
+        u32 acc = 0;
+        for (u64 i = 0; i <= n; i++) { if (g[i] != acc) throw DeviceError("primitives self-test: exclusive_scan_u32 differs at " + std::to_string(i)); acc += h32[i]; }
+        exclusive_scan_u64(a64.ptr(), o64.ptr(), n + 1);
+        std::vector<u64> g64 = to_host(o64, n + 1);
+        u64 acc64 = 0;
+        for (u64 i = 0; i <= n; i++) { if (g64[i] != acc64) throw DeviceError("primitives self-test: exclusive_scan_u64 differs at " + std::to_string(i)); acc64 += hk64[i]; }
+        if (n) {
+            inclusive_scan_u32(a.ptr(), o.ptr(), n);
+            g = to_host(o, n); acc = 0;
+            for (u64 i = 0; i < n; i++) { acc += h32[i]; if (g[i] != acc) throw DeviceError("primitives self-test: inclusive_scan_u32 differs at " + std::to_string(i)); }
+            inclusive_max_scan_u32(a.ptr(), o.ptr(), n);
+            g = to_host(o, n); acc = 0;
+            for (u64 i = 0; i < n; i++) { acc = std::max(acc, h32[i]); if (g[i] != acc) throw DeviceError("primitives self-test: inclusive_max_scan_u32 differs at " + std::to_string(i)); }
+            exclusive_scan_u32(a.ptr(), a.ptr(), n);      // in place
+            g = to_host(a, n); acc = 0;
+            for (u64 i = 0; i < n; i++) { if (g[i] != acc) throw DeviceError("primitives self-test: in-place scan differs at " + std::to_string(i)); acc += h32[i]; }
+        }
+    }
     stream_sync();
 }
 

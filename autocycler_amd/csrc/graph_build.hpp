@@ -169,6 +169,9 @@ struct VerifyReport {
 void verify_graph_device(const FinalGraph& g, const uint8_t* d_text, uint64_t n_text, const std::vector<uint64_t>& off,
                          const std::vector<uint32_t>& len, VerifyReport* rep);
 
+// device_prims.hpp against std:: on n pseudo-random items (tests); throws on a mismatch.
+void primitives_selftest(uint64_t n, uint64_t seed, int end_bit, int key_kind);
+
 // Measured ceilings of the device for random atomicCAS / random 8-byte reads on a 134 MB table, in 10^9 operations per second.
 void random_access_ceilings(double* cas_gops, double* read_gops, uint64_t table_slots = (uint64_t)1 << 24);
 

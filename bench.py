@@ -596,6 +596,7 @@ def main():
             "total_device_timed_ms": sum(t["total_device"] for t in tms_head) / len(tms_head) * 1e3,
             "step_ms_list": step_head,
             "step_ms": {"min": min(step_head), "median": sorted(step_head)[len(step_head) // 2], "max": max(step_head)},
+            "launches_per_build": tms[-1].get("launches"), "host_round_trips_per_build": tms[-1].get("readbacks"),
             "stages_s": stage, "stages_note": "from 2 extra untimed builds with per-stage stream syncs (total_device there includes them)",
             "graph": {**graph_info, "distinct_canonical": tms[-1]["n_distinct"],
                       "path_entries": tms[-1]["n_path_entries"], "table_capacity": tms[-1]["table_capacity"],

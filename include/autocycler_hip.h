@@ -129,6 +129,10 @@ int ac_verify_graph(const ac_graph* graph, const ac_seq_view* seqs, uint32_t n_s
 int ac_verify_graph_device(const ac_graph* graph, const void* d_text, uint64_t n_text, const uint64_t* seq_off, const uint32_t* seq_len,
                            uint32_t n_seqs, int device, ac_verify_report* report);
 
+/* Test hook: the library's own scan / radix sort / comparator sort kernels (csrc/device_prims.hpp) against the host's std:: algorithms on
+ * n pseudo-random items; key_kind 0 uniform, 1 few distinct values, 2 sorted, 3 reverse sorted, 4 one hot digit.  0 = equal. */
+int ac_selftest_primitives(int device, uint64_t n, uint64_t seed, int end_bit, int key_kind);
+
 /* The 2-bit packing the host entry applies before the upload (sequence.rs:39-48 validates the same alphabet): n_text bytes ->
  * (n_text + 31) / 32 words of 2-bit codes (A, C, G, T = 0..3, first base most significant) and as many 32-bit mask words
  * (bit i = byte i is not a base).  force_scalar != 0 selects the portable loop instead of the AVX2 / BMI2 one (both are

@@ -160,3 +160,14 @@ def test_verify_graph_accepts_oracle_equal_graphs(emu):
 def test_verify_graph_names_the_damage(emu):
     import verify_cases
     verify_cases.names_the_damage(emu)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4])
+def test_hand_written_primitives_equal_std(emu, kind):
+    # csrc/device_prims.hpp (scan with decoupled look-back, onesweep radix sort, merge sort by ranks) under the lockstep emulation: tile
+    # boundaries (2048 items per tile), end bits that are not a multiple of eight, duplicate-heavy keys (stability)
+    import ctypes as C
+    lib = _capi.load_library(emu)
+    for n in (0, 1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4096, 4097, 9999, 40_000):
+        for end_bit in ((64, 33, 8, 5) if n < 5000 else (64, 21)):
+            assert lib.ac_selftest_primitives(C.c_int(0), C.c_uint64(n), C.c_uint64(7 * n + kind), C.c_int(end_bit), C.c_int(kind)) == 0, (n, end_bit, lib.ac_last_error())

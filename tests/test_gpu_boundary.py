@@ -120,3 +120,12 @@ def test_verify_graph_names_the_damage(lib):
     # one flipped base, one dropped link, one swapped path entry, ... : each reported with its class; the graph holds again once restored
     import verify_cases
     verify_cases.names_the_damage(None)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4])
+def test_hand_written_primitives_equal_std(lib, kind):
+    # csrc/device_prims.hpp on the device: thousands of tiles in flight (the look-back chains), every key kind, odd end bits
+    import ctypes as C
+    for n in (0, 1, 257, 2048, 2049, 100_003, 1_000_000, 6_000_011):
+        for end_bit in ((64, 33, 5) if n < 200_000 else (64, 27)):
+            assert lib.ac_selftest_primitives(C.c_int(0), C.c_uint64(n), C.c_uint64(11 * n + kind), C.c_int(end_bit), C.c_int(kind)) == 0, (n, end_bit, lib.ac_last_error())

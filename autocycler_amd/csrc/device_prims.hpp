@@ -329,7 +329,11 @@ template <class V> inline void radix_sort_pairs_impl(DBuf<u64>& keys, DBuf<V>& v
     for (int p = 0; p < passes; p++) {
         const int bits_here = std::min(8, end_bit - begin_bit - 8 * p);
         launch_wave_kernel(radix_pass_kernel<V>, tiles, s, (const u64*)ka, (const V*)va, kb, vb, (u64)n, p, bits_here, begin_bit, (const u32*)hist.ptr(), state.ptr(),
+#ifdef AC_EMU
+                           ticket.ptr());      // (the emulation runs the workgroups one after the other, in any order AC_EMU_ORDER asks for: always by ticket)
+#else
                            tiles > RS_COLOCATED_TILES ? ticket.ptr() : (u64*)nullptr);
+#endif
         std::swap(ka, kb); std::swap(va, vb);
     }
     if (passes & 1) { keys = std::move(k2); vals = std::move(v2); }

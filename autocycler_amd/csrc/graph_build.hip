@@ -26,6 +26,12 @@
 #include <thread>
 #include <functional>
 #include <condition_variable>
+#include <mutex>
+#include <fcntl.h>
+#include <unistd.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "device_rt.hpp"
 
@@ -474,12 +480,64 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 // The packers write the codes straight into device memory (through the PCIe BAR, write-combined) instead of into a pinned ring a copy
 // engine then reads: 1 / 0 forces / forbids, otherwise on when the device says its whole memory is host-visible (hipDeviceAttributeIsLargeBar).
 [[maybe_unused]] static int upload_direct_mode() { const char* e = getenv("AC_UPLOAD_DIRECT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }
+#ifndef AC_EMU
+template <int UNUSED> __global__ void __launch_bounds__(256) bar_selftest_kernel(const u64* p, u64 n, u64* out) {
+    u64 acc = 0;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) acc += p[i] * (i + 1);
+    if (acc) atomicAdd((unsigned long long*)out, (unsigned long long)acc);
+}
+// ONE self-test per device before the packers are allowed to store into device memory: that the device reports a large BAR
+// does not promise that a hipMalloc pointer can be stored through from the host, nor that a kernel then sees what was stored.  The test
+// (a) asks the kernel whether the pointer is host-writable WITHOUT touching it (read(2) into it fails with EFAULT instead of a fault),
+// (b) stores a pattern through it the way the packers do (plain stores, store fence, one read back), (c) has a kernel on the device
+// checksum the buffer.  Any mismatch — or any HIP error — sends every build on this device through the pinned ring.
+static bool bar_selftest(int dev) {
+    const u64 n = (u64)1 << 17;      // 1 MB of words
+    u64* d = nullptr; u64* d_out = nullptr;
+    bool ok = false;
+    int fd = -1;
+    do {
+        if (hipSetDevice(dev) != hipSuccess) break;
+        if (hipMalloc((void**)&d, n * 8) != hipSuccess || hipMalloc((void**)&d_out, 8) != hipSuccess) break;
+        if (hipMemset(d, 0, n * 8) != hipSuccess || hipMemset(d_out, 0, 8) != hipSuccess || hipDeviceSynchronize() != hipSuccess) break;
+        fd = ::open("/dev/zero", O_RDONLY);
+        if (fd < 0) break;
+        if (::read(fd, (void*)d, 4096) != 4096 || ::read(fd, (void*)(d + n - 512), 4096) != 4096) break;      // EFAULT: not mapped for the host
+        u64 expect = 0;
+        for (u64 i = 0; i < n; i++) { const u64 v = (i * 0x9E3779B97F4A7C15ULL) | 1ULL; d[i] = v; expect += v * (i + 1); }
+#if defined(__x86_64__)
+        _mm_sfence();
+#endif
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        const volatile u64* back = d + (n - 1);
+        if (*back != (((n - 1) * 0x9E3779B97F4A7C15ULL) | 1ULL)) break;      // (a PCIe read does not pass the posted writes before it)
+        hipLaunchKernelGGL(bar_selftest_kernel<0>, dim3(256), dim3(256), 0, 0, (const u64*)d, n, d_out);
+        u64 got = 0;
+        if (hipGetLastError() != hipSuccess || hipMemcpy(&got, d_out, 8, hipMemcpyDeviceToHost) != hipSuccess) break;
+        ok = got == expect;
+    } while (false);
+    if (fd >= 0) ::close(fd);
+    (void)hipGetLastError();
+    if (d) (void)hipFree(d);
+    if (d_out) (void)hipFree(d_out);
+    if (getenv("AC_DEBUG_ARENA")) fprintf(stderr, "direct upload self-test on device %d: %s\n", dev, ok ? "passed" : "FAILED (the packed upload goes through the pinned ring)");
+    return ok;
+}
+#endif
 [[maybe_unused]] static bool upload_direct_for(int dev) {
 #ifndef AC_EMU
-    if (upload_direct_mode() >= 0) return upload_direct_mode() == 1;
-    int large_bar = 0;
-    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return large_bar != 0;
+    if (upload_direct_mode() == 0) return false;
+    if (upload_direct_mode() < 0) {
+        int large_bar = 0;
+        if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (!large_bar) return false;
+    }
+    // (forced on or offered by the device: either way only after the self-test, once per device and process)
+    static std::mutex mu; static std::map<int, bool> tested;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = tested.find(dev);
+    if (it == tested.end()) it = tested.emplace(dev, bar_selftest(dev)).first;
+    return it->second;
 #else
     (void)dev; return false;
 #endif
@@ -2246,6 +2304,7 @@ void GraphBuilder::Impl::UploadJob::run() {
 #if defined(__x86_64__)
                 _mm_sfence();
 #endif
+                std::atomic_thread_fence(std::memory_order_release);      // (hosts without sfence: at least the portable release fence)
                 if (ng) { const volatile u64* back = dst + (ng - 1); bar_sink.fetch_xor(*back, std::memory_order_relaxed); }
                 const u32 n_sub = (u32)((clen + SUB - 1) / SUB);
                 if (done[c].fetch_add(1, std::memory_order_acq_rel) + 1 == n_sub) {

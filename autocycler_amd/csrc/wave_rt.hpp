@@ -52,10 +52,9 @@ __device__ __forceinline__ void block_sync() { __syncthreads(); }
 namespace ac { namespace wv {
 enum { OP_NONE = 0, OP_BALLOT, OP_SHFL, OP_SHFL_XOR, OP_SHFL_UP, OP_SHFL_DOWN, OP_SYNC, OP_FIRST };
 // A fiber switch without system calls (glibc's swapcontext saves the signal mask: a syscall per switch, and a kernel makes several
-// switches per text position): the callee-saved registers and the stack pointer, x86-64 System V.  Test infrastructure only.
-#if !defined(__x86_64__)
-#error "the lockstep emulation's context switch is written for x86-64"
-#endif
+// switches per text position): the callee-saved registers and the stack pointer, x86-64 System V.  Other hosts (or -DAC_EMU_UCONTEXT, which
+// the suite uses to test this path on x86-64 too) fall back to <ucontext.h>: slower, portable.  Test infrastructure only.
+#if defined(__x86_64__) && !defined(AC_EMU_UCONTEXT)
 extern "C" void ac_emu_ctx_switch(void** save_sp, void* load_sp);
 #ifdef AC_EMU_DEFINE_CTX_SWITCH
 asm(R"(
@@ -81,8 +80,32 @@ ac_emu_ctx_switch:
 .size ac_emu_ctx_switch,.-ac_emu_ctx_switch
 )");
 #endif
+typedef void* ctx_t;
+inline void ctx_switch(ctx_t* save, ctx_t* load) { ac_emu_ctx_switch(save, *load); }
+// a fresh stack whose first switch-in "returns" into `entry`: six zero registers below the entry address, which sits at a 16-byte
+// boundary (so that `entry` starts with the stack alignment a call would have left)
+inline void ctx_make(ctx_t* c, char* lo, size_t bytes, void (*entry)()) {
+    char* top = (char*)((uintptr_t)(lo + bytes) & ~(uintptr_t)15);
+    void** sp = (void**)top;
+    *--sp = nullptr;                        // (where a return address of entry's caller would be: never used)
+    *--sp = (void*)entry;
+    for (int r = 0; r < 6; r++) *--sp = nullptr;
+    *c = sp;
+}
+#else
+} }
+#include <ucontext.h>
+namespace ac { namespace wv {
+typedef ucontext_t ctx_t;
+inline void ctx_switch(ctx_t* save, ctx_t* load) { swapcontext(save, load); }
+inline void ctx_make(ctx_t* c, char* lo, size_t bytes, void (*entry)()) {
+    getcontext(c);
+    c->uc_stack.ss_sp = lo; c->uc_stack.ss_size = bytes; c->uc_link = nullptr;
+    makecontext(c, entry, 0);
+}
+#endif
 struct Lane {
-    void* sp = nullptr;
+    ctx_t ctx{};
     bool done = true;
     int op = OP_NONE, scope = 0;      // scope: 64 = wavefront, G < 64 = lane group, 0 = workgroup (barrier)
     unsigned long long arg = 0, res = 0;
@@ -92,7 +115,7 @@ struct Block {
     std::vector<Lane> lanes;
     char* stacks = nullptr; size_t stacks_bytes = 0;      // (malloc: never zeroed — 32 MB per emulating thread)
     ~Block() { free(stacks); }
-    void* sched_sp = nullptr;
+    ctx_t sched{};
     unsigned n = 0, cur = 0, block_idx = 0;
     const std::function<void()>* body = nullptr;
     std::string error;
@@ -103,18 +126,20 @@ inline unsigned tid() { return blk().cur; }
 inline unsigned bid() { return blk().block_idx; }
 inline int lane() { return (int)(blk().cur & 63); }
 static const size_t STACK_BYTES = 128 << 10;
+static const size_t STACK_GUARD = 4096;
+static const unsigned long long STACK_CANARY = 0xAC57AC4B0F1BE255ULL;
 inline void lane_entry() {
     Block& b = blk();
     try { (*b.body)(); } catch (const std::exception& e) { if (b.error.empty()) b.error = e.what(); } catch (...) { if (b.error.empty()) b.error = "unknown exception in a kernel"; }
     b.lanes[b.cur].done = true;
-    ac_emu_ctx_switch(&b.lanes[b.cur].sp, b.sched_sp);      // never comes back
+    ctx_switch(&b.lanes[b.cur].ctx, &b.sched);      // never comes back
     abort();
 }
 inline unsigned long long wait_op(int op, int scope, unsigned long long arg, int src) {
     Block& b = blk();
     Lane& l = b.lanes[b.cur];
     l.op = op; l.scope = scope; l.arg = arg; l.src = src;
-    ac_emu_ctx_switch(&l.sp, b.sched_sp);
+    ctx_switch(&l.ctx, &b.sched);
     return l.res;
 }
 // Completes every operation whose participants have all arrived.  Returns whether anything was released.
@@ -159,8 +184,10 @@ inline bool resolve(Block& b) {
                         int src = op == OP_SHFL ? l.src : (op == OP_SHFL_XOR ? (int)((i - s0) ^ (unsigned)l.src) : (op == OP_SHFL_UP ? (int)(i - s0) - l.src : (int)(i - s0) + l.src));
                         const int width = (int)(s1 - s0);
                         if (op == OP_SHFL) src = ((src % width) + width) % width;
-                        const bool ok = src >= 0 && src < width && !b.lanes[s0 + (unsigned)src].done;
-                        l.res = ok ? b.lanes[s0 + (unsigned)src].arg : l.arg;      // (out of range / a lane that has returned: the own value, as the device's shuffles do)
+                        // out of range: the own value, as the device's shuffles do; a lane that has RETURNED is EXEC-disabled on the device and
+                        // ds_bpermute reads 0 from it — the emulation answers 0 too, so that a kernel relying on such a read fails here as there
+                        const bool in_range = src >= 0 && src < width;
+                        l.res = in_range ? (b.lanes[s0 + (unsigned)src].done ? 0ULL : b.lanes[s0 + (unsigned)src].arg) : l.arg;
                     }
                 }
                 for (unsigned i = s0; i < s1; i++) if (!b.lanes[i].done) b.lanes[i].op = OP_NONE;
@@ -182,15 +209,11 @@ inline void run_block(unsigned block_idx, unsigned threads, const std::function<
     for (unsigned i = 0; i < threads; i++) {
         Lane& l = b.lanes[i];
         l.done = false; l.op = OP_NONE;
-        // a fresh stack whose first switch-in "returns" into lane_entry: six zero registers below the entry address, which sits at a
-        // 16-byte boundary (so that lane_entry starts with the stack alignment a call would have left)
-        char* top = b.stacks + (size_t)(i + 1) * STACK_BYTES;
-        top = (char*)((uintptr_t)top & ~(uintptr_t)15);
-        void** sp = (void**)top;
-        *--sp = nullptr;                        // (where a return address of lane_entry's caller would be: never used)
-        *--sp = (void*)&lane_entry;
-        for (int r = 0; r < 6; r++) *--sp = nullptr;
-        l.sp = sp;
+        char* lo = b.stacks + (size_t)i * STACK_BYTES;
+        // the lowest STACK_GUARD bytes are not handed out: eight canary words right below the usable part (checked when the workgroup is
+        // done: a kernel whose locals outgrow the fiber's stack), the rest slack that keeps a small overrun off the neighbour's stack
+        for (int q = 1; q <= 8; q++) ((unsigned long long*)(lo + STACK_GUARD))[-q] = STACK_CANARY;
+        ctx_make(&l.ctx, lo + STACK_GUARD, STACK_BYTES - STACK_GUARD, &lane_entry);
     }
     for (;;) {
         bool alive = false, ran = false;
@@ -200,7 +223,7 @@ inline void run_block(unsigned block_idx, unsigned threads, const std::function<
             alive = true;
             if (l.op != OP_NONE) continue;
             b.cur = i;
-            ac_emu_ctx_switch(&b.sched_sp, l.sp);
+            ctx_switch(&b.sched, &l.ctx);
             ran = true;
         }
         if (!alive) break;
@@ -209,6 +232,10 @@ inline void run_block(unsigned block_idx, unsigned threads, const std::function<
         if (!ran && !released) { b.error = "lockstep emulation: deadlock (a cross-lane operation that not all of its lanes reach)"; break; }
     }
     tl_block() = prev;
+    if (b.error.empty())
+        for (unsigned i = 0; i < threads && b.error.empty(); i++)
+            for (int q = 1; q <= 8; q++)
+                if (((const unsigned long long*)(b.stacks + (size_t)i * STACK_BYTES + STACK_GUARD))[-q] != STACK_CANARY) { b.error = "lockstep emulation: a fiber overran its stack (kernel locals beyond " + std::to_string((STACK_BYTES - STACK_GUARD) >> 10) + " KB)"; break; }
     if (!b.error.empty()) {
         for (unsigned i = 0; i < threads; i++) b.lanes[i].done = true;
         throw std::runtime_error(b.error);
@@ -230,9 +257,20 @@ inline void block_sync() { wait_op(OP_SYNC, 0, 0, 0); }
 inline long long clock64() { return 0; }      // (the profiling variants of a kernel are never launched by the emulation)
 namespace ac { namespace wv {
 // hipLaunchKernelGGL for the emulation: the workgroups one after the other
+// AC_EMU_ORDER=1 / 2 (the order knob of the functor launcher, device_rt.hpp): the workgroups in descending / pseudo-random order, so that
+// the tests can check that no result of a wave kernel depends on which workgroup runs first
 template <class K, class... A> void launch_kernel(K kernel, unsigned blocks, unsigned threads, A... args) {
     const std::function<void()> body = [&] { kernel(args...); };
-    for (unsigned bi = 0; bi < blocks; bi++) run_block(bi, threads, body);
+    const char* now = getenv("AC_EMU_ORDER");      // (read per launch: the tests switch it between builds of one process)
+    const int ord = now ? atoi(now) : 0;
+    if (ord == 1) { for (unsigned bi = blocks; bi-- > 0;) run_block(bi, threads, body); }
+    else if (ord == 2) {
+        std::vector<unsigned> perm(blocks);
+        for (unsigned i = 0; i < blocks; i++) perm[i] = i;
+        unsigned long long st = 0x9E3779B97F4A7C15ULL ^ blocks;
+        for (unsigned i = blocks; i > 1; i--) { st = st * 6364136223846793005ULL + 1442695040888963407ULL; std::swap(perm[i - 1], perm[(st >> 33) % i]); }
+        for (unsigned i = 0; i < blocks; i++) run_block(perm[i], threads, body);
+    } else { for (unsigned bi = 0; bi < blocks; bi++) run_block(bi, threads, body); }
 }
 } }
 #endif

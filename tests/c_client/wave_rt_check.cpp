@@ -4,6 +4,7 @@
 #define AC_EMU_DEFINE_CTX_SWITCH
 #include "wave_rt.hpp"
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 using namespace ac;
 static int fails = 0;
@@ -44,10 +45,11 @@ int main() {
             for (int l = 0; l < live; l++) if (((w0 + l) % 3) == 0) bal |= 1ULL << l;
             CHECK(o.bal == bal);
             CHECK(o.first == (unsigned long long)(w0 + 7));
-            CHECK(o.sh == (5 < live ? (w0 + 5) * 3 + 1 : t * 3 + 1));
-            CHECK(o.sx == ((lane ^ 1) < live ? (w0 + (lane ^ 1)) * 3 + 1 : t * 3 + 1));
+            // a source lane that has RETURNED reads as 0 (EXEC-disabled on the device: ds_bpermute gives 0), one beyond the wavefront as the own value
+            CHECK(o.sh == (5 < live ? (w0 + 5) * 3 + 1 : 0));
+            CHECK(o.sx == ((lane ^ 1) < live ? (w0 + (lane ^ 1)) * 3 + 1 : 0));
             CHECK(o.su == (lane >= 2 ? (t - 2) * 3 + 1 : t * 3 + 1));
-            CHECK(o.sd == (lane + 3 < live ? (t + 3) * 3 + 1 : t * 3 + 1));
+            CHECK(o.sd == (lane + 3 < live ? (t + 3) * 3 + 1 : (lane + 3 < 64 ? 0 : t * 3 + 1)));
             CHECK(o.all_even);
             CHECK(o.nb == ((t + 1) % n_live) * 3 + 1);
             if ((t / 16) % 2 == 0) {
@@ -55,7 +57,7 @@ int main() {
                 unsigned long long gb = 0;
                 for (int l = 0; l < glive; l++) if ((g0 + l) & 1) gb |= 1ULL << l;
                 CHECK(o.gb == gb);
-                CHECK(o.gs == (3 < glive ? (g0 + 3) * 3 + 1 : t * 3 + 1));
+                CHECK(o.gs == (3 < glive ? (g0 + 3) * 3 + 1 : 0));
             }
         }
     bool caught = false;
@@ -65,6 +67,19 @@ int main() {
     std::vector<unsigned long long> joined(64);
     wv::launch_kernel(+[](unsigned long long* o) { unsigned long long g = 0; if (wv::tid() < 16) g = wv::grp_ballot<16>((wv::tid() & 3) == 0, 0); o[wv::tid()] = wv::ballot(wv::tid() >= 60) ^ g; }, 1, 64, joined.data());
     CHECK(joined[0] == (0xF000000000000000ULL ^ 0x1111ULL) && joined[40] == 0xF000000000000000ULL);
+    // a kernel whose locals outgrow the fiber's stack is reported (a canary below every stack), not left to corrupt the heap
+    caught = false;
+    try {
+        wv::launch_kernel(+[](int* sink) { volatile char big[(128 << 10) - 4096]; for (size_t i = 0; i < 512; i++) big[i] = (char)(i + 1);      /* exactly the usable stack: the frames above it push its low end into the guard */ sink[0] = big[1024] + (int)wv::ballot(true); }, 1, 64, (int*)joined.data());
+    } catch (const std::exception& e) { caught = true; printf("reported: %s\n", e.what()); }
+    CHECK(caught);
+    // the workgroup order knob of the launcher (AC_EMU_ORDER): every workgroup still runs exactly once
+    for (const char* ord : {"1", "2", "0"}) {
+        setenv("AC_EMU_ORDER", ord, 1);
+        std::vector<unsigned long long> seen(37);
+        wv::launch_kernel(+[](unsigned long long* o) { if (wv::tid() == 0) o[wv::bid()] += 1 + wv::bid(); }, 37, 64, seen.data());
+        for (unsigned b = 0; b < 37; b++) CHECK(seen[b] == 1 + b);
+    }
     // the runtime is usable after an error
     wv::launch_kernel(kern, 1, 256, out.data(), 256);
     CHECK(out[255].sh == 5 * 3 + 1 + 192 * 3);

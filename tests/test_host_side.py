@@ -39,10 +39,13 @@ def test_lockstep_emulation_of_the_wave_primitives(tmp_path):
     """autocycler_amd/csrc/wave_rt.hpp under AC_EMU — what lets the CPU suite run the SAME wave kernels the device runs — checked on its own:
     ballots, shuffles, a barrier over LDS, diverging lane groups, lanes that return early, a reported deadlock."""
     import subprocess
-    exe = tmp_path / "wave_rt_check"
-    subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-I", str(ROOT / "autocycler_amd" / "csrc"), str(ROOT / "tests" / "c_client" / "wave_rt_check.cpp"), "-o", str(exe)])
-    out = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert out.returncode == 0 and "wave_rt_check: OK" in out.stdout, out.stdout[-2000:]
+    # (twice: the hand-written x86-64 context switch, and the portable <ucontext.h> fallback other hosts get: -DAC_EMU_UCONTEXT)
+    for extra in ([], ["-DAC_EMU_UCONTEXT"]):
+        exe = tmp_path / ("wave_rt_check" + ("_uc" if extra else ""))
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", *extra, "-I", str(ROOT / "autocycler_amd" / "csrc"), str(ROOT / "tests" / "c_client" / "wave_rt_check.cpp"), "-o", str(exe)])
+        out = subprocess.run([str(exe)], capture_output=True, text=True)
+        assert out.returncode == 0 and "wave_rt_check: OK" in out.stdout, out.stdout[-2000:]
+        assert "overran its stack" in out.stdout
 
 
 def test_header_symbols_exported_by_product_library():

@@ -56,7 +56,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,
 EXPORTS = ["ac_compress_build", "ac_compress_build_multi", "ac_multi_info_get", "ac_compress_build_device", "ac_pack_text", "ac_text_size", "ac_layout_text", "ac_kmer_count",
            "ac_stats_pre", "ac_stats_post", "ac_unitig_count", "ac_unitig", "ac_unitigs_bulk", "ac_paths_bulk", "ac_unitig_positions", "ac_links",
            "ac_path", "ac_timings_get", "ac_timings_get_sized", "ac_free", "ac_gfa_string", "ac_string_free", "ac_last_error",
-           "ac_device_count", "ac_max_kmer", "ac_version", "ac_source_hash", "ac_set_stage_timing", "ac_random_access_ceilings", "ac_random_access_ceilings_at", "ac_release_memory", "ac_end_repair_device", "ac_pairwise_distances", "ac_selftest_primitives", "ac_verify_graph", "ac_verify_graph_device", "ac_graph_from_gfa", "ac_graph_kmer_size", "ac_graph_seq_info", "ac_decompress_seq", "ac_decompress",
+           "ac_device_count", "ac_max_kmer", "ac_version", "ac_source_hash", "ac_set_stage_timing", "ac_random_access_ceilings", "ac_random_access_ceilings_at", "ac_release_memory", "ac_end_repair_device", "ac_pairwise_distances", "ac_selftest_primitives", "ac_verify_graph", "ac_verify_graph_device", "ac_graph_from_gfa", "ac_graph_kmer_size", "ac_graph_seq_info", "ac_decompress_seq", "ac_decompress_device", "ac_decompress",
            "ac_shard_begin", "ac_shard_fragment_sizes", "ac_shard_fragments_export", "ac_shard_build_union", "ac_shard_fragment_packed_words", "ac_shard_fragments_export_packed", "ac_shard_build_union_packed",
            "ac_shard_unitig_count", "ac_shard_table_capacity", "ac_shard_bitmap_words", "ac_shard_bitmap_export", "ac_shard_build_novel", "ac_shard_sib_words", "ac_shard_sib_export", "ac_shard_degrees",
            "ac_shard_degree_bytes", "ac_multi_info_get_sized", "ac_shard_links_export", "ac_shard_links_import",
@@ -225,6 +225,21 @@ class Graph:
         buf = C.create_string_buffer(ln.value)
         _check(self._lib, self._lib.ac_decompress_seq(self._h, C.c_uint32(seq_index), buf))
         return buf.raw
+
+    def decompress_all(self, device=0):
+        """reconstruct_original_sequences for every sequence at once, on the device (ac_decompress_device) -> list of bytes."""
+        n = self._lib.ac_graph_seq_count(self._h)
+        lens = []
+        for i in range(n):
+            ln = C.c_uint32()
+            _check(self._lib, self._lib.ac_graph_seq_info(self._h, C.c_uint32(i), None, C.byref(ln), None, None))
+            lens.append(ln.value)
+        buf = C.create_string_buffer(max(sum(lens), 1))
+        _check(self._lib, self._lib.ac_decompress_device(self._h, C.c_int(device), buf, C.c_uint64(sum(lens))))
+        out, o = [], 0
+        for ln in lens:
+            out.append(buf.raw[o:o + ln]); o += ln
+        return out
 
     def pairwise_distances(self, device=0):
         """cluster.rs:132-157 -> S x S list of lists (row a, column b)."""

@@ -750,6 +750,21 @@ int ac_verify_graph(const ac_graph* g, const ac_seq_view* seqs, uint32_t n_seqs,
     });
 }
 
+// reconstruct_original_sequences for every sequence of the graph at once, on the device (kernels_verify.inc): out = sum of the sequence
+// lengths bytes, sequence i at offset sum(length[0 .. i)).  What ac_decompress_seq does one sequence at a time on the host.
+int ac_decompress_device(const ac_graph* g, int device, uint8_t* out, uint64_t out_bytes) {
+    return guarded([&] {
+        if (!g || !out) throw DeviceError("null pointer");
+        if (!g->host_arrays || !g->host_paths) throw DeviceError("this rank kept no host arrays (sharded build, not the writing rank)");
+        uint64_t need = 0;
+        for (uint32_t l : g->seq_lens) need += l;
+        if (out_bytes < need) throw DeviceError("ac_decompress_device: the buffer holds " + std::to_string(out_bytes) + " bytes, the sequences need " + std::to_string(need));
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
+        select_device(device);
+        decompress_device(g->g, g->seq_lens, out);
+    });
+}
 // The hand-written scan / radix sort / comparator sort (device_prims.hpp) against the host's std:: algorithms — test hook.
 int ac_selftest_primitives(int device, uint64_t n, uint64_t seed, int end_bit, int key_kind) {
     return guarded([&] {

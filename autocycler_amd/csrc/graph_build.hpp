@@ -169,6 +169,8 @@ struct VerifyReport {
 void verify_graph_device(const FinalGraph& g, const uint8_t* d_text, uint64_t n_text, const std::vector<uint64_t>& off,
                          const std::vector<uint32_t>& len, VerifyReport* rep);
 
+// reconstruct_original_sequences (unitig_graph.rs:362-400) for ALL sequences on the device: out_host holds sum(seq_len) bytes, sequence s behind s - 1.
+void decompress_device(const FinalGraph& g, const std::vector<uint32_t>& seq_len, uint8_t* out_host);
 // device_prims.hpp against std:: on n pseudo-random items (tests); throws on a mismatch.
 void primitives_selftest(uint64_t n, uint64_t seed, int end_bit, int key_kind);
 

@@ -574,15 +574,20 @@ def main():
         line = {
             "metric": "Mbp/sec through compress->unitig GFA (k=%d)" % k,
             "value": value, "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "ms_per_step_median": sorted(step_head)[len(step_head) // 2], "ms_per_step_max": max(step_head),
+            "value_from_median_step": total_bases / 1e3 / sorted(step_head)[len(step_head) // 2],
+            "value_note": "value / ms_per_step = the whole timed bracket (K steps between two barriers) / K, as the benchmark contract asks; the median and the slowest step beside it",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic" if not emu_lib else "emulation dry run (not a measurement)",
-            "config": {"workload": f"{args.assemblies} x ~{args.genome / 1e6:g} Mbp synthetic assemblies per GPU (+plasmid {args.plasmid} bp, "
-                                   f"sub {args.sub:g}, indel {args.indel:g}), k={k}, " +
-                                   ((f"1 species; {workload_label(args, k)}" if not named else f"named workload {args.workload} (autocycler_amd/synth.py WORKLOADS)") if world == 1 else
+            "config": {"workload": (f"{args.workload}: {_synth.WORKLOAD_NOTES.get(args.workload, 'a named workload')} (autocycler_amd/synth.py WORKLOADS; sub {args.sub:g}, indel {args.indel:g})"
+                                    if named else
+                                    f"{args.assemblies} x ~{args.genome / 1e6:g} Mbp synthetic assemblies per GPU (+plasmid {args.plasmid} bp, "
+                                    f"sub {args.sub:g}, indel {args.indel:g}), k={k}, " +
+                                   (f"1 species; {workload_label(args, k)}" if world == 1 else
                                     (f"ONE job of {world} species, one per GPU (mixed-species job as in BASELINE.json configs[4]; rank 0 holds "
                                      "exactly the N=1 workload, configs[2])" if (mode == "sharded" and args.species == "per-gpu") else
                                      f"ONE job of {world * args.assemblies} assemblies of one species" if mode == "sharded" else
-                                     f"{world} unrelated jobs of one species each")),
+                                     f"{world} unrelated jobs of one species each"))),
                        "bases_per_gpu": bases, "sequences_per_gpu": n, "mode": mode, "sharding": sharding,
                        "timed_region": ("SURVEY.md 8(d) T_hot: padded+repaired sequences in pageable host RAM -> final unitig graph in host RAM through "
                                         "ac_compress_build (host-side 2-bit pack, H2D, device build, D2H); the same region with the text already resident "
@@ -647,6 +652,13 @@ def main():
             "packed text (0.375 B per position) read on both sides of a followed run + one 64-byte slot line per distinct k-mer + the novel bitmap "
             "(1 bit per position)", pmc_of("insert_wave_kernel"), ins_ceiling)
         line["roofline"]["library_source_hash"] = lib_hash
+        if pj and pj.get("traffic_raw"):      # the raw counter, the streaming-calibrated upper bound and the factor actually applied
+            raw, x2 = pj["traffic_raw"], pj.get("traffic_streaming_x2") or pj["traffic_raw"]
+            line["roofline"]["traffic_raw"] = raw
+            line["roofline"]["traffic_streaming_x2"] = x2
+            line["roofline"]["fetch_factor_applied"] = pj.get("fetch_correction")
+            line["roofline"]["fetch_factor_calibration"] = pj.get("calibration_random") or "streaming (PackFunctor) only: no random-access calibration file for these sources"
+            line["roofline"]["frac_range"] = [raw / (ins_ms * 1e-3) / HBM_PEAK, x2 / (ins_ms * 1e-3) / HBM_PEAK]
         if pmc_note:
             line["roofline"]["traffic_note"] = pmc_note
         line["roofline"]["whole_path_equiv"] = {"bytes": alg_bytes, "B_per_bp": A_K(k), "frac_of_peak_over_the_whole_step": alg_bytes / (elapsed_head / args.steps) / HBM_PEAK,
@@ -724,21 +736,26 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             a, b2 = args.cpu_sample.split("x")
             sample = cpu_baseline(k, int(a), int(b2))      # timed now, on this box's host cores
+            # cpu_baseline.value = what was TIMED IN THIS RUN, on this box's host cores (the figure recorded elsewhere is context, under
+            # its own key; a speed-up quoted from `value` compares two clocks of one machine)
+            sample["host_threads_in_t_hot"] = int(os.environ.get("AC_UPLOAD_THREADS", "32"))      # the GPU path's T_hot packs the text with this many host threads; the CPU path's hot stages are single-threaded like the reference's
             line["cpu_baseline"] = sample
             gold = ROOT / "tests" / "golden" / (f"{args.workload}.json" if named else "configC_k51.json")      # the oracle on the WHOLE workload, run once where it was recorded
             if counted_workload and gold.exists():
                 try:
                     gj = json.loads(gold.read_text())
                     hot = gj["seconds"]["kmer_graph"] + gj["seconds"]["unitig_graph"] + gj["seconds"]["simplify"]
-                    # the figure of record is the whole workload's (the small sample has 4 copies of every k-mer instead of 96 and
-                    # understates the CPU path 1.8x); the sample timed in this run stays beside it, on this box's cores
-                    line["cpu_baseline"] = {
+                    md5_now = (t_hot or {}).get("gfa_md5")
+                    if md5_now is not None and not emu_lib and md5_now != gj["gfa_md5"]:
+                        raise SystemExit(f"this run's GFA md5 {md5_now} is not the oracle's full-size golden {gj['gfa_md5']} ({gold.name})")
+                    # (the small sample has 4 copies of every k-mer instead of 96 and understates the CPU path ~1.8x: the whole-workload figure,
+                    # recorded once on another host, stays beside it)
+                    line["cpu_baseline"]["recorded_whole_workload"] = {
                         "value": (487_499_962 if emu_lib else bases) / 1e6 / hot, "unit": "Mbp/s", "cores": 1, "kind": "port", "seconds": hot,
-                        "sample": f"the WHOLE workload ({args.workload or 'configC_k51: 96 x ~5 Mbp, k=51'}) through the C++ restatement of the reference CPU path, hot stages on 1 core "
-                                  "(the reference's are single-threaded): recorded once by tests/golden/make_configC_golden.sh on " +
-                                  gj.get("host", "the build container") + " (NOT timed in this run); its GFA md5 is the digest every "
-                                  "device build of this run produced",
-                        "gfa_md5": gj["gfa_md5"], "timed_in_this_run": sample}
+                        "what": f"the WHOLE workload ({args.workload or 'configC_k51: 96 x ~5 Mbp, k=51'}) through the C++ restatement of the reference CPU path, hot stages on 1 core: "
+                                "recorded once by tests/golden/make_configC_golden.sh on " + gj.get("host", "the build container") + " (NOT timed in this run)",
+                        "gfa_md5": gj["gfa_md5"],
+                        "gfa_md5_equals_this_runs": (md5_now == gj["gfa_md5"]) if md5_now is not None else None}
                 except (KeyError, ValueError, TypeError):
                     pass
         print(json.dumps(line))

@@ -129,6 +129,11 @@ int ac_verify_graph(const ac_graph* graph, const ac_seq_view* seqs, uint32_t n_s
 int ac_verify_graph_device(const ac_graph* graph, const void* d_text, uint64_t n_text, const uint64_t* seq_off, const uint32_t* seq_len,
                            uint32_t n_seqs, int device, ac_verify_report* report);
 
+/* reconstruct_original_sequences (unitig_graph.rs:362-400; decompress.rs:83-105) for ALL sequences of the graph on the device: sequence i lands
+ * at out[sum of the lengths before it ...]; out_bytes >= the sum of the lengths (ac_graph_seq_info).  ac_decompress_seq is the per-sequence
+ * host form. */
+int ac_decompress_device(const ac_graph*, int device, uint8_t* out, uint64_t out_bytes);
+
 /* Test hook: the library's own scan / radix sort / comparator sort kernels (csrc/device_prims.hpp) against the host's std:: algorithms on
  * n pseudo-random items; key_kind 0 uniform, 1 few distinct values, 2 sorted, 3 reverse sorted, 4 one hot digit.  0 = equal. */
 int ac_selftest_primitives(int device, uint64_t n, uint64_t seed, int end_bit, int key_kind);

@@ -29,6 +29,10 @@ def accepts_oracle_equal_graphs(lib_path, ks=(5, 11, 51), seeds=range(12)):
             rep = g.verify(triples)
             assert rep["failed"] == 0, (k, seed, rep)
             assert rep["bases_checked"] == sum(t[1] for t in triples) and rep["unitigs"] == g.unitig_count
+            # ... and the writing twin of the spelling check: every sequence decompressed on the device == the host's per-sequence form == the input
+            dec = g.decompress_all()
+            assert dec == [g.decompress(i) for i in range(len(triples))]
+            assert dec == [bytes(t[0])[k // 2:k // 2 + t[1]] for t in triples]
             assert rep["path_entries"] == sum(g.path_counts())
             # the same graph reloaded from its GFA text (ac_graph_from_gfa: what `autocycler cluster` / `decompress` start from)
             gfa = g.gfa([q["filename"] for q in loaded], [q["header"] for q in loaded])

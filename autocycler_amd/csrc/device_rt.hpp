@@ -27,6 +27,7 @@ namespace ac {
 
 struct DeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
 struct NeedExactPositions {};      // thrown by the tail, caught by GraphBuilder::build (graph_build.hip)
+struct NeedCheckedSorts {};        // ... a sort whose "group too large" flag was only looked at with the build's last read-back had it set: repeat, checking at once
 
 #ifndef AC_EMU
 #define AC_HIP_CHECK(expr)                                                                              \

@@ -347,10 +347,12 @@ int max_supported_k() { return 501; }   // the reference's own limit (compress.r
 // renumber_unitigs (unitig_graph.rs:295-315): stable sort of `order` by (length desc, sequence asc, depth desc).
 [[maybe_unused]] static bool renum_two_pass() { const char* e = getenv("AC_RENUM_TWO_PASS"); return e && atoi(e) != 0; }      // 1: always the two-pass renumber sort
 [[maybe_unused]] static u32 renum_max_group() { const char* e = getenv("AC_RENUM_MAX_GROUP"); int v = e ? atoi(e) : (int)RENUM_MAX_GROUP; return (u32)(v < 1 ? 1 : (v > (int)RENUM_MAX_GROUP ? (int)RENUM_MAX_GROUP : v)); }      // tests: smaller groups take the fallbacks
-[[maybe_unused]] static void renumber_sort(DBuf<u32>& order, u32 U, const u32* len, const u64* off, const u8* seq, const u32* depth, u32* flag) {
+// deferred: do not wait for the "group too large" flag (a host round trip per renumbering) — the caller reads it with the build's last
+// read-back and repeats the build with checked sorts if it was ever set (GraphBuilder::build; the flag is sticky then: never cleared here).
+[[maybe_unused]] static void renumber_sort(DBuf<u32>& order, u32 U, const u32* len, const u64* off, const u8* seq, const u32* depth, u32* flag, bool deferred = false) {
     if (U <= 1) return;
-    DBuf<u32> backup(U);
-    copy_d2d(backup.ptr(), order.ptr(), (size_t)U * 4);
+    DBuf<u32> backup(deferred && !renum_two_pass() ? 0 : U);      // (the order to fall back from: only a checked sort ever does)
+    if (backup.size()) copy_d2d(backup.ptr(), order.ptr(), (size_t)U * 4);
     DBuf<u64> prefix(U), key(U);
     launch(U, RenumKeyFunctor{len, off, seq, prefix.ptr()});
     UnitigLess less{len, off, seq, depth};
@@ -371,6 +373,7 @@ int max_supported_k() { return 501; }   // the reference's own limit (compress.r
                     (unsigned long long)members, (unsigned long long)biggest, (unsigned long long)longest, *flag);
         }
 #endif
+        if (deferred) return;
         if (!read_scalar(flag)) return;
         copy_d2d(order.ptr(), backup.ptr(), (size_t)U * 4);      // a large group of unitigs sharing length and 16 bases: the two-pass form
         copy_h2d(flag, &zero, 4);
@@ -561,6 +564,7 @@ static thread_local int tl_upload_threads_cap = 0;      // a rank of a multi-dev
 [[maybe_unused]] static bool seq_writer_forced() { const char* e = getenv("AC_SEQ_WRITER"); return e && atoi(e) == 1; }    // 1 = always the indexed / LDS-tiled writers
 [[maybe_unused]] static u64 seed_radix_limit() { const char* e = getenv("AC_SEED_RADIX_LIMIT"); return e ? (u64)atoll(e) : (1u << 19); }      // unitigs from which the seed order is a radix sort
 [[maybe_unused]] static bool upload_overlap() { const char* e = getenv("AC_UPLOAD_OVERLAP"); return e ? atoi(e) != 0 : true; }      // host entry: first insert phases while the upload's tail is in flight
+[[maybe_unused]] static bool sort_checks_deferrable() { const char* e = getenv("AC_SORT_CHECKS"); return !(e && atoi(e) == 1); }      // 1 = every "group too large" flag read where it is raised (round 4)
 [[maybe_unused]] static bool shard_host_remap() { const char* e = getenv("AC_SHARD_HOST_REMAP"); return e ? atoi(e) != 0 : true; }      // 0 = sharded builds renumber their paths on the device (round 4)
 [[maybe_unused]] static bool shard_degree_flags() { const char* e = getenv("AC_SHARD_DEGREE_FLAGS"); return e ? atoi(e) != 0 : true; }      // 0 = sharded builds probe every degree (round 4)
 [[maybe_unused]] static bool insert_adaptive() { const char* e = getenv("AC_INSERT_ADAPT"); return e ? atoi(e) != 0 : true; }
@@ -657,6 +661,11 @@ struct GraphBuilder::Impl {
     u32 pos_cap_now = 0xFFFFFFFFu; bool exact_positions = false;
     bool host_remap_allowed = false;      // GraphBuilder::build, and a rank of a sharded build that keeps its own paths: the result block of the paths is this build's own
     bool paths_in_seed_numbers = false;   // the tail left ent_val in seed numbers (the host renumbered the copy it took)
+    // single-device builds: the "group too large" flags of the seed sort and of the two renumberings are read with the build's LAST read-back
+    // (sort_flags: [0] seed ties, [1] renumbering) and a build that had one set is repeated with every flag checked where it is raised
+    bool checked_sorts = false; DBuf<u32> sort_flags;
+    bool deferred_sort_checks() const { return host_remap_allowed_build && !checked_sorts && sort_checks_deferrable(); }
+    bool host_remap_allowed_build = false;      // (GraphBuilder::build only: the one driver that can repeat a build)
     DBuf<u8> maybe_dest; bool maybe_dest_valid = false;      // (unitig, side) that may become an expand_repeats destination (walk's position filter)
     // fragments of a sharded build
     DBuf<u8> frag_text; DBuf<u64> frag_meta, frag_fpos, frag_boff; u64 frag_bytes = 0, n_frags = 0;      // (frag_text: only when someone asks for bytes)
@@ -667,6 +676,7 @@ struct GraphBuilder::Impl {
         rt_counters() = RtCounters();
         host_remap_allowed = false;      // (GraphBuilder::build switches it on for itself)
         counters.alloc(8); counters.fill_bytes(0);
+        sort_flags.alloc(2); sort_flags.fill_bytes(0);
     }
     void check_sizes(const PackedText& t) const {
         if (t.n_text >= POS_MASK) throw DeviceError("input too large for 40-bit text positions");
@@ -1188,13 +1198,15 @@ template <int W> void GraphBuilder::Impl::unitigs() {
         // MINIMUM towards small values): the ties are ranked on full keys anyway (SeedTieFunctor), and every digit less is a pass less
         int keep = seed_prefix_bits();
         if (keep <= 0) { int lg = 1; while ((1ULL << lg) < (u64)U) lg++; keep = std::min(64, ((2 * lg + 8 + 7) / 8) * 8); }
-        launch(U, SeedPrefixFunctor<W>{umin.ptr(), (int)k, wkey.ptr(), keep});
         DBuf<u32> by_prefix(U);
-        copy_d2d(by_prefix.ptr(), order.ptr(), (size_t)U * 4);
+        launch(U, SeedPrefixFunctor<W>{umin.ptr(), (int)k, wkey.ptr(), keep, by_prefix.ptr()});      // (... and the identity the sort permutes)
         sort_pairs_u64_u32(wkey, by_prefix, U, 64, 0, 64 - keep);
         DBuf<u32> settled(U), big(1, true);
-        launch(U, SeedTieFunctor<W>{by_prefix.ptr(), wkey.ptr(), U, umin.ptr(), settled.ptr(), seed_max_group(), big.ptr()});
-        if (read_scalar(big.ptr()) == 0) {
+        // (a single-device build does not wait for the "group too large" flag: it is read with the build's last read-back, and a build in
+        // which it was set is repeated with checked sorts — one host round trip less here, two in the renumberings)
+        const bool defer = deferred_sort_checks();
+        launch(U, SeedTieFunctor<W>{by_prefix.ptr(), wkey.ptr(), U, umin.ptr(), settled.ptr(), seed_max_group(), defer ? sort_flags.ptr() : big.ptr()});
+        if (defer || read_scalar(big.ptr()) == 0) {
             order = std::move(settled);
             DBuf<MinVal<W>> sorted(U);
             launch(U, GatherMinFunctor<W>{order.ptr(), umin.ptr(), sorted.ptr()});
@@ -1359,8 +1371,7 @@ template <int W> void GraphBuilder::Impl::walk() {
     pos_cap_now = (exact_positions || walk_answers || n_owners > 1 || G != &loc || pos_cap() == 0) ? 0xFFFFFFFFu : pos_cap();
     if (pos_cap_now == 0xFFFFFFFFu) { minpos_fwd.fill_bytes(0xFF); minpos_rev.fill_bytes(0xFF); }
     else {
-        launch(U, FillU32Functor{minpos_fwd.ptr(), (pos_cap_now + 1) | POS_BOUND});
-        launch(U, FillU32Functor{minpos_rev.ptr(), (pos_cap_now + 1) | POS_BOUND});
+        launch(U, FillU32PairFunctor{minpos_fwd.ptr(), minpos_rev.ptr(), (pos_cap_now + 1) | POS_BOUND});
     }
     path_off.alloc((u64)loc.n_seqs + 1);
     const bool filter = path_filter();
@@ -1456,17 +1467,16 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     DBuf<u32> order1(U);
     launch(U, IotaFunctor{order1.ptr()});
     DBuf<u32> renum_flag(1, true);
-    renumber_sort(order1, U, ulen.ptr(), useq_off.ptr(), useq.ptr(), depth.ptr(), renum_flag.ptr());
+    const bool defer_sorts = deferred_sort_checks();
+    renumber_sort(order1, U, ulen.ptr(), useq_off.ptr(), useq.ptr(), depth.ptr(), defer_sorts ? sort_flags.ptr() + 1 : renum_flag.ptr(), defer_sorts);
     lap(&tm->analysis);
 
     // K17 expand_repeats, level-scheduled (see the kernels)
     DBuf<u64> coff(U), len64((u64)U + 1), noff((u64)U + 1);
     DBuf<u32> clen(U), pre_off(U, true), pre_len(U, true), post_off(U, true), post_len(U, true);
-    copy_d2d(coff.ptr(), useq_off.ptr(), (size_t)U * 8);
-    copy_d2d(clen.ptr(), ulen.ptr(), (size_t)U * 4);
     DBuf<u8> seq_alt(total), pool(std::min<u64>(8 * total + (1u << 20), 0xFFFFFFF0ULL)), dirty((u64)U * 2);
     DBuf<u64> shifted(1); DBuf<u32> pool_used(EXP_SUBPOOLS + 1);
-    copy_d2d(dirty.ptr(), cand.ptr(), (size_t)U * 2);
+    launch(U, ExpInitFunctor{useq_off.ptr(), ulen.ptr(), cand.ptr(), coff.ptr(), clen.ptr(), dirty.ptr()});      // core views = the unitigs, dirty = the candidates (three copies, one launch)
     u8* cur = useq.ptr(); u8* alt = seq_alt.ptr();
     u64 final_total = total;
     int passes = 0;
@@ -1627,7 +1637,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     }
     DBuf<u32> order2(U);
     copy_d2d(order2.ptr(), order1.ptr(), (size_t)U * 4);
-    renumber_sort(order2, U, clen.ptr(), coff.ptr(), cur, depth.ptr(), renum_flag.ptr());
+    renumber_sort(order2, U, clen.ptr(), coff.ptr(), cur, depth.ptr(), defer_sorts ? sort_flags.ptr() + 1 : renum_flag.ptr(), defer_sorts);
     DBuf<u64> number_len(U), lcount((u64)U + 1), loff((u64)U + 1);
     DBuf<u32> number_only(host_remap ? U : 0);
     DBuf<u8> meta((size_t)U * 20);
@@ -1695,11 +1705,13 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     out->path_off.resize((size_t)n_seqs + 1);
     std::vector<u32> errs(8);
     u32 pack_bad[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+    u32 h_sort_flags[2] = {0, 0};
     {
         ReadBatch rb;
         rb.add(h_sums.data(), sums.ptr(), (size_t)n_seqs * 8);
         rb.add(out->path_off.data(), path_off.ptr(), ((size_t)n_seqs + 1) * 8);
         rb.add(errs.data(), counters.ptr(), 8 * 4);
+        rb.add(h_sort_flags, sort_flags.ptr(), 8);
         if (loc.check_alphabet && loc.pack_bad.size()) rb.add(pack_bad, loc.pack_bad.ptr(), 8);
         rb.run();                                   // synchronises stream 0 (once)
     }
@@ -1712,6 +1724,10 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     }
     if (loc.pack_bad.size()) loc.verify_alphabet(pack_bad);      // before any internal check: a text with foreign bytes explains them all
     if (errs[7] & 128u) throw NeedExactPositions();      // (before anything else: a repeat of the build settles it)
+    if (h_sort_flags[0] || h_sort_flags[1]) {
+        if (!deferred_sort_checks()) throw DeviceError("internal error: a sort flag was left set by a checked sort");
+        throw NeedCheckedSorts();      // (the order the flagged sort left is a permutation, not THE order: everything behind it is void)
+    }
     if (errs[7]) throw DeviceError("internal error: expand_repeats pool overflow");
     if (errs[3] || errs[4])
         throw DeviceError("internal error: inconsistent unitig ends (codes " + std::to_string(errs[3]) + "/" + std::to_string(errs[4]) + ")");
@@ -2540,7 +2556,7 @@ void GraphBuilder::build(uint32_t assembly_count_hint, FinalGraph* out) {
     Impl& m = *impl_;
     m.begin(&tm_);
     m.G = &m.loc;
-    m.host_remap_allowed = true;
+    m.host_remap_allowed = true; m.host_remap_allowed_build = true; m.checked_sorts = false;
     m.check_sizes(m.loc);
     m.pack_overlapped(assembly_count_hint);
     m.lap(&tm_.pack);
@@ -2553,6 +2569,18 @@ void GraphBuilder::build(uint32_t assembly_count_hint, FinalGraph* out) {
             AC_DISPATCH_W(walk, (*impl_))
             AC_DISPATCH_W(tail, (*impl_, out, true, true))
             break;
+        } catch (const NeedCheckedSorts&) {
+            // a deferred "group too large" flag was set (many unitigs sharing a key prefix): once more, every sort checked where it runs
+            if (m.checked_sorts) throw DeviceError("internal error: checked sorts left a flag");
+            m.checked_sorts = true;
+            {
+                BuildTimings again = BuildTimings();
+                again.h2d = tm_.h2d; again.pack = tm_.pack; again.graph_hint = tm_.graph_hint; again.position_retries = tm_.position_retries; again.sort_retries = tm_.sort_retries + 1;
+                tm_ = again;
+            }
+            stream_sync();
+            Arena::device().rewind(packed);
+            m.sort_flags.fill_bytes(0);
         } catch (const NeedExactPositions&) {
             // expand_repeats met a common sequence longer than the bound the walk kept for a destination's smallest position
             // (exp_avoid_start_of_path): everything behind the packed text again, with exact positions
@@ -2565,6 +2593,7 @@ void GraphBuilder::build(uint32_t assembly_count_hint, FinalGraph* out) {
             }
             stream_sync();
             Arena::device().rewind(packed);
+            m.sort_flags.fill_bytes(0);      // (a flag of the abandoned attempt must not repeat the next one)
         }
     }
 #ifndef AC_EMU

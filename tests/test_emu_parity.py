@@ -147,7 +147,7 @@ def test_high_diversity_table_growth(emu):
     assert time.time() - t0 < 60
 
 
-KNOB_SETTINGS = [{"AC_TABLE_SHIFT": "0"}, {"AC_TABLE_SHIFT": "2"}, {"AC_MINKEY_VARIANT": "0"}, {"AC_MINKEY_VARIANT": "1"}, {"AC_MINKEY_VARIANT": "2"}, {"AC_MINKEY_VARIANT": "2", "AC_MINKEY_PREFIX_BASES": "2"}, {"AC_PATH_CHUNK": "64"}, {"AC_PATH_FILTER": "0"}, {"AC_EXPAND_REWRITE_ALWAYS": "1"}, {"AC_SEED_RADIX_LIMIT": "0"}, {"AC_HOST_PACK": "0"}, {"AC_SEED_PREFIX_SORT": "0"}, {"AC_SEED_PREFIX_BITS": "3"}, {"AC_SEED_PREFIX_BITS": "12"}, {"AC_POS_CAP": "0"}, {"AC_POS_CAP": "3"}, {"AC_POS_CAP": "200", "AC_PATH_COPY": "1"}, {"AC_PATH_COPY": "1"}, {"AC_PATH_COPY": "1", "AC_RUN_PIECE": "150"}, {"AC_PATH_COPY": "1", "AC_PATH_FILTER": "0"}, {"AC_SEED_PREFIX_BITS": "3", "AC_SEED_MAX_GROUP": "2"}, {"AC_SEED_PREFIX_BITS": "6", "AC_SEED_MAX_GROUP": "1", "AC_SEED_RADIX_LIMIT": "1000000000"}, {"AC_SEED_PREFIX_SORT": "0", "AC_SEED_RADIX_LIMIT": "0"}, {"AC_RENUM_TWO_PASS": "1"}, {"AC_RENUM_MAX_GROUP": "1"}, {"AC_RENUM_MAX_GROUP": "2"}, {"AC_DEGREE_FLAGS": "0"}, {"AC_DEGREE_REGION_CAP": "1"}, {"AC_DEGREE_REGION_CAP": "3"}, {"AC_UPLOAD_THREADS": "3"},
+KNOB_SETTINGS = [{"AC_TABLE_SHIFT": "0"}, {"AC_TABLE_SHIFT": "2"}, {"AC_MINKEY_VARIANT": "0"}, {"AC_MINKEY_VARIANT": "1"}, {"AC_MINKEY_VARIANT": "2"}, {"AC_MINKEY_VARIANT": "2", "AC_MINKEY_PREFIX_BASES": "2"}, {"AC_PATH_CHUNK": "64"}, {"AC_PATH_FILTER": "0"}, {"AC_EXPAND_REWRITE_ALWAYS": "1"}, {"AC_SEED_RADIX_LIMIT": "0"}, {"AC_HOST_PACK": "0"}, {"AC_SEED_PREFIX_SORT": "0"}, {"AC_SEED_PREFIX_BITS": "3"}, {"AC_SEED_PREFIX_BITS": "12"}, {"AC_POS_CAP": "0"}, {"AC_POS_CAP": "3"}, {"AC_POS_CAP": "200", "AC_PATH_COPY": "1"}, {"AC_PATH_COPY": "1"}, {"AC_PATH_COPY": "1", "AC_RUN_PIECE": "150"}, {"AC_PATH_COPY": "1", "AC_PATH_FILTER": "0"}, {"AC_SEED_PREFIX_BITS": "3", "AC_SEED_MAX_GROUP": "2"}, {"AC_SEED_PREFIX_BITS": "6", "AC_SEED_MAX_GROUP": "1", "AC_SEED_RADIX_LIMIT": "1000000000"}, {"AC_SEED_PREFIX_SORT": "0", "AC_SEED_RADIX_LIMIT": "0"}, {"AC_RENUM_TWO_PASS": "1"}, {"AC_RENUM_MAX_GROUP": "1"}, {"AC_SORT_CHECKS": "1"}, {"AC_SORT_CHECKS": "1", "AC_RENUM_MAX_GROUP": "1"}, {"AC_RENUM_MAX_GROUP": "2"}, {"AC_DEGREE_FLAGS": "0"}, {"AC_DEGREE_REGION_CAP": "1"}, {"AC_DEGREE_REGION_CAP": "3"}, {"AC_UPLOAD_THREADS": "3"},
                  {"AC_REMAP_BLOCK": "128"}, {"AC_HOST_REMAP": "1"}, {"AC_HOST_REMAP": "1", "AC_UPLOAD_THREADS": "3"}, {"AC_HOST_REMAP": "0"}, {"AC_INSERT_ADAPT": "0", "AC_INSERT_GROWTH": "4"}, {"AC_INSERT_CHUNK": "256", "AC_INSERT_WAVES": "1024"}]
 
 
@@ -230,3 +230,30 @@ def test_seed_kernel_long_unitigs_across_wavefronts(emu, monkeypatch):
         monkeypatch.setenv("AC_MINKEY_VARIANT", variant)
         for k in (21, 51, 101):
             parity_util.check_case(k, [a, a, b], ["x.fasta", "y.fasta", "z.fasta"], ["a", "a2", "b"], lib_path=emu)
+
+
+def test_deferred_sort_flags_repeat_the_build(emu, monkeypatch):
+    """Round 5: a single-device build reads the "group too large" flags of the seed sort and of the two renumberings with its LAST read-back
+    (three host round trips less); a build in which one was set is repeated with checked sorts — forced here with tiny group limits."""
+    from autocycler_amd import synth
+    seqs, fn, hd = [], [], []      # (SNP alleles: unitigs that tie on length and their first bases)
+    for i, contigs in enumerate(synth.make_assemblies(4, genome=20_000, plasmid=2_000, sub=2e-3, indel=2e-4, seed=7)):
+        for header, sq in contigs:
+            seqs.append(sq.tobytes().decode()); fn.append(f"assembly_{i:04d}.fasta"); hd.append(header)
+    g, _, _ = parity_util.check_case(51, seqs, fn, hd, lib_path=emu)
+    assert g.timings()["sort_retries"] == 0
+    g.close()
+    for knobs in ({"AC_RENUM_MAX_GROUP": "1"}, {"AC_SEED_PREFIX_BITS": "3", "AC_SEED_MAX_GROUP": "1"}):
+        for kk, vv in knobs.items():
+            monkeypatch.setenv(kk, vv)
+        g, _, _ = parity_util.check_case(51, seqs, fn, hd, lib_path=emu)      # (== the oracle, byte for byte)
+        assert g.timings()["sort_retries"] == 1, knobs
+        g.close()
+        monkeypatch.setenv("AC_SORT_CHECKS", "1")
+        g, _, _ = parity_util.check_case(51, seqs, fn, hd, lib_path=emu)
+        assert g.timings()["sort_retries"] == 0
+        g.close()
+        monkeypatch.delenv("AC_SORT_CHECKS")
+        for kk in knobs:
+            monkeypatch.delenv(kk)
+

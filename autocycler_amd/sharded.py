@@ -179,17 +179,26 @@ def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False, 
                        "table_capacity": tmg["table_capacity"], "walk_queries": 0, "walk_queries_sent_away": 0,
                        "candidates": tmg["n_candidates"], "candidates_owned": tmg["n_candidates"], "direct": True}
     h = C.c_void_p()
-    _check(lib, lib.ac_shard_begin(C.c_uint32(shard.k), C.c_uint32(shard.local_assembly_count), C.c_void_p(shard.d_text.data_ptr()),
-                                   C.c_uint64(shard.n_text), shard.off, shard.lens, shard.ids, shard.d1, shard.d2,
-                                   C.c_uint32(shard.n_seqs), C.c_int(device_index), C.byref(h)))
+    # A rank whose slice is refused (foreign bytes in a sequence, a layout that does not add up: the user-facing failures of this phase) must
+    # not leave the others waiting in the first collective: its status travels with the fragment sizes, and every rank raises.
+    begin_rc = lib.ac_shard_begin(C.c_uint32(shard.k), C.c_uint32(shard.local_assembly_count), C.c_void_p(shard.d_text.data_ptr()),
+                                  C.c_uint64(shard.n_text), shard.off, shard.lens, shard.ids, shard.d1, shard.d2,
+                                  C.c_uint32(shard.n_seqs), C.c_int(device_index), C.byref(h))
+    begin_err = lib.ac_last_error().decode(errors="replace") if begin_rc else None
     try:
         # fragments of all ranks -> union text
         nb, nf = C.c_uint64(), C.c_uint64()
-        lib.ac_shard_fragment_sizes(h, C.byref(nb), C.byref(nf))
+        if not begin_rc:
+            lib.ac_shard_fragment_sizes(h, C.byref(nb), C.byref(nf))
         nb, nf = nb.value, nf.value
-        gathered = comm.all_gather_sizes([nf, nb, lib.ac_shard_local_distinct(h)])
-        sizes = [(f, b) for f, b, _ in gathered]
-        lib.ac_shard_set_distinct_upper_bound(h, C.c_uint64(sum(d for _, _, d in gathered)))
+        gathered = comm.all_gather_sizes([nf, nb, 0 if begin_rc else lib.ac_shard_local_distinct(h), 1 if begin_rc else 0])
+        failed = [r for r, row in enumerate(gathered) if row[3]]
+        if begin_rc:
+            raise _capi.AutocyclerError(begin_err)
+        if failed:
+            raise _capi.AutocyclerError(f"rank {failed[0]} of the sharded build failed in ac_shard_begin (its own exception says why)")
+        sizes = [(f, b) for f, b, _, _ in gathered]
+        lib.ac_shard_set_distinct_upper_bound(h, C.c_uint64(sum(d for _, _, d, _ in gathered)))
         # the fragment texts travel as 2-bit codes on the union text's word grid (a quarter of the bytes): [records | code words] per rank
         nf_total = sum(f for f, _ in sizes)
         nb_total = 1 + sum(b for _, b in sizes)
@@ -322,4 +331,5 @@ def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False, 
                        "table_capacity": table_capacity, "walk_queries": nq, "walk_queries_sent_away": queries_sent_away,
                        "candidates": candidates, "candidates_owned": candidates_owned}
     finally:
-        lib.ac_shard_free(h)
+        if h:
+            lib.ac_shard_free(h)

@@ -175,6 +175,9 @@ def main():
     ap.add_argument("--species", choices=["per-gpu", "one"], default="per-gpu",
                     help="sharded mode at N > 1: one species per GPU (mixed-species job, fixed work and output per GPU) or all "
                          "N x A assemblies of one species (path output grows with N^2)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default=None,
+                    help="N > 1: torch.distributed backend of the sharded job. nccl = RCCL over xGMI (default); gloo = the collectives staged through host "
+                         "memory — the verified fallback should inter-device RCCL misbehave on a box (no inter-device transfer has ever run: DESIGN.md 7)")
     ap.add_argument("--protocol-always", action="store_true",
                     help="sharded mode at N = 1: run every phase of the N-rank protocol (fragments, union text, second insert, ...) instead of handing "
                          "the job to the single-device build — what the protocol itself costs before a byte moves")
@@ -195,7 +198,7 @@ def main():
     # BENCH_BACKEND=gloo moves the collectives through the host (RCCL refuses two ranks on one device).
     if os.environ.get("BENCH_FORCE_DEVICE") is not None:
         local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
-    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    backend = args.backend or os.environ.get("BENCH_BACKEND", "nccl")
     # BENCH_EMU_LIB=<path of tests/_emu/libautocycler_emu.so>: dry run of THIS SCRIPT's plumbing (rank layout, collectives over gloo,
     # the JSON line) on the CPU emulation of the kernels — used by tests/test_host_side.py only; its numbers mean nothing and the
     # line says so ("data": "emulation dry run").  Without it the product library is loaded and a GPU is required.
@@ -574,6 +577,8 @@ def main():
         line = {
             "metric": "Mbp/sec through compress->unitig GFA (k=%d)" % k,
             "value": value, "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value_bracket": ("t_hot: host RAM -> host RAM through ac_compress_build" if headline_is_hot else
+                              "hbm_resident: text resident in HBM -> graph in host RAM (N > 1: the torch driver keeps the ranks' texts on their devices; --no-host-bracket)"),
             "ms_per_step": ms_per_step, "ms_per_step_median": sorted(step_head)[len(step_head) // 2], "ms_per_step_max": max(step_head),
             "value_from_median_step": total_bases / 1e3 / sorted(step_head)[len(step_head) // 2],
             "value_note": "value / ms_per_step = the whole timed bracket (K steps between two barriers) / K, as the benchmark contract asks; the median and the slowest step beside it",

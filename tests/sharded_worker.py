@@ -116,6 +116,30 @@ def main():
             partition_case(lib_path, dev, rank, world)
             done += 1
             continue
+        if case == "badinput":
+            # the LAST rank's slice holds a foreign byte: ac_shard_begin refuses it there — and every rank must raise, none may be left waiting in
+            # the first collective (the status travels with the fragment sizes: autocycler_amd/sharded.py)
+            from autocycler_amd import AutocyclerError
+            import oracle_lib as O
+            seqs, fn, hd = seqgen.make_case(3, 11)
+            loaded = O.Seqs.from_raw(11, seqs, filenames=fn, headers=hd).all()
+            b = sharded_util.slice_bounds(len(loaded), world)
+            part = [dict(q) for q in loaded[b[rank]:b[rank + 1]]]
+            if rank == world - 1:
+                fwd = bytearray(part[0]["fwd"]); fwd[len(fwd) // 2] = ord("N"); part[0]["fwd"] = bytes(fwd)
+            lib = sharded_util._capi.load_library(lib_path)
+            shard = sharded_util.local_shard(lib, 11, part, 0, len(part), 1, dev)
+            try:
+                sharded.sharded_build(lib, shard, sharded.Comm(dev), device_index=dev.index or 0)
+                raise SystemExit("a sharded build with a foreign byte in one slice went through")
+            except AutocyclerError as e:
+                msg = str(e)
+                assert ("non-ACGT" in msg) if rank == world - 1 else (f"rank {world - 1}" in msg), msg
+            # ... and the library is usable again on every rank
+            comm = sharded.Comm(dev)
+            sharded_util.run_case(lib_path, 11, seqs, fn, hd, comm, dev)
+            done += 1
+            continue
         if case.startswith("big:"):
             # a realistic-size job (too big for the oracle): the sharded result must equal the single-device build of the same
             # sequences, which the full-size property tests pin (tests/test_gpu_fullsize.py)

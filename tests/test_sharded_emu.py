@@ -122,6 +122,12 @@ def test_phase_order_is_enforced(emu):
     compress_build(11, 1, [(q["fwd"], q["length"], q["id"]) for q in loaded], lib_path=emu).close()      # and builds work again
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_refused_slice_fails_every_rank(emu, world):
+    # a rank that fails before the first collective must not leave its peers inside it
+    launch(world, emu, "cpu", "badinput", timeout=300)
+
+
 def test_three_ranks_medium_size_vs_single(emu):
     # the same comparison on the CPU emulation at a size it can do: 9 assemblies of 40 kbp over three ranks
     outs = launch(3, emu, "cpu", "big:9:40000")

@@ -83,7 +83,7 @@ from autocycler_amd import synth
 synth.write_fasta_dir(synth.WORKLOADS['configC_k51'][2](), '/dev/shm/ac_cli_in')"
            for i in 1 2 3; do rm -rf /dev/shm/ac_cli_out; t0=$(date +%s.%N)
              AC_DEBUG_WARM=1 ./autocycler_amd/autocycler-compress compress -i /dev/shm/ac_cli_in -a /dev/shm/ac_cli_out --kmer 51 -t 32 2>&1 | tail -20 | tr '\n' ';'
-             t1=$(date +%s.%N); echo " WALL $(echo "$t1 - $t0" | bc) s"; done > gpurun_out/${TAG}_cli_fresh_process.txt 2>&1
+             t1=$(date +%s.%N); echo " WALL $(python -c "print(round($t1 - $t0, 3))") s"; done > gpurun_out/${TAG}_cli_fresh_process.txt 2>&1
            cut -c1-900 gpurun_out/${TAG}_cli_fresh_process.txt; rm -rf /dev/shm/ac_cli_in /dev/shm/ac_cli_out ;;
     superkmer) hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/microbench/superkmer_bench.hip -o /tmp/superkmer_bench 2> gpurun_out/${TAG}_build.err || { tail -3 gpurun_out/${TAG}_build.err; continue; }
            python -c "

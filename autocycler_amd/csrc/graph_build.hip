@@ -559,6 +559,7 @@ static thread_local int tl_upload_threads_cap = 0;      // a rank of a multi-dev
 }   // host threads laying out / packing the text (the byte upload uses at most 8)
 [[maybe_unused]] static bool host_pack() { const char* e = getenv("AC_HOST_PACK"); return e ? atoi(e) != 0 : true; }      // 0: upload the text as bytes and pack on the device
 [[maybe_unused]] static bool insert_profile() { static const bool v = getenv("AC_INSERT_PROFILE") != nullptr; return v; }      // measurement only
+[[maybe_unused]] static u32 expand_level_table() { const char* e = getenv("AC_EXPAND_LEVEL_TABLE"); int v = e ? atoi(e) : 1024; return (u32)(v < 1 ? 1 : v); }      // tests: a table too small for the levels
 [[maybe_unused]] static bool expand_rewrite_always() { return getenv("AC_EXPAND_REWRITE_ALWAYS") != nullptr; }      // tests: compact the expand pool after every host check
 [[maybe_unused]] static bool seq_writer_plain() { const char* e = getenv("AC_SEQ_WRITER"); return e && atoi(e) == 0; }      // 0 = always the search-per-thread writers
 [[maybe_unused]] static bool seq_writer_forced() { const char* e = getenv("AC_SEQ_WRITER"); return e && atoi(e) == 1; }    // 1 = always the indexed / LDS-tiled writers
@@ -793,8 +794,13 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
     c <<= shift;
     // the capacity the previous build of a text of this very size ended with (a process that builds the same job again, or a
     // stream of similar jobs, does not pay for the overflow retries twice)
-    static thread_local u64 memo_n_text = 0, memo_cap = 0; static thread_local u32 memo_k = 0; static thread_local int memo_shift = -2;      // (a capacity is a number, not memory: valid on any device)
-    if (pt.n_text == memo_n_text && k == memo_k && memo_shift == table_shift() && memo_cap > c) c = memo_cap;
+    // (four texts remembered, not one: a sharded build inserts its local slice AND the union text, each with a size of its own — with one slot
+    // the two evicted each other and the local insert of a mixed-species job overflowed and started over in every build: E' 5.8 instead of 4.1 ms)
+    struct CapMemo { u64 n_text = 0, cap = 0; u32 k = 0; int shift = -2; u32 owners = 0; };
+    static thread_local CapMemo memo[4]; static thread_local unsigned memo_next = 0;      // (a capacity is a number, not memory: valid on any device)
+    const u32 memo_owners = (&pt == &uni) ? n_owners : 1u;
+    for (const CapMemo& m : memo)
+        if (pt.n_text == m.n_text && k == m.k && m.shift == table_shift() && m.owners == memo_owners && m.cap > c) c = m.cap;
     const int copy_mode = (want_sib && &pt == &loc) ? path_copy() : 0;      // (want_sib = the graph table of a single-device build)
     bool want_runs = false;
     DBuf<InsertStats> istats(257);       // [256].real doubles as the kernel's error word: one D2H reads everything
@@ -953,8 +959,13 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
     if (n_distinct >= 0xFFFFFFF0ULL) throw DeviceError("too many distinct k-mers for 32-bit novel indices");
     // the next build of this text: the capacity that worked — twice that if it ended more than half full (probe sequences at load 0.66
     // instead of 0.33 cost the insert 20-25 % and the probing stages after it as much: mini-E 19.3 -> 15.4 ms, E' 5.45 -> 4.45, r08k)
-    memo_n_text = pt.n_text; memo_k = k; memo_shift = table_shift();
-    memo_cap = (n_distinct * 2 > c && c * 2 <= next_pow2(pt.n_bases * 4 + 1024)) ? c * 2 : c;
+    {
+        CapMemo* slot = nullptr;
+        for (CapMemo& m : memo) if (m.n_text == pt.n_text && m.k == k && m.owners == memo_owners) slot = &m;
+        if (!slot) slot = &memo[memo_next++ % 4];
+        slot->n_text = pt.n_text; slot->k = k; slot->shift = table_shift(); slot->owners = memo_owners;
+        slot->cap = (n_distinct * 2 > c && c * 2 <= next_pow2(pt.n_bases * 4 + 1024)) ? c * 2 : c;
+    }
     *slots_out = std::move(sl);
     *cap_out = c;
     *n_distinct_out = n_distinct;
@@ -1525,7 +1536,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             while (level_bits < 32 && (max_level >> level_bits)) level_bits++;
             sort_pairs_u64_u32(lkey, clist, C, level_bits);      // (the highest level came back with the convergence flags: one or two digits)
             // first index of every level; [0] = number of levels (levels beyond the table: a second, exact read)
-            const u32 LV_TABLE = 1024;
+            const u32 LV_TABLE = expand_level_table();
             DBuf<u32> bstart((u64)LV_TABLE + 2);
             launch(C, LevelBoundsFunctor{lkey.ptr(), C, bstart.ptr(), LV_TABLE});
             std::vector<u32> hb = to_host(bstart, (u64)LV_TABLE + 2);
@@ -1558,18 +1569,18 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                 moved_since_rewrite = 0;
             };
             const u32 sub_limit = (u32)(pool.size() / 2 / EXP_SUBPOOLS / 2);      // a region half full (or anything in the overflow half) asks for a rewrite
+            auto run_level = [&](u32 lv) {
+                const u64 cnt = (u64)(hb[lv + 1] - hb[lv]);
+                // sixteen lanes per junction, four junctions per wavefront (expand_wave_kernel; the emulation runs the same kernel in
+                // lockstep, wave_rt.hpp).  A thread per junction and 8 / 32 / 64 lanes were measured and retired (r06u/v: G = 16
+                // wins from config C to mixed-species graphs)
+                if (cnt) launch_wave_kernel(expand_wave_kernel<W, 16>, (cnt * 16 + 255) / 256, 0, e, (const u32*)clist.ptr(), (u64)hb[lv], cnt, (u32)pool.size(), counters.ptr() + 7);
+            };
             for (;;) {   // two passes per host check: if the first moved nothing the second is an (uncounted) no-op
                 shifted2.fill_bytes(0);
                 for (int half = 0; half < 2; half++) {
                     e.shifted = shifted2.ptr() + half;
-                    for (u32 lv = 1; lv <= n_levels; lv++) {
-                        const u64 cnt = (u64)(hb[lv + 1] - hb[lv]);
-                        if (cnt == 0) continue;
-                        // sixteen lanes per junction, four junctions per wavefront (expand_wave_kernel; the emulation runs the same kernel in
-                        // lockstep, wave_rt.hpp).  A thread per junction and 8 / 32 / 64 lanes were measured and retired (r06u/v: G = 16
-                        // wins from config C to mixed-species graphs)
-                        launch_wave_kernel(expand_wave_kernel<W, 16>, (cnt * 16 + 255) / 256, 0, e, (const u32*)clist.ptr(), (u64)hb[lv], cnt, (u32)pool.size(), counters.ptr() + 7);
-                    }
+                    for (u32 lv = 1; lv <= n_levels; lv++) run_level(lv);
                 }
                 u64 sh[2]; u32 used = 0;
                 {
@@ -2616,7 +2627,7 @@ void GraphBuilder::shard_begin(uint32_t local_assembly_hint) {
     Impl& m = *impl_;
     m.begin(&tm_);
     m.check_sizes(m.loc);
-    m.loc.pack();
+    m.pack_overlapped(local_assembly_hint);      // (round 5: the tail of the pack under the first insert phase, like a single-device build)
     m.lap(&tm_.pack);
     AC_DISPATCH_W(fragments, (*impl_))
 }

@@ -139,7 +139,8 @@ def main():
                                   "build_ms": sorted(u[2] for u in upl)[len(upl) // 2]} if hviews is not None else {}),
                               "stages_ms": {a: round(b * 1e3, 3) for a, b in tm.items() if isinstance(b, float) and b > 2e-5 and a != "insert_kernel_ms"},
                               "table_capacity": tm["table_capacity"], "insert_launches": tm["insert_launches"], "launches": tm.get("launches"), "readbacks": tm.get("readbacks"), "unitigs": st["unitigs"], "gfa_md5": dg,
-                              "path_runs_copied": tm["path_runs_copied"], "path_entries_walked": tm["path_entries_walked"], "position_retries": tm["position_retries"]}), flush=True)
+                              "path_runs_copied": tm["path_runs_copied"], "path_entries_walked": tm["path_entries_walked"], "position_retries": tm["position_retries"],
+                              "expand": {q: tm[q] for q in ("n_candidates", "n_levels", "simplify_passes") if q in tm}}), flush=True)
         except Exception as e:      # a variant that fails must not take the others with it
             print(json.dumps({"variant": variant, "error": str(e)}), flush=True)
     lib.ac_seqs_free(h_seqs)

@@ -47,12 +47,12 @@ for STEP in "$@"; do
            timeout 600 python bench.py $WL --mode sharded --protocol-always --steps 10 --warmup 3 --no-e2e --no-cpu-baseline --pmc off > gpurun_out/${TAG}_bench_protocol_n1_${ARG:-configC}.json 2>> gpurun_out/${TAG}_bench.err; summ gpurun_out/${TAG}_bench_protocol_n1_${ARG:-configC}.json
            timeout 600 python bench.py $WL --mode sharded --steps 10 --warmup 3 --no-e2e --no-cpu-baseline --pmc off > gpurun_out/${TAG}_bench_sharded_direct_n1_${ARG:-configC}.json 2>> gpurun_out/${TAG}_bench.err; summ gpurun_out/${TAG}_bench_sharded_direct_n1_${ARG:-configC}.json ;;
     ab)    WL=""; [ -n "$ARG" ] && WL="--workload $ARG"
-           AC_NO_TORCH=1 timeout 600 python tools/ab_knobs.py $WL --steps 12 --variants "base;base" > gpurun_out/${TAG}_ab_${ARG:-configC}.jsonl 2>> gpurun_out/${TAG}.err
+           AC_NO_TORCH=1 timeout 600 python tools/ab_knobs.py $WL --steps 12 --variants "${AB_VARIANTS:-base;base}" > gpurun_out/${TAG}_ab_${ARG:-configC}.jsonl 2>> gpurun_out/${TAG}.err
            python - gpurun_out/${TAG}_ab_${ARG:-configC}.jsonl <<'PY'
 import json, sys
 for l in open(sys.argv[1]):
     j = json.loads(l)
-    if "variant" in j: print(j["variant"], "| ms", round(j.get("ms_median", 0), 3), "min", round(j.get("ms_min", 0), 3), "launches", j.get("launches"), "round trips", j.get("readbacks"), j.get("stages_ms"), j.get("gfa_md5", "")[:8], j.get("error", ""))
+    if "variant" in j: print(j["variant"], "| ms", round(j.get("ms_median", 0), 3), "min", round(j.get("ms_min", 0), 3), "launches", j.get("launches"), "round trips", j.get("readbacks"), j.get("stages_ms"), j.get("expand"), j.get("gfa_md5", "")[:8], j.get("error", ""))
 PY
            ;;
     calibrate) bash tools/pmc_calibrate_random.sh $TAG > gpurun_out/${TAG}_cal.log 2>&1; tail -6 gpurun_out/${TAG}_cal.log; cp gpurun_out/${TAG}_pmc_calibration_random.json profiles/pmc_calibration_random.json ;;

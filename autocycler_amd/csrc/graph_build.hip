@@ -1313,7 +1313,7 @@ template <int W> bool GraphBuilder::Impl::walk_copy(u32 PC) {
     // positions they cover and the number of walkers reach the host in ONE read-back
     const u64 Rb = R0 + loc.n_text / run_piece() + 1;
     DBuf<RunRec> rr(Rb); DBuf<u32> rseq(Rb);
-    launch(R0, RunCompactFunctor{fixed.ptr(), ok.ptr(), at.ptr(), rr.ptr(), run_piece(), fseq.ptr(), rseq.ptr()});
+    launch(R0, RunCompactFunctor{fixed.ptr(), ok.ptr(), at.ptr(), rr.ptr(), run_piece(), fseq.ptr(), rseq.ptr(), nv, loc.n_text});
     DBuf<u64> gw(Rb + 2), wfirst(Rb + 2);
     launch(Rb + 2, GapWalkersFunctor{rr.ptr(), at.ptr() + R0, loc.n_text, PC, gw.ptr()});
     exclusive_scan_u64(gw.ptr(), wfirst.ptr(), Rb + 2);

@@ -180,6 +180,29 @@ def test_insert_phase_schedule_on_a_redundant_text(emu, monkeypatch, adapt):
     assert g.timings()["insert_launches"] == (3 if adapt == "1" else 5)
 
 
+def test_copying_walk_on_a_job_of_two_species(emu, monkeypatch):
+    # Six assemblies of one genome, then six of another: the second species' FIRST assembly goes in with the one-launch rest of the
+    # insert, so its copies repeat text whose novel bits the same launch is still writing.  The insert takes those bits on trust
+    # (wave_match's nov_from; checking them ended every run after a few positions: benchjob8's insert 36 ms instead of 18) and the
+    # piece-by-piece filter of the copying walk settles them: the graph is the oracle's, and runs of BOTH species are copied.
+    from autocycler_amd import synth
+    monkeypatch.setenv("AC_PATH_COPY", "1")
+    seqs, fn, hd = [], [], []
+    for sp, seed in enumerate((4711, 4712)):
+        for i, contigs in enumerate(synth.make_assemblies(6, genome=70_000, plasmid=2_000, sub=3e-4, indel=3e-5, seed=seed)):
+            for header, s_ in contigs:
+                seqs.append(s_.tobytes().decode()); fn.append(f"species{sp}_{i:02d}.fasta"); hd.append(header)
+    n_a = sum(1 for f in fn if f.startswith("species0"))
+    for piece in ("4096", "300"):
+        monkeypatch.setenv("AC_RUN_PIECE", piece)
+        g, _, _ = parity_util.check_case(51, seqs, fn, hd, lib_path=emu)
+        tm = g.timings()
+        assert tm["insert_launches"] == 3 and tm["path_runs_copied"] > 0
+        one, _, _ = parity_util.check_case(51, seqs[:n_a], fn[:n_a], hd[:n_a], lib_path=emu)      # the first species alone
+        assert tm["path_runs_copied"] > 1.6 * one.timings()["path_runs_copied"] > 0
+    monkeypatch.delenv("AC_RUN_PIECE")
+
+
 @pytest.mark.parametrize("copy", ["0", "1"])
 def test_position_bound_and_the_repeat_with_exact_positions(emu, monkeypatch, copy):
     # The walk only notes smallest positions within AC_POS_CAP of a sequence end; beyond it expand_repeats sees a lower bound, and a

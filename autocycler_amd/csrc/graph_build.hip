@@ -549,7 +549,8 @@ static bool bar_selftest(int dev) {
 [[maybe_unused]] static int degree_flags() { const char* e = getenv("AC_DEGREE_FLAGS"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }      // 0: every degree by probing (what sharded builds and k < 3 do)
 [[maybe_unused]] static int table_shift() { const char* e = getenv("AC_TABLE_SHIFT"); if (!e) return -1; int v = atoi(e); return v < 0 ? 0 : (v > 3 ? 3 : v); }      // -1 = automatic
 [[maybe_unused]] static u64 wave_chunk_max() { const char* e = getenv("AC_INSERT_CHUNK"); u64 x = e ? (u64)atoll(e) : 8192; return (std::max<u64>(x, 256) + 63) & ~63ULL; }
-[[maybe_unused]] static u64 wave_chunk_rest() { return 16384; }   // longest chunk of the one-launch rest (r04c: 4096 / 8192 / 16384 = 0.90 / 0.84 / 0.82 ms)
+[[maybe_unused]] static u64 wave_chunk_rest() { return 16384; }   // longest chunk of the one-launch rest (r04c, config C: 4096 / 8192 / 16384 = 0.90 / 0.84 / 0.82 ms); shorter where the rest brings new content
+[[maybe_unused]] static u64 insert_chunk_rest_env() { const char* e = getenv("AC_INSERT_CHUNK_REST"); if (!e) return 0; return (std::max<u64>((u64)atoll(e), 256) + 63) & ~63ULL; }      // measurement / tests: the chunk of the rest, whatever the sample says   // longest chunk of the one-launch rest (r04c: 4096 / 8192 / 16384 = 0.90 / 0.84 / 0.82 ms)
 static thread_local int tl_upload_threads_cap = 0;      // a rank of a multi-device build: its share of the host's cores (0 = no cap)
 [[maybe_unused]] static u64 upload_threads() {
     const char* e = getenv("AC_UPLOAD_THREADS");
@@ -836,6 +837,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
         // goes in ONE launch (measured on config C: 0.89 ms against 1.06 ms for the eight doubling phases); a text that keeps
         // bringing new k-mers stays on the doubling schedule, which bounds the share of a phase that cannot follow runs.
         u32 launches = 0;
+        u64 rest_chunk = wave_chunk_rest();
         u64 first = std::max<u64>(p_end_all / hint, 1u << 16);
         u64 pb = 0;
         bool rest_at_once = false;
@@ -861,7 +863,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
             const u64 len = pe - pb;
             {      // one wavefront per chunk: >= ~16 K wavefronts when the phase is long
                 u64 c = (len / (diverse ? std::max<u64>(insert_waves_target(), 65536) : insert_waves_target()) + 63) & ~63ULL;      // (... cut into more wavefronts)
-                u32 chunk = (u32)std::min<u64>(std::max<u64>(c, 256), rest_at_once ? wave_chunk_rest() : wave_chunk_max());
+                u32 chunk = (u32)std::min<u64>(std::max<u64>(c, 256), rest_at_once ? rest_chunk : wave_chunk_max());
                 u64 n_waves = (len + chunk - 1) / chunk;
                 if (want_runs && rest_at_once) {
                     // the one-launch rest of a redundant text (with the host entry: its few pieces) notes the runs it follows, a row per
@@ -870,7 +872,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
                     if (!run_rows_cap) {
                         run_rows_cap = 2 * ((p_end_all - pb) / chunk + 1) + n_waves + 64;
                         // (a short first piece has a short chunk: never more than four times what the longest chunks would need)
-                        run_rows_cap = std::min<u64>(run_rows_cap, 4 * (pt.n_text / wave_chunk_rest() + 1) + n_waves + 1024);
+                        run_rows_cap = std::min<u64>(run_rows_cap, 4 * (pt.n_text / rest_chunk + 1) + n_waves + 1024);
                         runs.alloc(3 * run_rows_cap * RUN_ROW); run_count.alloc(run_rows_cap + 1);
                         run_count.fill_bytes(0);
                     }
@@ -905,10 +907,24 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
             pb = pe;
             phase_end.push_back(pe);
             if (launches == 2 && insert_adaptive() && pb < p_end_all && (p_end_all - pb) > 4 * first) {
-                std::vector<InsertStats> st2 = to_host(istats, 257);
+                // ... and a sample of the REST looked up in the table as it stands (the first two stretches): how much of what is still
+                // to come repeats them.  A rest of copies (one species: ~all found) goes in chunks of 16 K positions; a rest that brings
+                // new content of its own (more species behind the first: benchjob8 finds 1 in 8) in shorter ones — a launch keeps
+                // ~8 K wavefronts x chunk of text in flight, every copy of a new stretch inside that window inserts it for real, and
+                // the shorter chunk is the narrower window (benchjob8 16 K / 8 K / 4 K / 2 K: insert 18.2 / 14.7 / 12.2 / 11.9 ms; config C
+                // 1.24 / 1.25 / 1.32 / 1.44, D 10.1 / 10.3 / 11.1 / 12.2: r12v).  Same read-back as the claim counters.
+                DBuf<u32> probe(2);
+                probe.fill_bytes(0);
+                const u64 n_probe = std::min<u64>(32768, (p_end_all - pb) / 4096 + 1);
+                launch(n_probe, RestProbeFunctor<W>{t, tb, pb, p_end_all, (p_end_all - pb) / n_probe, probe.ptr()});
+                std::vector<InsertStats> st2(257); u32 h_probe[2] = {0, 0};
+                { ReadBatch rb; rb.add(st2.data(), istats.ptr(), 257 * sizeof(InsertStats)); rb.add(h_probe, probe.ptr(), 8); rb.run(); }
                 u64 claimed = 0;
                 for (size_t q = 0; q < 256; q++) claimed += st2[q].claimed;
                 if (st2[256].real == 0 && claimed * 4 <= first * 5) rest_at_once = true;      // <= 25 % of the second stretch was new
+                const double known = h_probe[0] ? (double)h_probe[1] / (double)h_probe[0] : 1.0;
+                rest_chunk = insert_chunk_rest_env() ? insert_chunk_rest_env() : (known >= 0.9 ? 16384 : known >= 0.6 ? 8192 : known >= 0.3 ? 4096 : 2048);
+                tm->insert_rest_known = known;
                 // ... and whether the path walk will copy the runs this launch follows (then it has to note them)
                 const double r2 = claimed > first ? (double)(claimed - first) / (double)first : 0.0;
                 want_runs = rest_at_once && (copy_mode == 1 || (copy_mode == 2 && path_copy_pays(pt.n_text, hint, k, r2)));

@@ -71,6 +71,7 @@ typedef struct {
     uint32_t readbacks;          /* host round trips of this build: small device -> host reads the host waited for */
     uint64_t n_degrees_open;     /* sharded builds: k-mers whose degrees the sibling bits did not settle (= bytes of the compact degree exchange) */
     uint64_t sort_retries;       /* builds repeated because a sort's "group too large" flag, read with the last read-back, was set */
+    double insert_rest_known;    /* share of a sample of the insert's one-launch rest that the first two stretches already held (sizes the rest's chunks); 0 = no such rest */
 } ac_timings;
 
 /* Replaces compress.rs:42-44.  k: --kmer (odd).  assembly_count: the reference's capacity hint

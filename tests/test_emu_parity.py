@@ -198,8 +198,11 @@ def test_copying_walk_on_a_job_of_two_species(emu, monkeypatch):
         g, _, _ = parity_util.check_case(51, seqs, fn, hd, lib_path=emu)
         tm = g.timings()
         assert tm["insert_launches"] == 3 and tm["path_runs_copied"] > 0
+        # the sample of the rest taken behind the second stretch: four of the ten assemblies still to come repeat the first species
+        assert 0.25 < tm["insert_rest_known"] < 0.6
         one, _, _ = parity_util.check_case(51, seqs[:n_a], fn[:n_a], hd[:n_a], lib_path=emu)      # the first species alone
         assert tm["path_runs_copied"] > 1.6 * one.timings()["path_runs_copied"] > 0
+        assert one.timings()["insert_rest_known"] > 0.9
     monkeypatch.delenv("AC_RUN_PIECE")
 
 

@@ -603,6 +603,9 @@ struct PackedText {
         for (u32 i = 0; i < n_seqs; i++) { n_bases += len[i]; if (d1[i] || d2[i]) { any_dots = 1; n_dotted++; } expected_nonbase += (u64)d1[i] + d2[i]; }
         stream_sync();
     }
+    // The table of a union text, built on the device (build_union_impl): the arrays are filled by the caller, the sums come with its read-back.
+    void alloc_table(u32 n) { n_seqs = n; h_off.clear(); h_len.clear(); seq_off.alloc(n); seq_len.alloc(n); seq_d1.alloc(n); seq_d2.alloc(n); seq_flags.alloc(n); has_flags = true; }
+    void set_sums(u64 bases, u64 dotted, u64 dots) { n_bases = bases; n_dotted = dotted; any_dots = dotted ? 1 : 0; expected_nonbase = (u64)n_seqs + 1 + dots; }
     TextCtx ctx(int k) const { return TextCtx{bits.ptr(), mask.ptr(), n_text, k, seq_off.ptr(), seq_len.ptr(), seq_d1.ptr(), seq_d2.ptr(), n_seqs}; }
     bool packed = false;      // the host entry packs chunk by chunk behind the upload (set_sequences_host)
     void pack_alloc(stream_t s = 0) {
@@ -2685,22 +2688,23 @@ void GraphBuilder::build_union_impl(uint32_t rank, uint32_t n_shards, const uint
     Impl& m = *impl_;
     m.t0 = now_s();
     if (n_frags_total == 0 || n_frags_total >= 0xFFFFFFF0ULL) throw DeviceError("invalid fragment count");
-    std::vector<u64> meta(n_frags_total);
-    copy_d2h(meta.data(), d_meta, n_frags_total * 8);
-    std::vector<uint64_t> off(n_frags_total); std::vector<uint32_t> len(n_frags_total);
-    std::vector<uint16_t> d1(n_frags_total), d2(n_frags_total); std::vector<uint8_t> flags(n_frags_total);
-    u64 p = 1;
-    for (u64 i = 0; i < n_frags_total; i++) {
-        u64 r = meta[i];
-        len[i] = (u32)r; d1[i] = (u16)((r >> 32) & 0xFF); d2[i] = (u16)((r >> 40) & 0xFF); flags[i] = (u8)((r >> 48) & 0xFF);
-        if (len[i] == 0) throw DeviceError("invalid fragment record");
-        off[i] = p;
-        p += (u64)len[i] + impl_->k;
+    {   // the fragment table of the union text: lengths, dots and flags from the records, offsets by a scan (UnionMetaFunctor)
+        PackedText& u = m.uni;
+        u.d_text = d_union_text;
+        u.n_text = n_union_text;
+        u.alloc_table((u32)n_frags_total);
+        DBuf<u64> ext(n_frags_total + 1), ext_scan(n_frags_total + 1), sums(4);
+        sums.fill_bytes(0);
+        ext.fill_bytes_from(n_frags_total * 8, 0);      // [n] = 0: the exclusive scan then ends with the total
+        launch_full(n_frags_total, UnionMetaFunctor{(const u64*)d_meta, n_frags_total, impl_->k, u.seq_len.ptr(), u.seq_d1.ptr(), u.seq_d2.ptr(), u.seq_flags.ptr(), ext.ptr(), sums.ptr()});
+        exclusive_scan_u64(ext.ptr(), ext_scan.ptr(), n_frags_total + 1);
+        launch(n_frags_total, UnionOffFunctor{ext_scan.ptr(), u.seq_off.ptr()});
+        u64 h_sums[4] = {0, 0, 0, 0}, h_total = 0;
+        { ReadBatch rb; rb.add(h_sums, sums.ptr(), 32); rb.add(&h_total, ext_scan.ptr() + n_frags_total, 8); rb.run(); }
+        if (h_sums[3]) throw DeviceError("invalid fragment record");
+        if (h_total + 1 != n_union_text) throw DeviceError("fragment records do not add up to the union text size");
+        u.set_sums(h_sums[0], h_sums[1], h_sums[2]);
     }
-    if (p != n_union_text) throw DeviceError("fragment records do not add up to the union text size");
-    m.uni.d_text = d_union_text;
-    m.uni.n_text = n_union_text;
-    m.uni.set_table(off, len, d1, d2, &flags);
     m.G = &m.uni;
     tm_.graph_hint = n_shards;
     if (d_union_text) m.uni.pack();

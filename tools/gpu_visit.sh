@@ -8,11 +8,12 @@
 #   prims             the hand-written scan / radix sort against std:: + the verifier tests  -> TAG_pytest_prims.log
 #   bench[:WORKLOAD]  bench.py (config C: 20 steps, e2e, cpu baseline; a named workload: 5-10 steps, no e2e)  -> TAG_bench_<workload>.json
 #   protocol[:WL]     bench.py --mode sharded --protocol-always at N = 1 beside the direct dispatch           -> TAG_bench_protocol_n1_*.json
-#   ab[:WORKLOAD]     tools/ab_knobs.py base;base (torch-free driver: stage table, launches, round trips, md5) -> TAG_ab_<workload>.jsonl
+#   ab[:WORKLOAD]     tools/ab_knobs.py base;base or $AB_VARIANTS (torch-free driver: stage table, launches, round trips, md5) -> TAG_ab_<workload>.jsonl
 #   calibrate         FETCH_SIZE / WRITE_SIZE per random access (tools/pmc_calibrate_random.sh)                -> TAG_pmc_calibration_random.json
 #   pmc[:WORKLOAD]    the two PMC passes + pmc_traffic json stamped with the source hash                       -> pmc_traffic[_WORKLOAD].json
 #   prof              rocprofv3 --kernel-trace --stats of bench.py (config C) and of the torch-free driver     -> TAG_kernel_stats_*.csv, TAG_timeline_driver_configC.txt
 #   multi             ac_compress_build_multi with 1 / 2 / 4 / 8 ranks sharing the device (bytes per exchange) -> TAG_multi_entry_one_device_configC.jsonl
+#   multijob          the same entry, the 8-species bench job over 8 ranks sharing the device                   -> TAG_multi_entry_one_device_benchjob8.jsonl
 #   cli               three fresh autocycler-compress processes on config C with the warm-up breakdown          -> TAG_cli_fresh_process.txt
 #   superkmer         tools/microbench/superkmer_bench.hip on E' and config B                                   -> TAG_superkmer_bench_*.jsonl
 export TMPDIR=/tmp
@@ -74,6 +75,14 @@ import json, sys
 for l in open(sys.argv[1]):
     j = json.loads(l); m = j.get("multi") or {}
     print({k: j.get(k) for k in ("variant", "ms_median", "gfa_md5") if k in j}, {k: v for k, v in m.items() if k.startswith("bytes_") or k in ("n_ranks", "transport", "degrees_open", "candidates_owned_max")})
+PY
+           ;;
+    multijob) AC_NO_TORCH=1 timeout 900 python tools/multi_bench.py --bench-job 8 --steps 2 --warmup 1 --worlds 8 > gpurun_out/${TAG}_multi_entry_one_device_benchjob8.jsonl 2>> gpurun_out/${TAG}_multi.err; echo "multijob exit $?"
+           python - gpurun_out/${TAG}_multi_entry_one_device_benchjob8.jsonl <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    j = json.loads(l); m = j.get("multi") or {}
+    print(j.get("variant"), "| ms", round(j.get("ms_median", 0), 1), "| received by one rank at most", m.get("bytes_received_max"), "| md5", j.get("gfa_md5", "")[:8])
 PY
            ;;
     cli)   python -c "

@@ -318,7 +318,7 @@ class MultiInfo(C.Structure):
                                           "bytes_reduce", "queries_total", "queries_sent_away", "table_capacity_max", "table_capacity_sum",
                                           "union_text_bytes", "fragments", "distinct")] + \
                [("seconds_total", C.c_double), ("seconds_exchange_max", C.c_double), ("candidates_total", C.c_uint64), ("candidates_owned_max", C.c_uint64),
-                ("bytes_sibling", C.c_uint64), ("bytes_tail", C.c_uint64), ("degrees_open", C.c_uint64), ("bytes_received_max", C.c_uint64)]
+                ("bytes_sibling", C.c_uint64), ("bytes_tail", C.c_uint64), ("degrees_open", C.c_uint64), ("bytes_received_max", C.c_uint64), ("path_runs_copied", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

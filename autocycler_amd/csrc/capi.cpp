@@ -276,6 +276,7 @@ int ac_multi_info_get(const ac_graph* g, ac_multi_info* o) {
     o->seconds_total = m.seconds_total; o->seconds_exchange_max = m.seconds_exchange_max;
     o->candidates_total = m.candidates_total; o->candidates_owned_max = m.candidates_owned_max;
     o->bytes_sibling = m.bytes_sibling; o->bytes_tail = m.bytes_tail; o->degrees_open = m.degrees_open; o->bytes_received_max = m.bytes_received_max;
+    o->path_runs_copied = m.path_runs_copied;
     return 0;
 }
 size_t ac_multi_info_get_sized(const ac_graph* g, ac_multi_info* out, size_t out_size) {

@@ -561,6 +561,7 @@ static thread_local int tl_upload_threads_cap = 0;      // a rank of a multi-dev
 [[maybe_unused]] static bool host_pack() { const char* e = getenv("AC_HOST_PACK"); return e ? atoi(e) != 0 : true; }      // 0: upload the text as bytes and pack on the device
 [[maybe_unused]] static bool insert_profile() { static const bool v = getenv("AC_INSERT_PROFILE") != nullptr; return v; }      // measurement only
 [[maybe_unused]] static u32 expand_level_table() { const char* e = getenv("AC_EXPAND_LEVEL_TABLE"); int v = e ? atoi(e) : 1024; return (u32)(v < 1 ? 1 : v); }      // tests: a table too small for the levels
+[[maybe_unused]] static bool shard_path_copy() { const char* e = getenv("AC_SHARD_PATH_COPY"); return !(e && atoi(e) == 0); }      // 0 = a sharded build walks all of its text (rounds 3-4)
 [[maybe_unused]] static bool expand_rewrite_always() { return getenv("AC_EXPAND_REWRITE_ALWAYS") != nullptr; }      // tests: compact the expand pool after every host check
 [[maybe_unused]] static bool seq_writer_plain() { const char* e = getenv("AC_SEQ_WRITER"); return e && atoi(e) == 0; }      // 0 = always the search-per-thread writers
 [[maybe_unused]] static bool seq_writer_forced() { const char* e = getenv("AC_SEQ_WRITER"); return e && atoi(e) == 1; }    // 1 = always the indexed / LDS-tiled writers
@@ -690,6 +691,12 @@ struct GraphBuilder::Impl {
     template <int W> void insert(const PackedText& t, u32 hint, DBuf<u64>* slots_out, u64* cap_out, u64* n_distinct_out, DBuf<u64>* bm_out, bool want_sib = false);
     DBuf<u64> sflags;          // sibling bits per slot, written by the insert (sib_note); empty = not collected
     DBuf<u64> runs; DBuf<u32> run_count; u64 run_rows = 0, run_rows_cap = 0;      // the insert's followed runs (Table::runs: rows used / reserved), for the copying path walk
+    // Sharded builds (round 5): the runs are those of the LOCAL insert, checked against the rank's own novel bitmap (a run's source must be
+    // a first occurrence within this rank's text: then it lies in walked text); loc_bm / loc_wprefix = that bitmap with rank support
+    DBuf<u64> loc_bm; DBuf<u32> loc_wprefix; bool local_insert_of_shard = false;
+    // The plan of a copying walk (walk_copy_prepare): the usable pieces, the gaps between them cut into walkers.  A sharded build makes it
+    // before the walk-start keys go to their owners (the walkers ARE the gap walkers then) and walks when the answers are back.
+    struct CopyPlan { bool ok = false; u64 R = 0, NW = 0, Rb = 0; DBuf<RunRec> rr; DBuf<u32> rseq; DBuf<u64> wfirst, w_begin, w_end; DBuf<u32> w_gap; } cplan;
     void occupancy_bitmap(const DBuf<u64>& sl, u64 c, DBuf<u64>* occ_out, const u64* sflags_in, u64* sib_out);
     DBuf<u64> occ;             // slot-occupancy bitmap of the graph table
     DBuf<u64> sib;             // sibling bits of the graph table's real k-mers, two per text position (MarkFunctor); empty = not used
@@ -769,7 +776,8 @@ struct GraphBuilder::Impl {
     const u64* walk_answers = nullptr;                  // sharded: [n_walkers | n_seqs] answers (0 = not found), nullptr = look the table up
     template <int W> void unitigs();                    // K6..K11 on G
     template <int W> void walk();
-    template <int W> bool walk_copy(u32 PC);            // K10c: false = not worth it (or not possible) for this text, nothing done
+    template <int W> bool walk_copy_prepare(u32 PC, const Novel& nv_text);   // K10c, first half: false = not worth it (or not possible) for this text, nothing kept
+    template <int W> void walk_copy_finish(u32 PC);                          // K10c, second half: the walk over the gaps and the copies
     template <int W> void tail(FinalGraph* out, bool want_graph, bool want_paths);
     // sharded builds: in-place all-reduce of a device buffer over the ranks (dtype 0 = uint8, 1 = int32; op 0 = SUM, 1 = MIN), given by
     // whoever drives the ranks.  With it the tail runs expand_repeats on this rank's share of the junctions only (conflict components,
@@ -805,7 +813,8 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
     const u32 memo_owners = (&pt == &uni) ? n_owners : 1u;
     for (const CapMemo& m : memo)
         if (pt.n_text == m.n_text && k == m.k && m.shift == table_shift() && m.owners == memo_owners && m.cap > c) c = m.cap;
-    const int copy_mode = (want_sib && &pt == &loc) ? path_copy() : 0;      // (want_sib = the graph table of a single-device build)
+    // (want_sib = the graph table of a single-device build; a sharded build's LOCAL insert notes its runs too: round 5)
+    const int copy_mode = (&pt == &loc && (want_sib || (local_insert_of_shard && shard_path_copy()))) ? path_copy() : 0;
     bool want_runs = false;
     DBuf<InsertStats> istats(257);       // [256].real doubles as the kernel's error word: one D2H reads everything
     DBuf<u64> sl;
@@ -824,7 +833,7 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
         u32* ierr = (u32*)&istats.ptr()[256].real;
         Table tb{sl.ptr(), c - 1, nullptr, nbm.ptr(), (&pt == &uni) ? n_owners : 1u, (&pt == &uni) ? my_owner : 0u, want_sib ? sflags.ptr() : nullptr,
                  &istats.ptr()[256].claimed, nullptr, nullptr, 0};
-        runs = DBuf<u64>(); run_count = DBuf<u32>(); run_rows = run_rows_cap = 0;
+        if (&pt == &loc) { runs = DBuf<u64>(); run_count = DBuf<u32>(); run_rows = run_rows_cap = 0; cplan = CopyPlan(); }      // (the union insert of a sharded build leaves the local insert's runs alone)
         phase_end.clear();
         stream_sync();
 #ifndef AC_EMU
@@ -1002,8 +1011,10 @@ inline void GraphBuilder::Impl::occupancy_bitmap(const DBuf<u64>& sl, u64 c, DBu
 
 // Sharded phase 1 (after the local insert): novel runs of this rank -> fragment text + one meta record per fragment.
 template <int W> void GraphBuilder::Impl::fragments() {
-    DBuf<u64> lslots, lbm; u64 lcap = 0, ln = 0;
+    DBuf<u64> lslots; DBuf<u64>& lbm = loc_bm; u64 lcap = 0, ln = 0;      // (the rank's novel bitmap is kept: the copying walk checks its runs against it)
+    local_insert_of_shard = true;
     insert<W>(loc, tm->local_hint, &lslots, &lcap, &ln, &lbm);
+    local_insert_of_shard = false;
     tm->n_local_distinct = ln;
     lap(&tm->insert);
     u64 nw = loc.n_text / 64 + 1;
@@ -1281,10 +1292,21 @@ template <int W> void GraphBuilder::Impl::unitigs() {
 // Sharded builds: the keys of this rank's walker starts (see WalkQueryFunctor), and the owned answers to a batch of such keys.
 template <int W> void GraphBuilder::Impl::walk_queries() {
     const u32 PC = path_chunk(N, U);
-    const u64 n_walkers = (loc.n_text + PC - 1) / PC;
+    u64 n_walkers = (loc.n_text + PC - 1) / PC;
+    // the copying walk for this rank's sequences (round 5): the local insert noted its runs; if enough of them repeat first occurrences of
+    // this rank's own text, the walkers are the gaps' walkers and only THEIR first k-mers are asked for
+    cplan = CopyPlan();
+    if (run_rows && loc_bm.size() && PC <= 65535) {
+        const u64 nw = loc.n_text / 64 + 1;
+        DBuf<u32> wcnt(nw);
+        loc_wprefix.alloc(nw);
+        launch(nw, PopcFunctor{loc_bm.ptr(), wcnt.ptr()});
+        exclusive_scan_u32(wcnt.ptr(), loc_wprefix.ptr(), nw);
+        if (walk_copy_prepare<W>(PC, Novel{loc_bm.ptr(), loc_wprefix.ptr()})) n_walkers = cplan.NW;
+    }
     n_queries = n_walkers + loc.n_seqs;
     qkeys.alloc(n_queries * W);
-    launch(n_queries, WalkQueryFunctor<W>{loc.ctx((int)k), PC, n_walkers, qkeys.ptr()});
+    launch(n_queries, WalkQueryFunctor<W>{loc.ctx((int)k), PC, n_walkers, qkeys.ptr(), cplan.ok ? cplan.w_begin.ptr() : nullptr});
 }
 // The queries in owner order (stable): d_routed_keys[i] = key of query qidx[i]; counts_host[o] = how many go to owner o.
 template <int W> void GraphBuilder::Impl::route_queries(u32 n_shards, u64* d_routed_keys, u64* counts_host) {
@@ -1310,11 +1332,11 @@ template <int W> void GraphBuilder::Impl::answer_queries(const u64* d_keys, u64 
 }
 
 // K10c: walk the text between the insert's followed runs, copy the runs' entries from the stretches they repeat (kernels_paths.inc).
-template <int W> bool GraphBuilder::Impl::walk_copy(u32 PC) {
+// First half: which pieces of the runs are usable (nv_text: the novel bitmap of the TEXT THE RUNS LIE IN — the graph's on a single device,
+// the rank's own in a sharded build), the gaps between them cut into walkers.  Everything it keeps is in `cplan`.
+template <int W> bool GraphBuilder::Impl::walk_copy_prepare(u32 PC, const Novel& nv_text) {
     TextCtx t = loc.ctx((int)k);
-    Table tb = graph_table();
-    Novel nv{bm.ptr(), wprefix.ptr()};
-    UnitigCtx uc{head.ptr(), scan.ptr(), rank.ptr(), uorient.ptr(), ustart.ptr(), ulen.ptr(), U, N};
+    cplan = CopyPlan();
     // the runs in text order: the rows of the insert's wavefronts one behind the other
     const Arena::Mark mk = Arena::device().mark();
     DBuf<u32> rfirst(run_rows + 1);
@@ -1326,24 +1348,41 @@ template <int W> bool GraphBuilder::Impl::walk_copy(u32 PC) {
     DBuf<u32> ok(R0 + 1), at(R0 + 1); DBuf<u64> covered(1, true); DBuf<u32> overlap(1, true);
     ok.fill_bytes(0);
     DBuf<RunRec> fixed(R0); DBuf<u32> fseq(R0);
-    launch(R0, RunFilterFunctor{sorted.ptr(), fixed.ptr(), R0, nv, loc.n_text, ok.ptr(), covered.ptr(), t, overlap.ptr(), run_piece(), fseq.ptr()});
+    launch(R0, RunFilterFunctor{sorted.ptr(), fixed.ptr(), R0, nv_text, loc.n_text, ok.ptr(), covered.ptr(), t, overlap.ptr(), run_piece(), fseq.ptr()});
     exclusive_scan_u32(ok.ptr(), at.ptr(), R0 + 1);
     // pieces, and the gaps between them cut into walkers — launched over a bound on the number of pieces, so that their number, the
     // positions they cover and the number of walkers reach the host in ONE read-back
     const u64 Rb = R0 + loc.n_text / run_piece() + 1;
-    DBuf<RunRec> rr(Rb); DBuf<u32> rseq(Rb);
-    launch(R0, RunCompactFunctor{fixed.ptr(), ok.ptr(), at.ptr(), rr.ptr(), run_piece(), fseq.ptr(), rseq.ptr(), nv, loc.n_text});
-    DBuf<u64> gw(Rb + 2), wfirst(Rb + 2);
-    launch(Rb + 2, GapWalkersFunctor{rr.ptr(), at.ptr() + R0, loc.n_text, PC, gw.ptr()});
-    exclusive_scan_u64(gw.ptr(), wfirst.ptr(), Rb + 2);
+    CopyPlan& c = cplan;
+    c.rr.alloc(Rb); c.rseq.alloc(Rb);
+    launch(R0, RunCompactFunctor{fixed.ptr(), ok.ptr(), at.ptr(), c.rr.ptr(), run_piece(), fseq.ptr(), c.rseq.ptr(), nv_text, loc.n_text});
+    DBuf<u64> gw(Rb + 2);
+    c.wfirst.alloc(Rb + 2);
+    launch(Rb + 2, GapWalkersFunctor{c.rr.ptr(), at.ptr() + R0, loc.n_text, PC, gw.ptr()});
+    exclusive_scan_u64(gw.ptr(), c.wfirst.ptr(), Rb + 2);
     u64 h_cov = 0, NW = 0; u32 h_R = 0, h_overlap = 0;
-    { ReadBatch rb; rb.add(&h_cov, covered.ptr(), 8); rb.add(&h_R, at.ptr() + R0, 4); rb.add(&h_overlap, overlap.ptr(), 4); rb.add(&NW, wfirst.ptr() + (Rb + 1), 8); rb.run(); }
+    { ReadBatch rb; rb.add(&h_cov, covered.ptr(), 8); rb.add(&h_R, at.ptr() + R0, 4); rb.add(&h_overlap, overlap.ptr(), 4); rb.add(&NW, c.wfirst.ptr() + (Rb + 1), 8); rb.run(); }
     const u64 R = h_R;
     if (getenv("AC_DEBUG_ARENA")) fprintf(stderr, "path copy: %llu runs on the list, %llu pieces usable, covering %llu of %llu positions, %llu walkers\n", (unsigned long long)R0, (unsigned long long)R, (unsigned long long)h_cov, (unsigned long long)loc.n_text, (unsigned long long)NW);
-    if (R == 0 || h_overlap || h_cov * 2 < loc.n_text) { Arena::device().rewind(mk); return false; }      // little to copy: the plain walk
-    if (NW == 0 || NW >= 0xFFFFFFF0ULL) { Arena::device().rewind(mk); return false; }
-    DBuf<u64> w_begin(NW), w_end(NW), wcount(NW + 1), woff(NW + 1); DBuf<u32> w_gap(NW);
-    launch(NW, WalkerRangeFunctor{rr.ptr(), R, loc.n_text, PC, wfirst.ptr(), w_begin.ptr(), w_end.ptr(), w_gap.ptr()});
+    if (R == 0 || h_overlap || h_cov * 2 < loc.n_text || NW == 0 || NW >= 0xFFFFFFF0ULL) {      // little to copy: the plain walk
+        cplan = CopyPlan();
+        Arena::device().rewind(mk);
+        return false;
+    }
+    c.w_begin.alloc(NW); c.w_end.alloc(NW); c.w_gap.alloc(NW);
+    launch(NW, WalkerRangeFunctor{c.rr.ptr(), R, loc.n_text, PC, c.wfirst.ptr(), c.w_begin.ptr(), c.w_end.ptr(), c.w_gap.ptr()});
+    c.R = R; c.NW = NW; c.Rb = Rb; c.ok = true;
+    return true;
+}
+// Second half: the gap walkers (their first lookups answered by the owners beforehand in a sharded build: walk_answers), then the copies.
+template <int W> void GraphBuilder::Impl::walk_copy_finish(u32 PC) {
+    TextCtx t = loc.ctx((int)k), g = G->ctx((int)k);
+    Table tb = graph_table();
+    Novel nv{bm.ptr(), wprefix.ptr()};
+    UnitigCtx uc{head.ptr(), scan.ptr(), rank.ptr(), uorient.ptr(), ustart.ptr(), ulen.ptr(), U, N};
+    CopyPlan& c = cplan;
+    const u64 R = c.R, NW = c.NW;
+    DBuf<u64> wcount(NW + 1), woff(NW + 1);
     const u64 n_slots = ((NW + 63) / 64) * 64 * PC;
     DBuf<int32_t> stage(n_slots); DBuf<u16> stage_off(n_slots);
     DBuf<u32> seq_tid(loc.n_seqs), seq_j(loc.n_seqs);
@@ -1352,19 +1391,19 @@ template <int W> bool GraphBuilder::Impl::walk_copy(u32 PC) {
     launch((u64)U * 10, WlinkFlagFunctor{filter ? maybe_dest.ptr() : nullptr, wlinks.ptr(), counters.ptr() + 4});
     DBuf<V16> uinfo(U);
     launch(U, WalkInfoFunctor{uc, filter ? maybe_dest.ptr() : nullptr, uinfo.ptr()});
-    launch(NW, PathWalkFunctor<W>{t, t, tb, nv, uc, uinfo.ptr(), wlinks.ptr(), PC, stage.ptr(), wcount.ptr(), seq_tid.ptr(), seq_j.ptr(),
+    launch(NW, PathWalkFunctor<W>{t, g, tb, nv, uc, uinfo.ptr(), wlinks.ptr(), PC, stage.ptr(), wcount.ptr(), seq_tid.ptr(), seq_j.ptr(),
                                  depth.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), counters.ptr() + 4, filter ? maybe_dest.ptr() : nullptr,
-                                 pos_cap_now, 0, nullptr, NW, w_begin.ptr(), w_end.ptr(), stage_off.ptr()});
+                                 pos_cap_now, 0, walk_answers, NW, c.w_begin.ptr(), c.w_end.ptr(), stage_off.ptr()});
     exclusive_scan_u64(wcount.ptr(), woff.ptr(), NW + 1);
     const u64 NE = read_scalar(woff.ptr() + NW);      // walked entries
     DBuf<int32_t> ent(NE); DBuf<u64> ent_pos(NE), ent_end(NE); DBuf<u8> ent_want(NE); DBuf<u32> ent_gap(NE);
-    launch_full(NW, WalkCompactFunctor{stage.ptr(), stage_off.ptr(), wcount.ptr(), woff.ptr(), w_begin.ptr(), w_gap.ptr(), PC, NW, ulen.ptr(),
+    launch_full(NW, WalkCompactFunctor{stage.ptr(), stage_off.ptr(), wcount.ptr(), woff.ptr(), c.w_begin.ptr(), c.w_gap.ptr(), PC, NW, ulen.ptr(),
                                        filter ? maybe_dest.ptr() : nullptr, ent.ptr(), ent_pos.ptr(), ent_end.ptr(), ent_want.ptr(), ent_gap.ptr()});
     // what every run copies; entries per segment; the final array
     DBuf<u64> ra(R), rcnt(R + 1), seg(2 * R + 2), segoff(2 * R + 2); DBuf<u32> cov(NE + 1), copies(NE + 1);
     cov.fill_bytes(0);
-    launch(R, RunRangeFunctor{rr.ptr(), ent_pos.ptr(), ent_end.ptr(), NE, ra.ptr(), rcnt.ptr(), cov.ptr()});
-    launch(2 * R + 2, SegCountFunctor{wfirst.ptr(), woff.ptr(), rcnt.ptr(), R, seg.ptr()});
+    launch(R, RunRangeFunctor{c.rr.ptr(), ent_pos.ptr(), ent_end.ptr(), NE, ra.ptr(), rcnt.ptr(), cov.ptr()});
+    launch(2 * R + 2, SegCountFunctor{c.wfirst.ptr(), woff.ptr(), rcnt.ptr(), R, seg.ptr()});
     exclusive_scan_u64(seg.ptr(), segoff.ptr(), 2 * R + 2);
     inclusive_scan_u32(cov.ptr(), copies.ptr(), NE + 1);
     n_ent = read_scalar(segoff.ptr() + (2 * R + 1));
@@ -1377,15 +1416,14 @@ template <int W> bool GraphBuilder::Impl::walk_copy(u32 PC) {
     // (the scratch above stays where it is until the build ends: for a text this redundant it is a fraction of the text's size)
     ent_val.alloc(n_ent);
     int32_t* const out_ptr = ent_val.ptr();
-    launch(NE, GapOutFunctor{ent.ptr(), ent_gap.ptr(), woff.ptr(), wfirst.ptr(), segoff.ptr(), copies.ptr(), out_ptr, depth.ptr()});
-    launch_full(R * 32, RunOutFunctor<32, 1>{rr.ptr(), R, ra.ptr(), rcnt.ptr(), segoff.ptr(), ent.ptr(), ent_pos.ptr(), ent_end.ptr(), ulen.ptr(),
-                                             ent_want.ptr(), t, rseq.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), out_ptr, pos_cap_now});
-    launch(loc.n_seqs, PathOffCopyFunctor{seq_tid.ptr(), seq_j.ptr(), woff.ptr(), wfirst.ptr(), w_gap.ptr(), segoff.ptr(), path_off.ptr()});
+    launch(NE, GapOutFunctor{ent.ptr(), ent_gap.ptr(), woff.ptr(), c.wfirst.ptr(), segoff.ptr(), copies.ptr(), out_ptr, depth.ptr()});
+    launch_full(R * 32, RunOutFunctor<32, 1>{c.rr.ptr(), R, ra.ptr(), rcnt.ptr(), segoff.ptr(), ent.ptr(), ent_pos.ptr(), ent_end.ptr(), ulen.ptr(),
+                                             ent_want.ptr(), t, c.rseq.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), out_ptr, pos_cap_now});
+    launch(loc.n_seqs, PathOffCopyFunctor{seq_tid.ptr(), seq_j.ptr(), woff.ptr(), c.wfirst.ptr(), c.w_gap.ptr(), segoff.ptr(), path_off.ptr()});
     tm->n_path_entries = n_ent;
     tm->path_runs_copied = R; tm->path_entries_walked = NE;
     copy_h2d(path_off.ptr() + loc.n_seqs, &n_ent, 8);
     launch(loc.n_seqs, PathEndsFunctor{ent_val.ptr(), path_off.ptr(), fs0.ptr(), fe0.ptr()});
-    return true;
 }
 
 // K10 paths of this rank's sequences against the graph: count, scan, write; first / last unitig of every path.
@@ -1408,7 +1446,9 @@ template <int W> void GraphBuilder::Impl::walk() {
     maybe_dest_valid = filter;
     if (filter) { maybe_dest.alloc((u64)U * 2); launch((u64)U * 2, MaybeDestFunctor{links.ptr(), maybe_dest.ptr()}); }
     fs0.alloc(U, true); fe0.alloc(U, true);
-    if (run_rows && !walk_answers && n_owners <= 1 && G == &loc && PC <= 65535 && walk_copy<W>(PC)) { lap(&tm->paths); return; }
+    if (walk_answers) {      // a sharded build planned (or not) before the walk-start keys went out (walk_queries)
+        if (cplan.ok) { walk_copy_finish<W>(PC); lap(&tm->paths); return; }
+    } else if (run_rows && n_owners <= 1 && G == &loc && PC <= 65535 && walk_copy_prepare<W>(PC, nv)) { walk_copy_finish<W>(PC); lap(&tm->paths); return; }
     // everything from here to the compaction is the walk's own: 4 bytes of staging per text position (configs[4]: 20 GB) go back to
     // the arena once the entries are compacted — they are compacted into the staging area's own first bytes
     const Arena::Mark walk_mark = Arena::device().mark();

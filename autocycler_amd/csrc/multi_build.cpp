@@ -444,6 +444,7 @@ void rank_main(Shared& S, int rank) {
         const uint64_t ar = (b.bitmap_words() * 8 + sib_words * 8 + deg_bytes + U * 40 + U * 20 + tail_bytes) * (uint64_t)(R - 1) / (uint64_t)R * 2;
         const uint64_t mine = others_frag + ar + q_recv_total * kw * 8 + sent_away * 8;
         st.bytes_received_max = std::max(st.bytes_received_max, mine);
+        st.path_runs_copied += b.timings().path_runs_copied;
     }
 }
 

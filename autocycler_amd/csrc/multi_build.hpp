@@ -26,6 +26,7 @@ struct MultiStats {
     uint64_t bytes_tail = 0;                                 // the tail's merge: field lengths + sequence bytes (all-reduces)
     uint64_t bytes_sibling = 0, degrees_open = 0;            // round 5: the sibling bits' exchange; k-mers the light degree step left to the probes
     uint64_t bytes_received_max = 0;                         // the most any one rank received over the whole build
+    uint64_t path_runs_copied = 0;                           // pieces of followed runs the ranks' copying walks copied instead of walking (0: every rank walked all of its text)
 };
 
 // seqs: all sequences of the job in input order; devices[r] = HIP ordinal of rank r (an ordinal may appear more than once: those ranks

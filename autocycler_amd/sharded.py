@@ -329,7 +329,8 @@ def sharded_build(lib, shard, comm, device_index=0, root=0, gather_paths=False, 
                 graph.n_seqs = n_total
         return graph, {"fragments": nf_total, "union_text_bytes": nb_total, "distinct": N, "unitigs": U, "comm_s": comm.seconds,
                        "table_capacity": table_capacity, "walk_queries": nq, "walk_queries_sent_away": queries_sent_away,
-                       "candidates": candidates, "candidates_owned": candidates_owned}
+                       "candidates": candidates, "candidates_owned": candidates_owned,
+                       "path_runs_copied_here": tmg["path_runs_copied"]}      # (this rank's copying walk: pieces of its followed runs it copied instead of walking)
     finally:
         if h:
             lib.ac_shard_free(h)

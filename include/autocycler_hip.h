@@ -103,6 +103,7 @@ typedef struct {
     uint64_t bytes_tail;         /* the partitioned tail's merges (field lengths, sequence bytes) */
     uint64_t degrees_open;       /* k-mers the light degree step left to the probes (bytes_degrees is their exchange) */
     uint64_t bytes_received_max; /* the most any ONE rank received from the others over the whole build */
+    uint64_t path_runs_copied;   /* pieces of followed runs the ranks' copying walks copied instead of walking (their local inserts note the runs; 0: all text walked) */
 } ac_multi_info;
 int ac_multi_info_get(const ac_graph*, ac_multi_info* out);
 /* The same for a caller compiled against an older header: at most out_size bytes are written (the struct only grows at its end); returns

@@ -46,6 +46,8 @@ def big_case(lib_path, n_asm, genome, dev, rank, world):
         assert g.stats_post == single.stats_post and g.kmer_count == single.kmer_count
         assert gfa_sharded == gfa_single, "sharded and single-device GFA differ"
         assert info["fragments"] > 2 * n and g.stats_post["unitigs"] > 10
+        if os.environ.get("AC_PATH_COPY") == "1" and os.environ.get("AC_SHARD_PATH_COPY") != "0":      # (test_copying_walk_over_gloo)
+            assert info["path_runs_copied_here"] > 0, info
         print(f"big case: {n} sequences, {g.stats_post['unitigs']} unitigs, {info['fragments']} fragments, union text {info['union_text_bytes']} bytes")
     dist.barrier()
 

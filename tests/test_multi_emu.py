@@ -143,3 +143,26 @@ def test_round5_protocol_knobs(emu, world, monkeypatch):
         assert 0 < info["bytes_received_max"] * world <= 2 * sum(info[x] for x in info if x.startswith("bytes_") and x != "bytes_received_max")
     M.adversarial(emu, [0] * world, ks=(11, 51), seeds=range(6))
 
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_copying_walk_of_the_ranks(emu, world, monkeypatch):
+    """Round 5: a rank's LOCAL insert notes the runs it follows, the rank checks them against its OWN novel bitmap and walks only the
+    gaps (the walk-start keys it sends to the owners are the gap walkers'); what it copies instead of walking shows in
+    ac_multi_info.path_runs_copied.  Same graph as with every rank walking all of its text (AC_SHARD_PATH_COPY=0) and as one device."""
+    monkeypatch.setenv("AC_MULTI_TRANSPORT", "host")      # (one rank: every phase of the protocol, not the direct dispatch)
+    monkeypatch.setenv("AC_PATH_COPY", "1")
+    # every rank's slice must be redundant in itself: 8 assemblies of 70 kbp per rank (the insert's one-launch rest needs > 4 x 64 K positions)
+    seqs, fn, hd = M.synth_case(8 * world, 70_000, 2_000, 3e-4, 3e-5, 11)
+    for piece in (None, "300"):
+        if piece: monkeypatch.setenv("AC_RUN_PIECE", piece)
+        gfa, info = M.run_case(emu, 51, seqs, fn, hd, [0] * world)
+        assert info["path_runs_copied"] > 0
+        monkeypatch.setenv("AC_SHARD_PATH_COPY", "0")
+        gfa_walk, info_walk = M.run_case(emu, 51, seqs, fn, hd, [0] * world)
+        monkeypatch.delenv("AC_SHARD_PATH_COPY")
+        assert gfa == gfa_walk and info_walk["path_runs_copied"] == 0
+        assert info["queries_total"] < info_walk["queries_total"]      # fewer walkers: only the gaps are walked
+    monkeypatch.delenv("AC_RUN_PIECE")
+    monkeypatch.delenv("AC_MULTI_TRANSPORT")
+    gfa_one, _ = M.run_case(emu, 51, seqs, fn, hd, [0])
+    assert gfa_one == gfa

@@ -37,6 +37,26 @@ def test_rccl_world_of_one(lib, monkeypatch):
     assert info["transport"] == 2 and info["queries_total"] > 0 and info["queries_sent_away"] == 0
 
 
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_copying_walk_of_the_ranks(lib, world, monkeypatch):
+    """Round 5 (tests/test_multi_emu.py has the same on the emulation): a rank's local insert notes its followed runs, the rank copies
+    their path entries instead of walking them — forced here (AC_PATH_COPY=1: the cost model only picks it for slices of config C's size,
+    where `bench.py --mode sharded --protocol-always` shows it).  Same graph as with AC_SHARD_PATH_COPY=0 and as one device."""
+    monkeypatch.setenv("AC_MULTI_TRANSPORT", "host")
+    seqs, fn, hd = M.synth_case(8 * world, 70_000, 2_000, 3e-4, 3e-5, 11)
+    monkeypatch.setenv("AC_PATH_COPY", "1")
+    gfa, info = M.run_case(None, 51, seqs, fn, hd, [0] * world)
+    assert info["path_runs_copied"] > 0
+    monkeypatch.setenv("AC_SHARD_PATH_COPY", "0")
+    gfa_walk, info_walk = M.run_case(None, 51, seqs, fn, hd, [0] * world)
+    monkeypatch.delenv("AC_SHARD_PATH_COPY")
+    assert gfa == gfa_walk and info_walk["path_runs_copied"] == 0 and info["queries_total"] < info_walk["queries_total"]
+    monkeypatch.delenv("AC_PATH_COPY")
+    monkeypatch.delenv("AC_MULTI_TRANSPORT")
+    gfa_one, _ = M.run_case(None, 51, seqs, fn, hd, [0])
+    assert gfa_one == gfa
+
+
 @pytest.mark.parametrize("world", [2, 3, 4])
 def test_ranks_sharing_the_device(lib, world):
     assert M.adversarial(None, [0] * world, ks=(11, 51), seeds=range(8)) == 2 * 8 * 2

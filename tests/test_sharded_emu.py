@@ -89,6 +89,14 @@ def test_many_ranks_gloo(emu, world):
     assert done >= 3, outs[0][-500:]
 
 
+def test_copying_walk_over_gloo(emu, monkeypatch):
+    # round 5: every rank copies the followed runs of its own slice instead of walking them (its local insert notes them, its own novel
+    # bitmap settles them); two processes over gloo, 8 redundant assemblies of 70 kbp each, result = the single-device build's
+    monkeypatch.setenv("AC_PATH_COPY", "1")
+    outs = launch(2, emu, "cpu", "big:16:70000", timeout=900)
+    assert "big case" in outs[0]
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_table_is_partitioned_over_the_ranks(emu, world):
     # per-rank table capacity ~ 1/N of the single-device one, result still byte-identical to the oracle

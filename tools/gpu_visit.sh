@@ -77,7 +77,7 @@ for l in open(sys.argv[1]):
     print({k: j.get(k) for k in ("variant", "ms_median", "gfa_md5") if k in j}, {k: v for k, v in m.items() if k.startswith("bytes_") or k in ("n_ranks", "transport", "degrees_open", "candidates_owned_max")})
 PY
            ;;
-    multijob) AC_NO_TORCH=1 timeout 900 python tools/multi_bench.py --bench-job 8 --steps 2 --warmup 1 --worlds 8 > gpurun_out/${TAG}_multi_entry_one_device_benchjob8.jsonl 2>> gpurun_out/${TAG}_multi.err; echo "multijob exit $?"
+    multijob) AC_NO_TORCH=1 timeout 900 python tools/multi_bench.py --workload benchjob8_k51 --steps 2 --warmup 1 --worlds 8 > gpurun_out/${TAG}_multi_entry_one_device_benchjob8.jsonl 2>> gpurun_out/${TAG}_multi.err; echo "multijob exit $?"
            python - gpurun_out/${TAG}_multi_entry_one_device_benchjob8.jsonl <<'PY'
 import json, sys
 for l in open(sys.argv[1]):

@@ -421,7 +421,7 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 //   AC_DEGREE_FLAGS   1 (default): degrees from the sibling bits the insert collects, probes only where they do not settle it (two
 //                     passes); 0: every degree by probing (what sharded builds and k < 3 do).
 //   AC_RENUM_TWO_PASS 1: renumber with two sorts (length | 32 bases | depth) instead of one (length | 16 bases); AC_RENUM_MAX_GROUP (tests).
-//   AC_UPLOAD_THREADS (32) / AC_HOST_PACK (1) / AC_UPLOAD_OVERLAP (1)   host entry: packing threads, 2-bit pack on the host, the
+//   AC_UPLOAD_THREADS (24) / AC_HOST_PACK (1) / AC_UPLOAD_OVERLAP (1)   host entry: packing threads, 2-bit pack on the host, the
 //                     insert issued chunk by chunk while background threads still pack and send the rest (0: everything is sent
 //                     before anything else is issued); AC_UPLOAD_SLOTS (tests: staging slots).
 //   AC_NO_MAILBOX     (read once) small read-backs through hipMemcpyAsync + synchronise instead of the mapped mailbox page.
@@ -554,7 +554,9 @@ static bool bar_selftest(int dev) {
 static thread_local int tl_upload_threads_cap = 0;      // a rank of a multi-device build: its share of the host's cores (0 = no cap)
 [[maybe_unused]] static u64 upload_threads() {
     const char* e = getenv("AC_UPLOAD_THREADS");
-    long x = e ? atol(e) : 32;
+    // 24 since round 5: 16 / 24 / 32 threads pack config C at the same median (5.9-6.0 ms per build, two 64-core sockets), but with 32 one step
+    // in twenty waits 10-20 ms for a straggler (unpinned threads on a shared host): mean 6.5-6.8 ms against 5.95-6.07 (r13b)
+    long x = e ? atol(e) : 24;
     if (tl_upload_threads_cap > 0 && x > tl_upload_threads_cap) x = tl_upload_threads_cap;
     return (u64)(x < 1 ? 1 : (x > 128 ? 128 : x));
 }   // host threads laying out / packing the text (the byte upload uses at most 8)

@@ -743,7 +743,7 @@ def main():
             sample = cpu_baseline(k, int(a), int(b2))      # timed now, on this box's host cores
             # cpu_baseline.value = what was TIMED IN THIS RUN, on this box's host cores (the figure recorded elsewhere is context, under
             # its own key; a speed-up quoted from `value` compares two clocks of one machine)
-            sample["host_threads_in_t_hot"] = int(os.environ.get("AC_UPLOAD_THREADS", "32"))      # the GPU path's T_hot packs the text with this many host threads; the CPU path's hot stages are single-threaded like the reference's
+            sample["host_threads_in_t_hot"] = int(os.environ.get("AC_UPLOAD_THREADS", "24"))      # the GPU path's T_hot packs the text with this many host threads; the CPU path's hot stages are single-threaded like the reference's
             line["cpu_baseline"] = sample
             gold = ROOT / "tests" / "golden" / (f"{args.workload}.json" if named else "configC_k51.json")      # the oracle on the WHOLE workload, run once where it was recorded
             if counted_workload and gold.exists():

@@ -1545,10 +1545,10 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
 
     // K17 expand_repeats, level-scheduled (see the kernels)
     DBuf<u64> coff(U), len64((u64)U + 1), noff((u64)U + 1);
-    DBuf<u32> clen(U), pre_off(U, true), pre_len(U, true), post_off(U, true), post_len(U, true);
+    DBuf<u32> clen(U); DBuf<ExpU> ev(U);      // the views of expand_repeats (one 32-byte record per unitig); coff / clen: offsets and lengths as plain arrays for what follows
     DBuf<u8> seq_alt(total), pool(std::min<u64>(8 * total + (1u << 20), 0xFFFFFFF0ULL)), dirty((u64)U * 2);
     DBuf<u64> shifted(1); DBuf<u32> pool_used(EXP_SUBPOOLS + 1);
-    launch(U, ExpInitFunctor{useq_off.ptr(), ulen.ptr(), cand.ptr(), coff.ptr(), clen.ptr(), dirty.ptr()});      // core views = the unitigs, dirty = the candidates (three copies, one launch)
+    launch(U, ExpInitFunctor{useq_off.ptr(), ulen.ptr(), cand.ptr(), ev.ptr(), coff.ptr(), clen.ptr(), dirty.ptr()});      // core views = the unitigs, dirty = the candidates (three copies, one launch)
     u8* cur = useq.ptr(); u8* alt = seq_alt.ptr();
     u64 final_total = total;
     int passes = 0;
@@ -1609,8 +1609,9 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             }
             hb.resize((size_t)n_levels + 2);
             hb[n_levels + 1] = (u32)C;
-            ExpState e{cur, coff.ptr(), clen.ptr(), pre_off.ptr(), pre_len.ptr(), post_off.ptr(), post_len.ptr(), pool.ptr(),
-                       pool_used.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), dirty.ptr(), cand.ptr(), L, shifted.ptr()};
+            DBuf<V16> touch(U);
+            launch(U, TouchFunctor{L, cand.ptr(), touch.ptr()});
+            ExpState e{cur, ev.ptr(), pool.ptr(), pool_used.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), dirty.ptr(), cand.ptr(), L, shifted.ptr(), touch.ptr()};
             pool_used.fill_bytes(0);
             u64 moved = 0, moved_since_rewrite = 0;
             DBuf<u64> shifted2(2);
@@ -1623,7 +1624,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                 exclusive_scan_u64(len64.ptr(), noff.ptr(), (u64)U + 1);
                 final_total = read_scalar(noff.ptr() + U);
                 write_seqs(1, &e, noff.ptr(), final_total, alt);
-                launch(U, ExpResetFunctor{e, noff.ptr()});
+                launch(U, ExpResetFunctor{e, noff.ptr(), coff.ptr(), clen.ptr()});
                 std::swap(cur, alt);
                 e.cur = cur;
                 pool_used.fill_bytes(0);
@@ -1687,7 +1688,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                 launch((final_total + per - 1) / per, MergeSeqFunctor{e, fown.ptr(), gpre.ptr(), gpost.ptr(), my_owner, lens3.ptr(), noff.ptr(), U, final_total, alt, per});
                 stream_sync();
                 tail_xchg(alt, final_total, 0, 0);
-                launch(U, ExpResetFunctor{e, noff.ptr()});
+                launch(U, ExpResetFunctor{e, noff.ptr(), coff.ptr(), clen.ptr()});
                 std::swap(cur, alt);
                 e.cur = cur;
             }

@@ -1583,8 +1583,8 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                 gpre.alloc(U, true); gpost.alloc(U, true);
             }
             u32 max_level = 1;
-            for (;;) {   // longest-path levels of the conflict DAG by relaxation (monotone, so stale reads only delay); eight
-                changed.fill_bytes(0);       // sweeps per host check, converged when the last of them changed nothing
+            for (;;) {   // longest-path levels of the conflict DAG, settled front to back (LevelRelaxFunctor); eight sweeps per host
+                changed.fill_bytes(0);       // check, done when the last of them left no candidate open (a sweep settles one more level)
                 for (int it = 0; it < 8; it++)
                     launch(C, LevelRelaxFunctor{preds.ptr(), npred.ptr(), C, level.ptr(), changed.ptr() + it, it ? changed.ptr() + it - 1 : nullptr, changed.ptr() + 8});
                 const std::vector<u32> hc = to_host(changed, 9);

@@ -1287,7 +1287,9 @@ template <int W> void GraphBuilder::Impl::unitigs() {
 
     // K11 links by successor symbol
     links.alloc((u64)U * 10); wlinks.alloc((u64)U * 10);
-    launch((u64)U * 2, LinksFunctor<W>{t, tb, nv, uc, order.ptr(), npos.ptr(), g.any_dots, links.ptr(), wlinks.ptr(), counters.ptr() + 3});
+    DBuf<V16> ui(U);      // (16 bytes per unitig; the walk builds its own with the destination flags the links decide)
+    launch(U, WalkInfoFunctor{uc, nullptr, ui.ptr()});
+    launch((u64)U * 2, LinksFunctor<W>{t, tb, nv, uc, order.ptr(), npos.ptr(), g.any_dots, links.ptr(), wlinks.ptr(), counters.ptr() + 3, ui.ptr()});
     lap(&tm->links);
 }
 

@@ -1574,7 +1574,9 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             launch(J, CandListFunctor{order1.ptr(), cflag.ptr(), cpos.ptr(), clist.ptr(), prio.ptr()});
             launch(C, FillU32Functor{level.ptr(), 1u});
             DBuf<u32> changed(9), preds(C * MAX_PREDS); DBuf<u8> npred(C);
-            launch(C, LevelPredsFunctor{L, cand.ptr(), clist.ptr(), prio.ptr(), C, preds.ptr(), npred.ptr()});
+            DBuf<V16> touch(U);      // the candidate junctions touching each unitig: for the conflict lists here and for every junction that moves something
+            launch(U, TouchFunctor{L, cand.ptr(), touch.ptr()});
+            launch(C, LevelPredsFunctor{L, cand.ptr(), clist.ptr(), prio.ptr(), C, preds.ptr(), npred.ptr(), touch.ptr()});
             if (partitioned) {      // this rank's share of the junctions: the conflict components it owns
                 DBuf<u32> parent(C);
                 jowner.alloc(C); owned_count.alloc(1); owned_count.fill_bytes(0);
@@ -1611,8 +1613,6 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             }
             hb.resize((size_t)n_levels + 2);
             hb[n_levels + 1] = (u32)C;
-            DBuf<V16> touch(U);
-            launch(U, TouchFunctor{L, cand.ptr(), touch.ptr()});
             ExpState e{cur, ev.ptr(), pool.ptr(), pool_used.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), dirty.ptr(), cand.ptr(), L, shifted.ptr(), touch.ptr()};
             pool_used.fill_bytes(0);
             u64 moved = 0, moved_since_rewrite = 0;

@@ -411,12 +411,19 @@ static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 //   AC_POS_CAP        (65536) single-device builds: occurrences further than this from both ends of their sequence do not lower a
 //                     unitig's smallest positions; beyond it expand_repeats works with a lower bound and, where that cannot decide,
 //                     the build is repeated with exact positions (kernels_tail.inc exp_avoid_start_of_path).  0: every occurrence counts.
-//   AC_PATH_COPY      1: the copying path walk (K10c, walk_copy: followed runs are copied from the stretch they repeat, the text between
-//                     them is walked); AC_RUN_PIECE (4096): positions per copied piece of a run (tests).  Default 0: a small win only.
+//   AC_PATH_COPY      the copying path walk (K10c: followed runs are copied from the stretch they repeat, the text between them is
+//                     walked): 1 whenever the insert has a one-launch rest, 0 never, unset: where the cost model says it pays
+//                     (path_copy_pays).  AC_RUN_PIECE (4096): positions per copied piece of a run (tests).  AC_SHARD_PATH_COPY (1): the
+//                     same for a rank's own sequences in a sharded build (round 5).
 //   AC_REMAP_BLOCK    path entries per wavefront in the final renumbering (tests).
 //   AC_INSERT_CHUNK / AC_INSERT_GROWTH / AC_INSERT_WAVES   insert phases: longest wavefront chunk, prefix growth factor, wavefronts per phase;
-//   AC_INSERT_ADAPT (default 1)   redundant text: everything after the second phase in one launch (chunks of up to 16384 positions).
-//   AC_EXPAND_REWRITE_ALWAYS  rewrite the sequences contiguously after every host check of the expand passes (tests).
+//   AC_INSERT_ADAPT (default 1)   redundant text: everything after the second phase in one launch, in chunks of 16384 positions — or
+//                     shorter ones where a sample of that rest finds content of its own (round 5); AC_INSERT_CHUNK_REST fixes the chunk.
+//   AC_EXPAND_REWRITE_ALWAYS  rewrite the sequences contiguously after every host check of the expand passes (tests);
+//                     AC_EXPAND_LEVEL_TABLE (1024): levels the first read of the level bounds holds (tests: the exact second read).
+//   AC_SORT_CHECKS    1: every "group too large" flag of a sort read where it is raised (default: with the build's last read-back, and a
+//                     build that had one set is repeated).
+//   AC_SHARD_DEGREE_FLAGS (1) / AC_SHARD_HOST_REMAP (1)   sharded builds: sibling bits + probe-free degrees; own paths renumbered on the host.
 //   AC_SEQ_WRITER     0 / 1 = always the search-per-thread / the indexed LDS-tiled sequence writers (default: by output size).
 //   AC_DEGREE_FLAGS   1 (default): degrees from the sibling bits the insert collects, probes only where they do not settle it (two
 //                     passes); 0: every degree by probing (what sharded builds and k < 3 do).

@@ -402,7 +402,7 @@ def main():
         t_hot = {"value": bases / 1e6 / (e_hot / args.steps), "unit": "Mbp/s", "ms_per_step": e_hot / args.steps * 1e3, "steps": args.steps,
                  "elapsed_s": e_hot, "step_ms_list": [round(x * 1e3, 2) for x in hs],
                  "timed_region": "padded+repaired sequences in pageable host RAM (one buffer per sequence view) -> final unitig graph in host "
-                                 "RAM through ac_compress_build: 2-bit pack on the host (32 background threads) straight into device memory where the "
+                                 "RAM through ac_compress_build: 2-bit pack on the host (AC_UPLOAD_THREADS = 24 background threads by default) straight into device memory where the "
                                  "device's memory is host-visible (large BAR; else into a pinned ring sent as 16 MB copies): 0.25 B per base over PCIe, "
                                  "the mask plane derived on the device, the insert issued piece by piece as the 64 MB chunks land, device build, D2H "
                                  "of the results",

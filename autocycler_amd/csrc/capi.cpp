@@ -168,6 +168,7 @@ const char* ac_version(void) {
     return "autocycler_amd 0.1 (gfx950)";
 #endif
 }
+int ac_abi_version(void) { return AC_ABI_VERSION; }
 void ac_set_stage_timing(int on) { set_stage_timing(on != 0); }
 // The device arena and the pool of pinned result blocks stay allocated between builds; this gives them back (e.g. before a
 // long-lived host process turns to other work).  Graph handles that are still alive keep their blocks.
@@ -704,6 +705,7 @@ static void fill_report(const VerifyReport& r, ac_verify_report* o) {
     o->first_bad_sequence = r.first_bad_sequence; o->first_bad_base = r.first_bad_base;
     o->unitigs = r.unitigs; o->links = r.links; o->path_entries = r.path_entries; o->bases_checked = r.bases_checked;
     o->self_mirror_links = r.self_mirror_links; o->seconds = r.seconds;
+    o->checks = r.checks; o->first_bad_junction = r.first_bad_junction;
 }
 int ac_verify_graph_device(const ac_graph* g, const void* d_text, uint64_t n_text, const uint64_t* seq_off, const uint32_t* seq_len,
                            uint32_t n_seqs, int device, ac_verify_report* report) {

@@ -1722,16 +1722,17 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     renumber_sort(order2, U, clen.ptr(), coff.ptr(), cur, depth.ptr(), defer_sorts ? sort_flags.ptr() + 1 : renum_flag.ptr(), defer_sorts);
     DBuf<u64> number_len(U), lcount((u64)U + 1), loff((u64)U + 1);
     DBuf<u32> number_only(host_remap ? U : 0);
-    DBuf<u8> meta((size_t)U * 20);
+    DBuf<u8> meta((size_t)U * 24);
     u64* d_seq_begin = (u64*)meta.ptr();
     double* d_depth = (double*)(meta.ptr() + (size_t)U * 8);
     u32* d_seq_len = (u32*)(meta.ptr() + (size_t)U * 16);
+    u32* d_seed_index = (u32*)(meta.ptr() + (size_t)U * 20);
     lcount.fill_bytes(0);
     out->k = k;
     out->n_kmers = 2 * (u64)N;
     out->n_unitigs = U;
     launch(U, FinalMetaFunctor{order2.ptr(), coff.ptr(), clen.ptr(), depth.ptr(), lcnt.ptr(), number_len.ptr(), d_seq_begin, d_depth,
-                               d_seq_len, lcount.ptr(), host_remap ? number_only.ptr() : nullptr});
+                               d_seq_len, lcount.ptr(), host_remap ? number_only.ptr() : nullptr, d_seed_index});
     if (host_remap) {      // the number table first: the host threads start on the entries while the rest is still crossing
         number_block = PinnedPool::get().alloc((size_t)U * 4);
         side.after_main();
@@ -1745,9 +1746,9 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
 #endif
     }
     if (want_graph) {
-        out->meta_block = PinnedPool::get().alloc((size_t)U * 20);
+        out->meta_block = PinnedPool::get().alloc((size_t)U * 24);
         side.after_main();
-        copy_d2h_async(out->meta_block.p, meta.ptr(), (size_t)U * 20, side.stream());
+        copy_d2h_async(out->meta_block.p, meta.ptr(), (size_t)U * 24, side.stream());
     }
     exclusive_scan_u64(lcount.ptr(), loff.ptr(), (u64)U + 1);
     u64 n_links = read_scalar(loff.ptr() + U);
@@ -1818,6 +1819,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         out->seq_begin = (const u64*)out->meta_block.p;
         out->depth = (const double*)((const u8*)out->meta_block.p + (size_t)U * 8);
         out->seq_len = (const u32*)((const u8*)out->meta_block.p + (size_t)U * 16);
+        out->seed_index = (const u32*)((const u8*)out->meta_block.p + (size_t)U * 20);
         out->links = (const Link*)out->links_block.p;
     }
     if (want_paths) out->path = (const int32_t*)out->path_block.p;

@@ -167,6 +167,8 @@ struct VerifyReport {
     uint64_t first_bad_unitig = ~0ULL, first_bad_link = ~0ULL, first_bad_path_entry = ~0ULL, first_bad_sequence = ~0ULL, first_bad_base = ~0ULL;
     uint64_t unitigs = 0, links = 0, path_entries = 0, bases_checked = 0, self_mirror_links = 0;
     double seconds = 0;
+    uint32_t checks = 0;                                   // VerifyCheck bits: which of the order-sensitive checks ran
+    uint64_t first_bad_junction = ~0ULL;                   // 2 * unitig index + side (0 = its inputs, 1 = its outputs) that would still shift
 };
 void verify_graph_device(const FinalGraph& g, const uint8_t* d_text, uint64_t n_text, const std::vector<uint64_t>& off,
                          const std::vector<uint32_t>& len, VerifyReport* rep);

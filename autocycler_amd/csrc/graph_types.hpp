@@ -38,10 +38,13 @@ struct FinalGraph {
     GraphStats pre, post;
     uint32_t n_unitigs = 0;
     HostBlock seq_block;                     // final forward sequences, concatenated (in seed order)
-    HostBlock meta_block;                    // seq_begin[U] (u64) | depth[U] (double) | seq_len[U] (u32)
+    HostBlock meta_block;                    // seq_begin[U] (u64) | depth[U] (double) | seq_len[U] (u32) [| seed_index[U] (u32): built graphs]
     const uint64_t* seq_begin = nullptr;     // offset of unitig i's sequence in seq_block
     const double* depth = nullptr;
     const uint32_t* seq_len = nullptr;
+    // built graphs only (null for a graph loaded from a GFA): the index final unitig i had in SEED order, i.e. its number - 1 when
+    // create_links ran (unitig_graph.rs:234-287 pushes links in that order).  Only the verifier reads it (L-line order inside a group).
+    const uint32_t* seed_index = nullptr;
     HostBlock links_block;                   // Link[n_links] in get_links_for_gfa order (unitig_graph.rs:333-350)
     const Link* links = nullptr;
     uint64_t n_links = 0;

@@ -119,12 +119,28 @@ size_t ac_multi_info_get_sized(const ac_graph*, ac_multi_info* out, size_t out_s
  * Returns 0 when the checks RAN (report->failed says what they found: 0 = the graph holds), non-zero on a usage error (ac_last_error).
  * `failed` bits: 1 unitig length / range, 2 renumber order, 4 link endpoint out of range, 8 duplicate link, 16 link without mirror,
  * 32 path entry out of range, 64 path step that is no link, 128 path length != sequence length, 256 a path does not spell its sequence,
- * 512 depth != occurrences, 1024 statistics.  first_bad_*: the smallest offending index of each kind (all ones: none). */
+ * 512 depth != occurrences, 1024 statistics.  first_bad_*: the smallest offending index of each kind (all ones: none).
+ *
+ * ABI 6 adds the three ORDER-SENSITIVE guarantees of the reference, so that a graph no CPU oracle can hold is checked as "the reference's
+ * graph" and not only as "lossless and consistent" (the struct grew at its end: `checks`, `first_bad_junction`):
+ *   2048  L-line order: the links are not in get_links_for_gfa order (unitig_graph.rs:333-350: unitigs ascending, forward_next before
+ *         reverse_next, inside a list create_links' push order :248-286).  The order inside a class of one list is by SEED number, which a
+ *         built graph carries and a graph reloaded from a GFA does not (`checks` bit 2 says whether that part ran);
+ *   4096  maximality: a link a -> b that is a's only successor and b's only predecessor, and none of the walk's break cases
+ *         (unitig_graph.rs:192-223: the end of a / start of b on a sequence-strand end, b == -a, b == a): a unitig cut in two
+ *         (first_bad_link names it);
+ *   8192  expand_repeats has not reached its fixed point (graph_simplification.rs:26-40): junction `first_bad_junction` = 2 x unitig index
+ *         + side (0 = its exclusive inputs, 1 = its exclusive outputs) passes the reference's candidate test (:190-280) and its clamps
+ *         (:145-181) still leave a shift > 0.
+ * `checks`: 1 link order, 2 ... with seed numbers, 4 maximality, 8 fixed point — 4 and 8 need a link set that holds (no 4 / 8 / 16), 8 also
+ * paths that add up. */
 typedef struct {
     uint32_t failed;
     uint64_t first_bad_unitig, first_bad_link, first_bad_path_entry, first_bad_sequence, first_bad_base;
     uint64_t unitigs, links, path_entries, bases_checked, self_mirror_links;
     double seconds;
+    uint32_t checks;
+    uint64_t first_bad_junction;
 } ac_verify_report;
 /* seqs: the sequences the graph was built from, as for ac_compress_build (host memory; they are laid out and uploaded as text) */
 int ac_verify_graph(const ac_graph* graph, const ac_seq_view* seqs, uint32_t n_seqs, int device, ac_verify_report* report);
@@ -255,6 +271,8 @@ int ac_shard_set_allreduce(ac_shard*, ac_allreduce_fn fn, void* user);
 int ac_device_copy(void* dst, const void* src, uint64_t bytes, int device);
 int ac_shard_finish(ac_shard*, int want, ac_graph** out);
 uint64_t ac_shard_path_entries(const ac_shard*);
+/* Only for ranks that did NOT keep their own paths: after ac_shard_finish(want & 2) the rank's entries got their final numbers in host
+ * memory (the handle's paths; the device copy stays in seed numbers) and this call fails with an error (ABI 5). */
 int ac_shard_paths_export(ac_shard*, void* d_out_i32 /* ac_shard_path_entries() */);
 void ac_shard_free(ac_shard*);
 /* path_counts[s] = number of path entries of sequence s; d_path_i32 = all entries, concatenated (device). */
@@ -367,6 +385,14 @@ const char* ac_last_error(void);
 int ac_device_count(void);       /* number of visible HIP devices (0 if none / no driver) */
 uint32_t ac_max_kmer(void);      /* largest --kmer this build supports */
 const char* ac_version(void);
+/* The ABI generation of this header (the round it was last changed incompatibly in); ac_abi_version() is the library's.  A caller
+ * compiled against another generation must not pass caller-allocated structs that grew (ac_verify_report) or drive the ac_shard_* phases.
+ *   5: ac_shard_*: sib_export / all-reduce / ac_shard_degrees between ac_shard_build_novel and the degree exchange whenever
+ *      ac_shard_sib_words() > 0; degree buffers are ac_shard_degree_bytes() bytes; ac_shard_paths_export fails after
+ *      ac_shard_finish(want & 2) (the rank's own paths were renumbered on the host: read them from the handle).
+ *   6: ac_verify_report grew (checks, first_bad_junction; failed bits 2048 / 4096 / 8192). */
+#define AC_ABI_VERSION 6
+int ac_abi_version(void);
 const char* ac_source_hash(void);   /* 16 hex digits: digest of the sources this library was built from (csrc/Makefile; tools/source_hash.py) */
 
 #ifdef __cplusplus

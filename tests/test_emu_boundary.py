@@ -162,6 +162,12 @@ def test_verify_graph_names_the_damage(emu):
     verify_cases.names_the_damage(emu)
 
 
+def test_verify_graph_names_order_sensitive_damage(emu):
+    """maximality, expand_repeats' fixed point, L-line order (unitig_graph.rs:192-223, 333-350; graph_simplification.rs:26-86)"""
+    import verify_cases
+    verify_cases.names_order_sensitive_damage(emu)
+
+
 @pytest.mark.parametrize("kind", [0, 1, 2, 3, 4])
 def test_hand_written_primitives_equal_std(emu, kind):
     # csrc/device_prims.hpp (scan with decoupled look-back, onesweep radix sort, merge sort by ranks) under the lockstep emulation: tile

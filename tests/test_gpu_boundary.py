@@ -122,6 +122,13 @@ def test_verify_graph_names_the_damage(lib):
     verify_cases.names_the_damage(None)
 
 
+def test_verify_graph_names_order_sensitive_damage(lib):
+    # round 6: a unitig cut in two (maximality, unitig_graph.rs:192-223), a shift expand_repeats did not apply (graph_simplification.rs:26-86),
+    # L lines out of get_links_for_gfa order (unitig_graph.rs:333-350) — each named
+    import verify_cases
+    verify_cases.names_order_sensitive_damage(None)
+
+
 @pytest.mark.parametrize("kind", [0, 1, 2, 3, 4])
 def test_hand_written_primitives_equal_std(lib, kind):
     # csrc/device_prims.hpp on the device: thousands of tiles in flight (the look-back chains), every key kind, odd end bits

@@ -66,6 +66,9 @@ def verify_on_device(g, seqs):
     t0 = time.time()
     rep = g.verify_device(j["d_text"].data_ptr(), j["n_text"], j["off"], j["lens"])
     assert rep["failed"] == 0, rep
+    # round 6: the order-sensitive guarantees all ran — L-line order with seed numbers, maximality, expand_repeats' fixed point
+    # (unitig_graph.rs:192-223, 333-350; graph_simplification.rs:26-86): "the reference's graph", not only "lossless and consistent"
+    assert rep["checks"] == 15, rep
     assert rep["bases_checked"] == sum(len(s) for s in seqs) and rep["unitigs"] == g.unitig_count
     print(f"ac_verify_graph_device: {rep['unitigs']} unitigs, {rep['links']} links, {rep['path_entries']} path entries, {rep['bases_checked']} bases in "
           f"{rep['seconds'] * 1e3:.1f} ms on the device ({(time.time() - t0) * 1e3:.1f} ms with the call)")
@@ -200,6 +203,7 @@ def test_config_e_full_size_k51():
     # behind the ABI (tests/fullsize_e.py::check_on_device is the torch restatement rounds 3-4 used; AC_TEST_TORCH_CHECK=1 runs it as well)
     r = g.verify_device(d_text.data_ptr(), job["n_text"], job["off"], job["lens"])
     assert r["failed"] == 0 and r["bases_checked"] == job["bases"], r
+    assert r["checks"] == 15, r      # round 6: L-line order (with seed numbers), maximality and expand_repeats' fixed point ran on all 81.9 M unitigs
     if os.environ.get("AC_TEST_TORCH_CHECK"):
         lib.ac_release_memory()
         fullsize_e.check_on_device(g, job, d_text, log=print)

@@ -107,6 +107,20 @@ def test_config_b_over_two_ranks_digest(lib):
     _golden_job_over(lib, "configB_k51", ([0, 0], [0]))
 
 
+def test_config_d_prime_k101_over_two_and_four_ranks_digest(lib):
+    """D' (24 x ~10 Mbp, k = 101 — FOUR-word keys through every exchange: the routed walk-start keys are 32 bytes each) as
+    one job over 2 and over 4 ranks sharing the device: the oracle's md5 (tests/golden/configDprime_k101.json)."""
+    for mi in _golden_job_over(lib, "configDprime_k101", ([0, 0], [0, 0, 0, 0])):
+        assert mi.n_ranks in (2, 4) and mi.queries_total > 0
+
+
+def test_config_c_over_eight_ranks_digest(lib):
+    """BASELINE configs[2] (96 x ~5 Mbp, k = 51) as one job over EIGHT ranks sharing the device (12 assemblies per rank: every rank's slice is
+    new to it, the hardest case for the fragments): the oracle's whole-workload md5 (tests/golden/configC_k51.json)."""
+    mi, = _golden_job_over(lib, "configC_k51", ([0] * 8,))
+    assert mi.n_ranks == 8 and mi.bytes_received_max > 0
+
+
 def _distinct_devices(lib):
     n = lib.ac_device_count()
     if n < 2:

@@ -45,7 +45,7 @@ class Timings(C.Structure):
                 ("fragments", C.c_double), ("union_pack", C.c_double), ("union_insert", C.c_double),
                 ("n_local_distinct", C.c_uint64), ("n_fragments", C.c_uint64), ("fragment_bytes", C.c_uint64),
                 ("upload_device_ms", C.c_double), ("path_runs_copied", C.c_uint64), ("path_entries_walked", C.c_uint64), ("position_retries", C.c_uint64), ("n_candidates_owned", C.c_uint32),
-                ("launches", C.c_uint32), ("readbacks", C.c_uint32), ("n_degrees_open", C.c_uint64), ("sort_retries", C.c_uint64), ("insert_rest_known", C.c_double)]
+                ("launches", C.c_uint32), ("readbacks", C.c_uint32), ("n_degrees_open", C.c_uint64), ("sort_retries", C.c_uint64), ("insert_rest_known", C.c_double), ("insert_rest_sampled", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -56,7 +56,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,
 EXPORTS = ["ac_compress_build", "ac_compress_build_multi", "ac_multi_info_get", "ac_compress_build_device", "ac_pack_text", "ac_text_size", "ac_layout_text", "ac_kmer_count",
            "ac_stats_pre", "ac_stats_post", "ac_unitig_count", "ac_unitig", "ac_unitigs_bulk", "ac_paths_bulk", "ac_unitig_positions", "ac_links",
            "ac_path", "ac_timings_get", "ac_timings_get_sized", "ac_free", "ac_gfa_string", "ac_string_free", "ac_last_error",
-           "ac_device_count", "ac_max_kmer", "ac_version", "ac_abi_version", "ac_source_hash", "ac_set_stage_timing", "ac_random_access_ceilings", "ac_random_access_ceilings_at", "ac_release_memory", "ac_end_repair_device", "ac_pairwise_distances", "ac_selftest_primitives", "ac_verify_graph", "ac_verify_graph_device", "ac_graph_from_gfa", "ac_graph_kmer_size", "ac_graph_seq_info", "ac_decompress_seq", "ac_decompress_device", "ac_decompress",
+           "ac_device_count", "ac_max_kmer", "ac_version", "ac_abi_version", "ac_set_host_side_device", "ac_source_hash", "ac_set_stage_timing", "ac_random_access_ceilings", "ac_random_access_ceilings_at", "ac_release_memory", "ac_end_repair_device", "ac_pairwise_distances", "ac_selftest_primitives", "ac_verify_graph", "ac_verify_graph_device", "ac_graph_from_gfa", "ac_graph_kmer_size", "ac_graph_seq_info", "ac_decompress_seq", "ac_decompress_device", "ac_decompress",
            "ac_shard_begin", "ac_shard_fragment_sizes", "ac_shard_fragments_export", "ac_shard_build_union", "ac_shard_fragment_packed_words", "ac_shard_fragments_export_packed", "ac_shard_build_union_packed",
            "ac_shard_unitig_count", "ac_shard_table_capacity", "ac_shard_bitmap_words", "ac_shard_bitmap_export", "ac_shard_build_novel", "ac_shard_sib_words", "ac_shard_sib_export", "ac_shard_degrees",
            "ac_shard_degree_bytes", "ac_multi_info_get_sized", "ac_shard_links_export", "ac_shard_links_import",

@@ -30,6 +30,7 @@ using namespace ac;
 
 static thread_local std::string g_err;
 static std::mutex g_build_mutex;   // one build at a time per process: the device / pinned arenas are shared
+static std::atomic<int> g_host_side_device{0};      // ac_set_host_side_device: where ac_seqs_load / ac_seqs_from_raw run the end repair
 static int g_live_shards = 0;      // a live sharded build owns the arenas between its phases: no other build may start
 
 struct ac_graph {
@@ -54,10 +55,11 @@ struct ac_seqs {
     }
 };
 
+// (a call that failed may have left a scan between its ticket take and its kernel: the calling thread's scan state pool starts over)
 template <class F> static int guarded(F&& f) {
     try { f(); return 0; }
-    catch (const std::exception& e) { g_err = e.what(); return 1; }
-    catch (...) { g_err = "unknown internal error"; return 1; }
+    catch (const std::exception& e) { g_err = e.what(); scan_pool().invalidate(); return 1; }
+    catch (...) { g_err = "unknown internal error"; scan_pool().invalidate(); return 1; }
 }
 
 static void select_device(int device) {
@@ -169,6 +171,7 @@ const char* ac_version(void) {
 #endif
 }
 int ac_abi_version(void) { return AC_ABI_VERSION; }
+int ac_set_host_side_device(int device) { if (device < 0) { g_err = "invalid HIP device ordinal"; return 1; } g_host_side_device.store(device); return 0; }
 void ac_set_stage_timing(int on) { set_stage_timing(on != 0); }
 // The device arena and the pool of pinned result blocks stay allocated between builds; this gives them back (e.g. before a
 // long-lived host process turns to other work).  Graph handles that are still alive keep their blocks.
@@ -922,7 +925,7 @@ int ac_timings_get(const ac_graph* g, ac_timings* o) {
     o->path_runs_copied = t.path_runs_copied; o->path_entries_walked = t.path_entries_walked; o->position_retries = t.position_retries;
     o->n_candidates_owned = t.n_candidates_owned;
     o->launches = t.launches; o->readbacks = t.readbacks; o->n_degrees_open = t.n_degrees_open; o->sort_retries = t.sort_retries;
-    o->insert_rest_known = t.insert_rest_known;
+    o->insert_rest_known = t.insert_rest_known; o->insert_rest_sampled = t.insert_rest_sampled;
     return 0;
 }
 // The same for a caller that was compiled against another version of the header: at most out_size bytes are written (the struct only
@@ -961,10 +964,54 @@ int ac_gfa_string_parts(const ac_graph* g, int parts, const char* const* filenam
 void ac_string_free(char* p) { free(p); }
 
 // ---- host side: load_sequences / end repair / whole command ---------------------------------------------
+// sequence_end_repair (compress.rs:202-270) for sequences that live in host memory (ac_seqs_load, ac_seqs_from_raw, the multi-device
+// command): the padded sequences go up as one text, the device kernels repair it in place (neighbours.inc — the only implementation
+// the library has), and the k - 1 leading / trailing bytes of every sequence come back.
+static void repair_on_device(LoadResult& lr, uint32_t k, int device) {
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<LoadedSeq>& seqs = lr.seqs;
+    const size_t m = (size_t)k - 1;
+    if (m == 0 || seqs.empty()) return;
+    std::vector<SeqView> v(seqs.size());
+    for (size_t i = 0; i < seqs.size(); i++) v[i] = SeqView{(const uint8_t*)seqs[i].forward_seq.data(), seqs[i].length};
+    std::vector<uint64_t> off; std::vector<uint32_t> len; std::vector<uint16_t> d1, d2;
+    std::vector<uint8_t> text = layout_text(v, k, &off, &len, &d1, &d2);
+    {
+        std::lock_guard<std::mutex> lock(g_build_mutex);
+        if (g_live_shards) throw DeviceError("a sharded build is in flight in this process");
+        select_device(device);
+        RepairTimings rt;
+#ifdef AC_EMU
+        end_repair_device(k, text.data(), text.size(), off, len, &d1, &d2, &rt);
+#else
+        void* d_text = nullptr;
+        AC_HIP_CHECK(hipMalloc(&d_text, text.size() + 64));
+        struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{d_text};
+        AC_HIP_CHECK(hipMemcpy(d_text, text.data(), text.size(), hipMemcpyHostToDevice));
+        end_repair_device(k, (uint8_t*)d_text, text.size(), off, len, &d1, &d2, &rt);
+        // only the two ends of a sequence can have changed: k - 1 bytes from either end of each come back (many short sequences: the whole text)
+        if (seqs.size() > 256) AC_HIP_CHECK(hipMemcpy(text.data(), d_text, text.size(), hipMemcpyDeviceToHost));
+        else for (size_t i = 0; i < seqs.size(); i++) {
+            const size_t plen = seqs[i].forward_seq.size();
+            AC_HIP_CHECK(hipMemcpyAsync(&text[off[i]], (const uint8_t*)d_text + off[i], std::min(m, plen), hipMemcpyDeviceToHost, 0));
+            if (plen > m) AC_HIP_CHECK(hipMemcpyAsync(&text[off[i] + plen - m], (const uint8_t*)d_text + off[i] + plen - m, m, hipMemcpyDeviceToHost, 0));
+        }
+        AC_HIP_CHECK(hipStreamSynchronize(0));
+#endif
+    }
+    for (size_t i = 0; i < seqs.size(); i++) {
+        std::string& f = seqs[i].forward_seq;
+        const size_t plen = f.size(), head = std::min(m, plen);
+        memcpy(&f[0], &text[off[i]], head);
+        if (plen > m) memcpy(&f[plen - m], &text[off[i] + plen - m], m);
+    }
+    lr.repair_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
 int ac_seqs_load(const char* assemblies_dir, uint32_t k, uint32_t max_contigs, int threads, ac_seqs** out) {
     return guarded([&] {
         auto h = std::make_unique<ac_seqs>();
         h->lr = load_sequences(assemblies_dir, k, max_contigs, threads);
+        repair_on_device(h->lr, k, g_host_side_device.load());
         h->make_views();
         *out = h.release();
     });
@@ -984,9 +1031,8 @@ int ac_seqs_from_raw(uint32_t k, uint32_t n, const uint8_t* const* seqs, const u
         }
         h->lr.assembly_count = assembly_count;
         h->lr.total_contigs_seen = n;
-        auto t0 = std::chrono::steady_clock::now();
-        if (repair) sequence_end_repair(h->lr.seqs, k, threads);
-        h->lr.repair_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        (void)threads;      // (the packers of a later build use their own pool; the repair is a device kernel)
+        if (repair) repair_on_device(h->lr, k, g_host_side_device.load());
         h->make_views();
         *out = h.release();
     });
@@ -1028,7 +1074,6 @@ int ac_compress_dir(const char* assemblies_dir, const char* autocycler_dir, uint
         fs::create_directories(autocycler_dir, ec);
         if (ec) throw UserError(std::string("failed to create directory ") + autocycler_dir + "\n" + ec.message());
         // load (host) -> text layout -> H2D -> end repair on the device text -> graph build from the same buffer
-        const bool host_repair = getenv("AC_HOST_REPAIR") != nullptr;      // the host implementation, kept for comparison
         // the HIP context and the code objects come up on another thread while the host reads the FASTA files
         // (with the arena and the upload ring it will need, sized from the files' sizes: a .gz holds about four times its size in bases)
         uint64_t est = 0;
@@ -1050,15 +1095,12 @@ int ac_compress_dir(const char* assemblies_dir, const char* autocycler_dir, uint
         });
         struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{warm};
         ac_seqs s;
-        s.lr = load_sequences(assemblies_dir, k, max_contigs, threads, host_repair);
+        s.lr = load_sequences(assemblies_dir, k, max_contigs, threads);
         s.make_views();
         warm.join();
         double t0 = now();
         ac_graph* g = nullptr;
-        if (host_repair) {
-            if (ac_compress_build(k, s.lr.assembly_count, s.views.data(), (uint32_t)s.views.size(), device, &g) != 0)
-                throw DeviceError(g_err);
-        } else {
+        {
             const uint32_t n = (uint32_t)s.views.size();
             validate(k, s.views.data(), n);
             std::lock_guard<std::mutex> lock(g_build_mutex);
@@ -1110,7 +1152,8 @@ int ac_compress_dir_multi(const char* assemblies_dir, const char* autocycler_dir
         fs::create_directories(autocycler_dir, ec);
         if (ec) throw UserError(std::string("failed to create directory ") + autocycler_dir + "\n" + ec.message());
         ac_seqs s;
-        s.lr = load_sequences(assemblies_dir, k, max_contigs, threads, /*repair=*/true);
+        s.lr = load_sequences(assemblies_dir, k, max_contigs, threads);
+        repair_on_device(s.lr, k, devices[0]);      // (compress.rs:38-41: load, then repair, then the build — the repair on the first rank's device)
         s.make_views();
         double t0 = now();
         ac_graph* g = nullptr;

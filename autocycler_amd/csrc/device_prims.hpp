@@ -57,6 +57,9 @@ struct ScanPool {
 #endif
         words = nullptr; cap = 0;
     }
+    // After anything failed between a take() and the end of its kernel (a launch that threw, a build that was abandoned): the device's ticket
+    // counter and the host's mirror of it may no longer agree — the next take() starts from a cleared pool.
+    void invalidate() { epoch = 1ULL << 16; }
     // the pool for a scan of `tiles` tiles: returns the epoch to tag with and the value the ticket counter starts this scan at
     void take(u64 tiles, u64* epoch_out, u64* ticket_base) {
 #ifndef AC_EMU
@@ -186,7 +189,6 @@ inline void exclusive_scan_u64(const u64* in, u64* out, size_t n, stream_t s = 0
 // ---- stable LSD radix sort of (u64 key, 32-bit value) pairs on key bits [0, end_bit) -------------------------------------------
 static const u32 RS_ITEMS = 8, RS_TILE = 256 * RS_ITEMS, RS_MAX_PASSES = 8;
 static const int RS_LB = 16;
-static const u64 RS_COLOCATED_TILES = 1024;      // a grid this small is resident as a whole (256 CUs x >= 4 workgroups): blockIdx can be the tile, no ticket
 // hist[p * 256 + d] = keys whose digit p is d
 template <int UNUSED> AC_KERNEL void __launch_bounds__(256) radix_hist_kernel(const u64* keys, u64 n, int passes, int begin_bit, int end_bit, u32* hist) {
     AC_SHARED u32 s_hist[RS_MAX_PASSES * 256];
@@ -329,11 +331,8 @@ template <class V> inline void radix_sort_pairs_impl(DBuf<u64>& keys, DBuf<V>& v
     for (int p = 0; p < passes; p++) {
         const int bits_here = std::min(8, end_bit - begin_bit - 8 * p);
         launch_wave_kernel(radix_pass_kernel<V>, tiles, s, (const u64*)ka, (const V*)va, kb, vb, (u64)n, p, bits_here, begin_bit, (const u32*)hist.ptr(), state.ptr(),
-#ifdef AC_EMU
-                           ticket.ptr());      // (the emulation runs the workgroups one after the other, in any order AC_EMU_ORDER asks for: always by ticket)
-#else
-                           tiles > RS_COLOCATED_TILES ? ticket.ptr() : (u64*)nullptr);
-#endif
+                           ticket.ptr());      // tiles always by ticket: a look-back only ever waits for tiles that have STARTED (round 5 let grids of <= 1024
+                                               // tiles use blockIdx, which needs the whole grid resident — not promised when ranks share a device: ADVICE r5)
         std::swap(ka, kb); std::swap(va, vb);
     }
     if (passes & 1) { keys = std::move(k2); vals = std::move(v2); }

@@ -934,10 +934,26 @@ void GraphBuilder::Impl::insert(const PackedText& pt, u32 hint, DBuf<u64>* slots
                 // ~8 K wavefronts x chunk of text in flight, every copy of a new stretch inside that window inserts it for real, and
                 // the shorter chunk is the narrower window (benchjob8 16 K / 8 K / 4 K / 2 K: insert 18.2 / 14.7 / 12.2 / 11.9 ms; config C
                 // 1.24 / 1.25 / 1.32 / 1.44, D 10.1 / 10.3 / 11.1 / 12.2: r12v).  Same read-back as the claim counters.
+                // (only text that IS on the device is sampled.  With the host entry's overlapped upload — or the device entry's pack
+                // beside the first phase — the text behind what stream 0 has waited for is not there yet: the sample takes what the first piece
+                // of the rest is about to read anyway (one more chunk at most) and ends where the uploaded text ends; ac_timings.
+                // insert_rest_sampled says how much of the rest that was.)
+                u64 probe_end = p_end_all;
+#ifndef AC_EMU
+                if (&pt == &loc) {
+                    if (job) {
+                        need_text(std::min<u64>(p_end_all, pb + (1u << 20)) + (u64)k + 8192);
+                        const u64 avail = job ? std::min<u64>(job->n, job->next_wait * job->CH) : pt.n_text;      // (the last chunk joins the uploaders: job is null then, all text is there)
+                        probe_end = std::min<u64>(p_end_all, avail > (u64)k + 64 ? avail - (u64)k - 64 : 0);
+                    } else if (upload_pending) probe_end = std::min<u64>(p_end_all, upload_avail > (u64)k + 64 ? upload_avail - (u64)k - 64 : 0);
+                }
+#endif
+                if (probe_end < pb) probe_end = pb;
                 DBuf<u32> probe(2);
                 probe.fill_bytes(0);
-                const u64 n_probe = std::min<u64>(32768, (p_end_all - pb) / 4096 + 1);
-                launch(n_probe, RestProbeFunctor<W>{t, tb, pb, p_end_all, (p_end_all - pb) / n_probe, probe.ptr()});
+                const u64 n_probe = std::min<u64>(32768, (probe_end - pb) / 4096 + 1);
+                if (probe_end > pb) launch(n_probe, RestProbeFunctor<W>{t, tb, pb, probe_end, (probe_end - pb) / n_probe, probe.ptr()});
+                tm->insert_rest_sampled = (double)(probe_end - pb) / (double)(p_end_all - pb);
                 std::vector<InsertStats> st2(257); u32 h_probe[2] = {0, 0};
                 { ReadBatch rb; rb.add(st2.data(), istats.ptr(), 257 * sizeof(InsertStats)); rb.add(h_probe, probe.ptr(), 8); rb.run(); }
                 u64 claimed = 0;
@@ -1178,9 +1194,24 @@ template <int W> void GraphBuilder::Impl::degrees() {
         const u32* kc_src = kc_tmp.ptr();
         kc_tmp = DBuf<u32>();
         Arena::device().rewind(deg_mark);
-        if (by_index) {      // the compact array moves to where the queues began (it lay behind them; 4 (P + F) bytes against >= 8 N of queues: no overlap)
+        if (by_index) {      // the compact array moves to where the queues began (it lay behind them: 4 (P + F) bytes against >= 8 N of queues)
             kcontrib.alloc(n_pending + n_first + 1);
-            if (kcontrib.ptr() != kc_src) copy_d2d(kcontrib.ptr(), kc_src, (n_pending + n_first + 1) * 4);
+            const u64 kc_bytes = (n_pending + n_first + 1) * 4;
+            if (kcontrib.ptr() != kc_src) {
+                // (nothing but sizes promised that the two do not overlap — F can reach twice the fragment count, AC_DEGREE_REGION_CAP
+                // shrinks the queues — and an overlapping device-to-device copy is undefined: then through a buffer behind both)
+                const u8* dst_b = (const u8*)kcontrib.ptr(); const u8* src_b = (const u8*)kc_src;
+                if (dst_b + kc_bytes <= src_b || src_b + kc_bytes <= dst_b) copy_d2d(kcontrib.ptr(), kc_src, kc_bytes);
+                else {
+                    const Arena::Mark bounce_mark = Arena::device().mark();
+                    DBuf<u32> pad((u64)(src_b + kc_bytes - dst_b) / 4 + 1), bounce(n_pending + n_first + 1);      // (pad: up to the end of the source, so that the bounce lies behind it)
+                    copy_d2d(bounce.ptr(), kc_src, kc_bytes);
+                    copy_d2d(kcontrib.ptr(), bounce.ptr(), kc_bytes);
+                    stream_sync();
+                    pad = DBuf<u32>(); bounce = DBuf<u32>();
+                    Arena::device().rewind(bounce_mark);
+                }
+            }
             tm->n_degrees_open = n_pending;
             lap(&tm->degree);
             return;

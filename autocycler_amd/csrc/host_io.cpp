@@ -139,102 +139,8 @@ void pad_sequence(LoadedSeq* s, const std::string& seq, uint32_t k) {
     s->length = (uint32_t)seq.size();
 }
 
-static inline char comp_char(char c) {
-    switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; case '.': return '.'; default: return 'N'; }
-}
-
-// compress.rs:202-270.  The reference compiles, per sequence, the first and the last k-1 padded characters
-// ('.' = wildcard) into regexes and scans every forward and reverse sequence with each (4·S·B byte steps).
-// Here all 2S literal halves are indexed once and every haystack is scanned once with a rolling hash; the
-// per-pattern leftmost-non-overlapping rule of find_iter and find_best_match's ordering (fewest dots, most
-// frequent, alphabetically first) are applied exactly.
-void sequence_end_repair(std::vector<LoadedSeq>& seqs, uint32_t k, int threads) {
-    const size_t m = k - 1, h = k / 2;
-    if (m == 0 || seqs.empty()) return;
-    const size_t S = seqs.size();
-    // snapshot of all forward + reverse padded sequences (compress.rs:209)
-    std::vector<std::string> hay(2 * S);
-    for (size_t i = 0; i < S; i++) {
-        hay[2 * i] = seqs[i].forward_seq;
-        std::string& r = hay[2 * i + 1];
-        const std::string& f = seqs[i].forward_seq;
-        r.resize(f.size());
-        for (size_t j = 0; j < f.size(); j++) r[j] = comp_char(f[f.size() - 1 - j]);
-    }
-    // pattern 2i = start of sequence i (h dots + literal), 2i+1 = end (literal + h dots).  m == 2h for odd k;
-    // for even k (not reachable from the CLI) the literal is m - h long.
-    const size_t lit = m - h;
-    auto literal_of = [&](size_t pid) -> const char* {
-        const std::string& f = hay[2 * (pid / 2)];
-        return (pid & 1) ? f.data() + f.size() - m : f.data() + h;
-    };
-    const uint64_t B = 0x9E3779B97F4A7C15ULL | 1;
-    uint64_t Bpow = 1;
-    for (size_t i = 1; i < lit; i++) Bpow *= B;
-    auto hash_of = [&](const char* p) { uint64_t x = 0; for (size_t i = 0; i < lit; i++) x = x * B + (unsigned char)p[i]; return x; };
-    std::unordered_map<uint64_t, std::vector<uint32_t>> index;
-    index.reserve(4 * S);
-    const size_t FB = 22;
-    std::vector<uint64_t> filter((1u << FB) / 64, 0);
-    for (size_t pid = 0; pid < 2 * S; pid++) {
-        uint64_t x = hash_of(literal_of(pid));
-        index[x].push_back((uint32_t)pid);
-        uint64_t b = x >> (64 - FB);
-        filter[b >> 6] |= 1ULL << (b & 63);
-    }
-    typedef std::map<std::string, uint32_t> Tally;
-    int T = std::max(1, std::min<int>(threads, (int)(2 * S)));
-    std::vector<std::vector<Tally>> tallies(T, std::vector<Tally>(2 * S));
-    std::atomic<size_t> next_hay{0};
-    auto worker = [&](int tid) {
-        std::vector<Tally>& tl = tallies[tid];
-        std::vector<size_t> next_free(2 * S, 0), stamp(2 * S, (size_t)-1);
-        for (size_t hi; (hi = next_hay.fetch_add(1)) < 2 * S;) {
-            const std::string& H = hay[hi];
-            if (H.size() < m) continue;
-            uint64_t x = hash_of(H.data());
-            for (size_t j = 0;; j++) {
-                uint64_t b = x >> (64 - FB);
-                if (filter[b >> 6] >> (b & 63) & 1) {
-                    auto it = index.find(x);
-                    if (it != index.end())
-                        for (uint32_t pid : it->second) {
-                            if (memcmp(literal_of(pid), H.data() + j, lit) != 0) continue;
-                            // pattern start i: end patterns begin with the literal, start patterns h bytes earlier
-                            if (!(pid & 1) && j < h) continue;
-                            size_t i = (pid & 1) ? j : j - h;
-                            if (i + m > H.size()) continue;
-                            if (stamp[pid] != hi) { stamp[pid] = hi; next_free[pid] = 0; }
-                            if (i < next_free[pid]) continue;           // overlaps the previous match of this regex
-                            next_free[pid] = i + m;
-                            tl[pid][H.substr(i, m)]++;
-                        }
-                }
-                if (j + lit >= H.size()) break;
-                x = (x - (unsigned char)H[j] * Bpow) * B + (unsigned char)H[j + lit];
-            }
-        }
-    };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < T; t++) pool.emplace_back(worker, t);
-    worker(0);
-    for (auto& t : pool) t.join();
-    for (size_t pid = 0; pid < 2 * S; pid++) {
-        Tally all;
-        for (int t = 0; t < T; t++) for (auto& kv : tallies[t][pid]) all[kv.first] += kv.second;
-        if (all.empty()) throw std::logic_error("There should be at least one match");
-        const std::string* best = nullptr; size_t best_dots = 0; uint32_t best_cnt = 0;
-        for (auto& kv : all) {   // std::map iterates alphabetically: the first of equals wins the tie
-            size_t dots = (size_t)std::count(kv.first.begin(), kv.first.end(), '.');
-            if (!best || dots < best_dots || (dots == best_dots && kv.second > best_cnt)) { best = &kv.first; best_dots = dots; best_cnt = kv.second; }
-        }
-        std::string& f = seqs[pid / 2].forward_seq;
-        if (pid & 1) f.replace(f.size() - m, m, *best); else f.replace(0, m, *best);
-    }
-}
-
 // compress.rs:84-133
-LoadResult load_sequences(const std::string& assemblies_dir, uint32_t k, uint32_t max_contigs, int threads, bool repair) {
+LoadResult load_sequences(const std::string& assemblies_dir, uint32_t k, uint32_t max_contigs, int threads) {
     LoadResult lr;
     double t0 = now_s();
     std::vector<std::string> assemblies = find_all_assemblies(assemblies_dir);
@@ -301,10 +207,8 @@ LoadResult load_sequences(const std::string& assemblies_dir, uint32_t k, uint32_
         throw UserError(std::string("the mean number of contigs per input assembly (") + buf + ") exceeds the allowed threshold (" +
                         std::to_string(max_contigs) + "). Are your input assemblies fragmented or contaminated?");
     }
-    double t1 = now_s();
-    if (repair) sequence_end_repair(lr.seqs, k, threads);
-    lr.load_seconds = t1 - t0;
-    lr.repair_seconds = now_s() - t1;
+    lr.load_seconds = now_s() - t0;      // (sequence_end_repair, compress.rs:202-270, is a device kernel: neighbours.inc — the callers in capi.cpp run it)
+    lr.repair_seconds = 0;
     return lr;
 }
 

@@ -82,7 +82,7 @@ def make_inputs(args, rank, sharded_job):
 
 
 def prepare(lib, k, seqs, fn, hd, n_assemblies, threads, repair=1):
-    """Sequence::new_with_seq (+ sequence_end_repair on the host when repair=1) — upstream of the timed region."""
+    """Sequence::new_with_seq (+ sequence_end_repair when repair=1: ac_seqs_from_raw runs it on the device text and brings the ends back) — upstream of the timed region."""
     from autocycler_amd import _capi
     n = len(seqs)
     ptrs = (C.c_void_p * n)(*[s.ctypes.data for s in seqs])
@@ -169,7 +169,8 @@ def main():
     ap.add_argument("--init-builds", type=int, default=2, help="untimed builds before the warmup (one-time process initialisation)")
     ap.add_argument("--init-seconds", type=float, default=1.5, help="keep running untimed builds until this much time has passed (device clocks ramp up under load)")
     ap.add_argument("--repair", choices=["device", "host"], default="device",
-                    help="where sequence_end_repair runs (upstream of the timed region): on the device text, or the host implementation")
+                    help="where the sequences are when sequence_end_repair runs (upstream of the timed region; the device kernels either way): 'device' = "
+                         "on the resident device text (ac_end_repair_device), 'host' = through ac_seqs_from_raw (host sequences up, repaired ends back)")
     ap.add_argument("--no-independent", action="store_true", help="N > 1: skip the secondary independent-jobs measurement")
     ap.add_argument("--no-multi-entry", action="store_true", help="N > 1: skip the secondary measurement of the same job through ac_compress_build_multi (one process, N devices)")
     ap.add_argument("--species", choices=["per-gpu", "one"], default="per-gpu",
@@ -246,6 +247,7 @@ def main():
     else:
         seqs, fn, hd = make_inputs(args, rank, mode == "sharded")
     t_gen = time.time() - t0
+    lib.ac_set_host_side_device(C.c_int(local_rank))      # (one process per GPU: the host-side helpers' end repair runs on this rank's device)
     h_seqs = prepare(lib, k, seqs, fn, hd, args.assemblies, threads=os.cpu_count() or 1, repair=1 if args.repair == "host" else 0)
     del seqs
     n = lib.ac_seqs_count(h_seqs)

@@ -72,6 +72,7 @@ typedef struct {
     uint64_t n_degrees_open;     /* sharded builds: k-mers whose degrees the sibling bits did not settle (= bytes of the compact degree exchange) */
     uint64_t sort_retries;       /* builds repeated because a sort's "group too large" flag, read with the last read-back, was set */
     double insert_rest_known;    /* share of a sample of the insert's one-launch rest that the first two stretches already held (sizes the rest's chunks); 0 = no such rest */
+    double insert_rest_sampled;  /* share of that rest the sample could cover: only text that was on the device when it was taken (an upload still in flight: its first chunks) */
 } ac_timings;
 
 /* Replaces compress.rs:42-44.  k: --kmer (odd).  assembly_count: the reference's capacity hint
@@ -352,7 +353,11 @@ void ac_string_free(char*);
  * CLI (autocycler-compress), the tests and the benchmarks. */
 typedef struct ac_seqs ac_seqs;
 int ac_seqs_load(const char* assemblies_dir, uint32_t k, uint32_t max_contigs, int threads, ac_seqs** out);
-/* Sequence::new_with_seq (sequence.rs:31-59) for ids 1..n + optional sequence_end_repair (compress.rs:202-236). */
+/* The device the host-side helpers below run sequence_end_repair on (ac_seqs_load, ac_seqs_from_raw with repair: the padded sequences
+ * go up as text, the device kernels of ac_end_repair_device patch it, the sequence ends come back — the library holds no host
+ * implementation of the repair).  Default 0; one process per GPU sets its own ordinal. */
+int ac_set_host_side_device(int device);
+/* Sequence::new_with_seq (sequence.rs:31-59) for ids 1..n + optional sequence_end_repair (compress.rs:202-236, on the device). */
 int ac_seqs_from_raw(uint32_t k, uint32_t n, const uint8_t* const* seqs, const uint32_t* lens,
                      const char* const* filenames, const char* const* headers, uint32_t assembly_count, int repair,
                      int threads, ac_seqs** out);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Whole-command timing (T_e2e of SURVEY.md §8d) on the GPU box: synthetic config-C FASTA directory -> autocycler-compress CLI
-# -> input_assemblies.gfa / .yaml, cold and warm, with the device and with the host end repair.  Usage: tools/e2e.sh TAG [N=96]
+# -> input_assemblies.gfa / .yaml, cold and warm.  Usage: tools/e2e.sh TAG [N=96]
 TAG=${1:-rXX}; N=${2:-96}
 mkdir -p gpurun_out
 D=/tmp/e2e_in; O=/tmp/e2e_out
@@ -14,6 +14,5 @@ du -sh $D | cut -f1
 for run in 1 2; do
   rm -rf $O; ./autocycler_amd/autocycler-compress -i $D -a $O -t 32 2>&1 | grep -E "Stage times|Time to run|unitigs" | tr '\n' ' '; echo
 done
-rm -rf $O; AC_HOST_REPAIR=1 ./autocycler_amd/autocycler-compress -i $D -a $O -t 32 2>&1 | grep -E "Stage times|Time to run" | tr '\n' ' '; echo "(host end repair)"
 ls -la $O; md5sum $O/input_assemblies.gfa
 rm -rf $O; ./autocycler_amd/autocycler-compress -i $D -a $O -t 32 2>/dev/null; md5sum $O/input_assemblies.gfa

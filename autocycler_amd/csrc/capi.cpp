@@ -62,7 +62,10 @@ template <class F> static int guarded(F&& f) {
     catch (...) { g_err = "unknown internal error"; scan_pool().invalidate(); return 1; }
 }
 
-static void select_device(int device) {
+static void select_device(int device, bool refresh_tuning = true) {
+    // (tests / the A/B tool change AC_* variables between builds: AC_TUNING_FOLLOW_ENV; else the knobs were read once.  The rank threads of a
+    // multi-device build do not refresh: their entry point did, before it started them)
+    if (refresh_tuning) tuning_refresh();
 #ifndef AC_EMU
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -91,7 +94,7 @@ static void select_device(int device) {
     }
 }
 
-namespace ac { void select_device_checked(int device) { select_device(device); } }
+namespace ac { void select_device_checked(int device) { select_device(device, /*refresh_tuning=*/false); } }
 
 static void validate(uint32_t k, const ac_seq_view* seqs, uint32_t n_seqs) {
     if (!seqs || n_seqs == 0) throw DeviceError("no sequences found in input assemblies");
@@ -261,8 +264,9 @@ int ac_compress_build_multi(uint32_t k, uint32_t assembly_count, const ac_seq_vi
             h->seq_ids.push_back(seqs[i].id);
             h->seq_lens.push_back(seqs[i].length);
         }
+        tuning_refresh();
         int transport = MULTI_AUTO;
-        if (const char* e = getenv("AC_MULTI_TRANSPORT")) transport = !strcmp(e, "host") ? MULTI_HOST_STAGED : (!strcmp(e, "rccl") ? MULTI_RCCL : MULTI_AUTO);
+        if (const int e = tuning_multi_transport()) transport = e == 1 ? MULTI_HOST_STAGED : MULTI_RCCL;
         build_multi(k, assembly_count, v, std::vector<int>(devices, devices + n_devices), transport, &h->g, &h->tm, &h->multi);
         *out = h.release();
     });

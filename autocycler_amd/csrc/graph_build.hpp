@@ -194,6 +194,11 @@ void pack_text_host(const uint8_t* text, uint64_t n_text, uint64_t* bits, uint32
 void release_host_stager();
 
 int max_supported_k();
+// The environment knobs are read once per process (graph_impl.hpp: Knobs); these are the ones code outside the graph build asks for.
+void tuning_refresh();                       // re-reads them if AC_TUNING_FOLLOW_ENV was set (tests, tools/ab_knobs.py); called under the build lock
+int tuning_multi_transport();                // AC_MULTI_TRANSPORT: 0 unset, 1 host, 2 rccl
+bool tuning_multi_fragments_as_bytes();      // AC_MULTI_FRAGMENTS=bytes
+bool tuning_multi_tail_replicated();         // AC_MULTI_TAIL=replicated
 void set_stage_timing(bool on);   // per-stage timers (a stream sync per stage); off by default
 bool stage_timing();
 

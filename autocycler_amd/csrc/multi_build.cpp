@@ -285,8 +285,7 @@ void rank_main(Shared& S, int rank) {
     uint8_t* d_meta = (uint8_t*)xalloc(nf_total * 8);
     {
         // the fragment texts travel as 2-bit codes on the union text's word grid (a quarter of the bytes; AC_MULTI_FRAGMENTS=bytes: as text)
-        const char* fenv = getenv("AC_MULTI_FRAGMENTS");
-        const bool as_bytes = fenv && std::string(fenv) == "bytes";
+        const bool as_bytes = tuning_multi_fragments_as_bytes();
         const Arena::Mark mk = rc.xarena.mark();
         uint8_t* my_meta = (uint8_t*)xalloc(mb[rank]);
         if (as_bytes) {
@@ -410,8 +409,7 @@ void rank_main(Shared& S, int rank) {
     // SUM all-reduces inside shard_finish (kernels_tail.inc; AC_MULTI_TAIL=replicated: every rank runs every junction, as before round 4);
     // rank 0 keeps unitigs + links, every rank the paths of its own sequences
     uint64_t tail_bytes = 0;
-    const char* tail_env = getenv("AC_MULTI_TAIL");
-    const bool tail_replicated = tail_env && std::string(tail_env) == "replicated";
+    const bool tail_replicated = tuning_multi_tail_replicated();
     if (!tail_replicated)
         b.set_tail_exchange([&](void* d_buf, uint64_t count, int dtype, int op) {
             tail_bytes += count * (dtype == 0 ? 1 : 4);

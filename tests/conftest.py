@@ -6,6 +6,9 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
+# The library reads its AC_* tuning knobs ONCE per process; the knob-parity tests change them between builds of this process
+# (monkeypatch.setenv): this variable, read when the library is first used, makes every build read them again.
+os.environ.setdefault("AC_TUNING_FOLLOW_ENV", "1")
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 

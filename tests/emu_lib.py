@@ -14,5 +14,5 @@ def emu_path():
     with open(EMU.parent / ".build.lock", "w") as lock:      # pytest-xdist workers: one builds, the others wait (never load a half-written .so)
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not EMU.exists() or any(s.stat().st_mtime > EMU.stat().st_mtime for s in srcs):
-            subprocess.check_call(["make", "-C", str(ROOT / "autocycler_amd" / "csrc"), "emu"], stdout=subprocess.DEVNULL)
+            subprocess.check_call(["make", "-j", "4", "-C", str(ROOT / "autocycler_amd" / "csrc"), "emu"], stdout=subprocess.DEVNULL)
     return EMU

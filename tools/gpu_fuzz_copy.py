@@ -3,6 +3,7 @@
 redundant assembly sets — where the insert follows long runs and the copying walk engages — against the oracle, under random
 settings of the run piece length and the bound.  Time-limited:   python tools/gpu_fuzz_copy.py [SECONDS]"""
 import os, random, sys, time
+os.environ.setdefault("AC_TUNING_FOLLOW_ENV", "1")      # (the knobs are read once per process otherwise)
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))

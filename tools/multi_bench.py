@@ -15,6 +15,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault("AC_NO_TORCH", "1")
+os.environ.setdefault("AC_TUNING_FOLLOW_ENV", "1")      # the variants change AC_* knobs between builds of this process
 
 
 def bench_job(args):

@@ -313,7 +313,7 @@ bool path_remap_is_wide();      // the host has the 16-lane gather (without it a
 void path_remap_start(PathRemapJob& j, int threads);      // returns at once; the work runs on the packing threads' pool
 void path_remap_finish(PathRemapJob& j) noexcept;         // until every thread is done (idempotent)
 [[maybe_unused]] static int key_words(int k) { int w = words_for_k(k); return w <= 4 ? w : (w <= 8 ? 8 : 16); }
-static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
+[[maybe_unused]] static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 // Device memory one build of an n_text-byte text needs, roughly: packed text + bitmaps (~0.6 B/position), staging slots
 // of the path walk (4 B/position), k-mer table and per-k-mer arrays (sized by distinct content), unitig-sized buffers.
 [[maybe_unused]] static size_t arena_estimate(u64 n_text, bool owns_text) { return (size_t)n_text * (owns_text ? 8 : 7) + ((size_t)768 << 20); }
@@ -626,11 +626,15 @@ struct GraphBuilder::Impl {
     DBuf<int32_t> links; DBuf<u64> wlinks;
     // per-occurrence quantities from the walk over loc
     DBuf<u32> depth, minpos_fwd, minpos_rev; DBuf<u64> path_off; DBuf<int32_t> ent_val; u64 n_ent = 0;
+    // the walk's own numbering is TEXT order (kernels_paths.inc): its successor table, and its outputs before walk_to_seed_order
+    DBuf<u64> wl_text; DBuf<u32> depth_u, minpos_fwd_u, minpos_rev_u, run_start, run_end;
+    void walk_tables(bool filter, bool plain);      // wl_text + the working arrays (plain: with the stretch counters of the plain walk)
+    void walk_to_seed_order();                      // depth / smallest positions by seed-order index, for the tail
     DBuf<u8> fs0, fe0;
     // single-device builds: smallest positions beyond it are kept as a lower bound only (kernels_tail.inc exp_avoid_start_of_path); all ones = exact
     u32 pos_cap_now = 0xFFFFFFFFu; bool exact_positions = false;
     bool host_remap_allowed = false;      // GraphBuilder::build, and a rank of a sharded build that keeps its own paths: the result block of the paths is this build's own
-    bool paths_in_seed_numbers = false;   // the tail left ent_val in seed numbers (the host renumbered the copy it took)
+    bool paths_in_seed_numbers = false;   // the tail left ent_val as the walk wrote it — in TEXT-order numbers since round 6 — (the host renumbered the copy it took)
     // single-device builds: the "group too large" flags of the seed sort and of the two renumberings are read with the build's LAST read-back
     // (sort_flags: [0] seed ties, [1] renumbering) and a build that had one set is repeated with every flag checked where it is raised
     bool checked_sorts = false; DBuf<u32> sort_flags;
@@ -781,6 +785,29 @@ inline void GraphBuilder::Impl::novel_list(u64 known_n) {
     launch_wave_kernel(fill_novel_wave_kernel<0>, (n_bm_words + 255) / 256, 0, (const u64*)bm.ptr(), (const u32*)wprefix.ptr(), npos.ptr(), n_bm_words);
     kinfo.alloc(N, true);
     lap(&tm->collect_sort);
+}
+
+// The walk's tables in text-order numbering (kernels_paths.inc): the successor table permuted, the outputs' working arrays.
+inline void GraphBuilder::Impl::walk_tables(bool filter, bool plain) {
+    launch((u64)U * 10, WlinkFlagFunctor{filter ? maybe_dest.ptr() : nullptr, wlinks.ptr(), counters.ptr() + 4});
+    wl_text.alloc((u64)U * 10);
+    launch((u64)U * 10, WlinkTextOrderFunctor{wlinks.ptr(), rank.ptr(), order.ptr(), wl_text.ptr()});
+    depth_u.alloc(U, true); minpos_fwd_u.alloc(U); minpos_rev_u.alloc(U);
+    if (pos_cap_now == 0xFFFFFFFFu) { minpos_fwd_u.fill_bytes(0xFF); minpos_rev_u.fill_bytes(0xFF); }
+    else launch(U, FillU32PairFunctor{minpos_fwd_u.ptr(), minpos_rev_u.ptr(), (pos_cap_now + 1) | POS_BOUND});
+    if (plain) { run_start.alloc((u64)U + 1, true); run_end.alloc((u64)U + 1, true); }
+    else { run_start = DBuf<u32>(); run_end = DBuf<u32>(); }
+}
+inline void GraphBuilder::Impl::walk_to_seed_order() {
+    depth.alloc(U); minpos_fwd.alloc(U); minpos_rev.alloc(U);
+    DBuf<u32> started, ended;
+    if (run_start.size()) {
+        started.alloc((u64)U + 1); ended.alloc((u64)U + 1);
+        inclusive_scan_u32(run_start.ptr(), started.ptr(), (u64)U + 1);      // stretches that began at or before u
+        exclusive_scan_u32(run_end.ptr(), ended.ptr(), (u64)U + 1);          // ... and those that ended before u
+    }
+    launch(U, WalkToSeedOrderFunctor{order.ptr(), depth_u.ptr(), run_start.size() ? started.ptr() : nullptr, run_start.size() ? ended.ptr() : nullptr,
+                                     minpos_fwd_u.ptr(), minpos_rev_u.ptr(), depth.ptr(), minpos_fwd.ptr(), minpos_rev.ptr()});
 }
 
 // The width-dependent stages behind one explicitly instantiated type per width.  The main unit only sees declarations, so it

@@ -654,17 +654,17 @@ template <int W> void GraphBuilder::Impl::walk_copy_finish(u32 PC) {
     DBuf<u32> seq_tid(loc.n_seqs), seq_j(loc.n_seqs);
     wcount.fill_bytes(0);
     const bool filter = maybe_dest_valid;
-    launch((u64)U * 10, WlinkFlagFunctor{filter ? maybe_dest.ptr() : nullptr, wlinks.ptr(), counters.ptr() + 4});
+    walk_tables(filter, /*plain=*/false);
     DBuf<V16> uinfo(U);
     launch(U, WalkInfoFunctor{uc, filter ? maybe_dest.ptr() : nullptr, uinfo.ptr()});
-    launch(NW, PathWalkFunctor<W>{t, g, tb, nv, uc, uinfo.ptr(), wlinks.ptr(), PC, stage.ptr(), wcount.ptr(), seq_tid.ptr(), seq_j.ptr(),
-                                 depth.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), counters.ptr() + 4, filter ? maybe_dest.ptr() : nullptr,
-                                 pos_cap_now, 0, walk_answers, NW, c.w_begin.ptr(), c.w_end.ptr(), stage_off.ptr()});
+    launch(NW, PathWalkFunctor<W>{t, g, tb, nv, uc, uinfo.ptr(), wl_text.ptr(), PC, stage.ptr(), wcount.ptr(), seq_tid.ptr(), seq_j.ptr(),
+                                 depth_u.ptr(), minpos_fwd_u.ptr(), minpos_rev_u.ptr(), counters.ptr() + 4, filter ? maybe_dest.ptr() : nullptr,
+                                 pos_cap_now, 0, walk_answers, NW, c.w_begin.ptr(), c.w_end.ptr(), stage_off.ptr(), nullptr, nullptr});
     exclusive_scan_u64(wcount.ptr(), woff.ptr(), NW + 1);
     const u64 NE = read_scalar(woff.ptr() + NW);      // walked entries
     DBuf<int32_t> ent(NE); DBuf<u64> ent_pos(NE), ent_end(NE); DBuf<u8> ent_want(NE); DBuf<u32> ent_gap(NE);
-    launch_full(NW, WalkCompactFunctor{stage.ptr(), stage_off.ptr(), wcount.ptr(), woff.ptr(), c.w_begin.ptr(), c.w_gap.ptr(), PC, NW, ulen.ptr(),
-                                       filter ? maybe_dest.ptr() : nullptr, ent.ptr(), ent_pos.ptr(), ent_end.ptr(), ent_want.ptr(), ent_gap.ptr()});
+    launch_full(NW, WalkCompactFunctor{stage.ptr(), stage_off.ptr(), wcount.ptr(), woff.ptr(), c.w_begin.ptr(), c.w_gap.ptr(), PC, NW, uinfo.ptr(),
+                                       ent.ptr(), ent_pos.ptr(), ent_end.ptr(), ent_want.ptr(), ent_gap.ptr()});
     // what every run copies; entries per segment; the final array
     DBuf<u64> ra(R), rcnt(R + 1), seg(2 * R + 2), segoff(2 * R + 2); DBuf<u32> cov(NE + 1), copies(NE + 1);
     cov.fill_bytes(0);
@@ -682,14 +682,15 @@ template <int W> void GraphBuilder::Impl::walk_copy_finish(u32 PC) {
     // (the scratch above stays where it is until the build ends: for a text this redundant it is a fraction of the text's size)
     ent_val.alloc(n_ent);
     int32_t* const out_ptr = ent_val.ptr();
-    launch(NE, GapOutFunctor{ent.ptr(), ent_gap.ptr(), woff.ptr(), c.wfirst.ptr(), segoff.ptr(), copies.ptr(), out_ptr, depth.ptr()});
-    launch_full(R * 32, RunOutFunctor<32, 1>{c.rr.ptr(), R, ra.ptr(), rcnt.ptr(), segoff.ptr(), ent.ptr(), ent_pos.ptr(), ent_end.ptr(), ulen.ptr(),
-                                             ent_want.ptr(), t, c.rseq.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), out_ptr, pos_cap_now});
+    launch(NE, GapOutFunctor{ent.ptr(), ent_gap.ptr(), woff.ptr(), c.wfirst.ptr(), segoff.ptr(), copies.ptr(), out_ptr, depth_u.ptr()});
+    launch_full(R * 32, RunOutFunctor<32, 1>{c.rr.ptr(), R, ra.ptr(), rcnt.ptr(), segoff.ptr(), ent.ptr(), ent_pos.ptr(), ent_end.ptr(), uinfo.ptr(),
+                                             ent_want.ptr(), t, c.rseq.ptr(), minpos_fwd_u.ptr(), minpos_rev_u.ptr(), out_ptr, pos_cap_now});
     launch(loc.n_seqs, PathOffCopyFunctor{seq_tid.ptr(), seq_j.ptr(), woff.ptr(), c.wfirst.ptr(), c.w_gap.ptr(), segoff.ptr(), path_off.ptr()});
     tm->n_path_entries = n_ent;
     tm->path_runs_copied = R; tm->path_entries_walked = NE;
     copy_h2d(path_off.ptr() + loc.n_seqs, &n_ent, 8);
-    launch(loc.n_seqs, PathEndsFunctor{ent_val.ptr(), path_off.ptr(), fs0.ptr(), fe0.ptr()});
+    launch(loc.n_seqs, PathEndsFunctor{ent_val.ptr(), path_off.ptr(), fs0.ptr(), fe0.ptr(), rank.ptr()});
+    walk_to_seed_order();
 }
 
 // K10 paths of this rank's sequences against the graph: count, scan, write; first / last unitig of every path.
@@ -700,13 +701,8 @@ template <int W> void GraphBuilder::Impl::walk() {
     UnitigCtx uc{head.ptr(), scan.ptr(), rank.ptr(), uorient.ptr(), ustart.ptr(), ulen.ptr(), U, N};
     const u32 PC = path_chunk(N, U);
     u64 n_walkers = (loc.n_text + PC - 1) / PC;
-    depth.alloc(U, true); minpos_fwd.alloc(U); minpos_rev.alloc(U);
     // (sharded builds keep exact positions: a repeat of the build would have to be agreed between the ranks)
     pos_cap_now = (exact_positions || walk_answers || n_owners > 1 || G != &loc || pos_cap() == 0) ? 0xFFFFFFFFu : pos_cap();
-    if (pos_cap_now == 0xFFFFFFFFu) { minpos_fwd.fill_bytes(0xFF); minpos_rev.fill_bytes(0xFF); }
-    else {
-        launch(U, FillU32PairFunctor{minpos_fwd.ptr(), minpos_rev.ptr(), (pos_cap_now + 1) | POS_BOUND});
-    }
     path_off.alloc((u64)loc.n_seqs + 1);
     const bool filter = path_filter();
     maybe_dest_valid = filter;
@@ -715,6 +711,7 @@ template <int W> void GraphBuilder::Impl::walk() {
     if (walk_answers) {      // a sharded build planned (or not) before the walk-start keys went out (walk_queries)
         if (cplan.ok) { walk_copy_finish<W>(PC); lap(&tm->paths); return; }
     } else if (run_rows && n_owners <= 1 && G == &loc && PC <= 65535 && walk_copy_prepare<W>(PC, nv)) { walk_copy_finish<W>(PC); lap(&tm->paths); return; }
+    walk_tables(filter, /*plain=*/true);      // (before the mark: the tables and working arrays outlive the staging area)
     // everything from here to the compaction is the walk's own: 4 bytes of staging per text position (configs[4]: 20 GB) go back to
     // the arena once the entries are compacted — they are compacted into the staging area's own first bytes
     const Arena::Mark walk_mark = Arena::device().mark();
@@ -722,12 +719,11 @@ template <int W> void GraphBuilder::Impl::walk() {
     DBuf<u64> wcount(n_walkers + 1), woff(n_walkers + 1);
     DBuf<u32> seq_tid(loc.n_seqs), seq_j(loc.n_seqs);
     wcount.fill_bytes(0);
-    launch((u64)U * 10, WlinkFlagFunctor{filter ? maybe_dest.ptr() : nullptr, wlinks.ptr(), counters.ptr() + 4});
     DBuf<V16> uinfo(U);
     launch(U, WalkInfoFunctor{uc, filter ? maybe_dest.ptr() : nullptr, uinfo.ptr()});
-    launch(n_walkers, PathWalkFunctor<W>{t, g, tb, nv, uc, uinfo.ptr(), wlinks.ptr(), PC, stage.ptr(), wcount.ptr(), seq_tid.ptr(), seq_j.ptr(),
-                                        depth.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), counters.ptr() + 4, filter ? maybe_dest.ptr() : nullptr,
-                                        pos_cap_now, path_diag(), walk_answers, n_walkers});
+    launch(n_walkers, PathWalkFunctor<W>{t, g, tb, nv, uc, uinfo.ptr(), wl_text.ptr(), PC, stage.ptr(), wcount.ptr(), seq_tid.ptr(), seq_j.ptr(),
+                                        depth_u.ptr(), minpos_fwd_u.ptr(), minpos_rev_u.ptr(), counters.ptr() + 4, filter ? maybe_dest.ptr() : nullptr,
+                                        pos_cap_now, path_diag(), walk_answers, n_walkers, nullptr, nullptr, nullptr, run_start.ptr(), run_end.ptr()});
     exclusive_scan_u64(wcount.ptr(), woff.ptr(), n_walkers + 1);
     n_ent = read_scalar(woff.ptr() + n_walkers);
     launch(loc.n_seqs, PathOffFunctor{seq_tid.ptr(), seq_j.ptr(), woff.ptr(), path_off.ptr()});
@@ -741,7 +737,8 @@ template <int W> void GraphBuilder::Impl::walk() {
         ent_val.alloc(n_ent);             // where the staging area began; `packed` lies behind the staging area's end (n_ent <= its size)
         if (ent_val.ptr() != packed.ptr()) copy_d2d(ent_val.ptr(), packed.ptr(), n_ent * 4);
     }
-    launch(loc.n_seqs, PathEndsFunctor{ent_val.ptr(), path_off.ptr(), fs0.ptr(), fe0.ptr()});
+    launch(loc.n_seqs, PathEndsFunctor{ent_val.ptr(), path_off.ptr(), fs0.ptr(), fe0.ptr(), rank.ptr()});
+    walk_to_seed_order();
     lap(&tm->paths);
 }
 
@@ -975,7 +972,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     DBuf<u32> order2(U);
     copy_d2d(order2.ptr(), order1.ptr(), (size_t)U * 4);
     renumber_sort(order2, U, clen.ptr(), coff.ptr(), cur, depth.ptr(), defer_sorts ? sort_flags.ptr() + 1 : renum_flag.ptr(), defer_sorts);
-    DBuf<u64> number_len(U), lcount((u64)U + 1), loff((u64)U + 1);
+    DBuf<u64> number_len(U), number_len_text(U), lcount((u64)U + 1), loff((u64)U + 1);      // (_text: by text-order index, what the path entries are in)
     DBuf<u32> number_only(host_remap ? U : 0);
     DBuf<u8> meta((size_t)U * 24);
     u64* d_seq_begin = (u64*)meta.ptr();
@@ -987,7 +984,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     out->n_kmers = 2 * (u64)N;
     out->n_unitigs = U;
     launch(U, FinalMetaFunctor{order2.ptr(), coff.ptr(), clen.ptr(), depth.ptr(), lcnt.ptr(), number_len.ptr(), d_seq_begin, d_depth,
-                               d_seq_len, lcount.ptr(), host_remap ? number_only.ptr() : nullptr, d_seed_index});
+                               d_seq_len, lcount.ptr(), host_remap ? number_only.ptr() : nullptr, d_seed_index, order.ptr(), number_len_text.ptr()});
     if (host_remap) {      // the number table first: the host threads start on the entries while the rest is still crossing
         number_block = PinnedPool::get().alloc((size_t)U * 4);
         side.after_main();
@@ -1019,7 +1016,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     if (host_remap) {      // the device only checks that every path spells its sequence's length (the sums), it stores nothing
         const u64 RB = remap_block();
         const u64 n_waves = (n_ent + RB - 1) / RB;
-        launch_full(n_waves * 64, RemapFunctor{ent_val.ptr(), number_len.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr(), 0, (u32)RB, nullptr, false});
+        launch_full(n_waves * 64, RemapFunctor{ent_val.ptr(), number_len_text.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr(), 0, (u32)RB, nullptr, false});
     } else {
         if (want_paths) out->path_block = PinnedPool::get().alloc(n_ent * 4);
         const u64 RB = remap_block();
@@ -1029,7 +1026,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         const u64 per_chunk = std::max<u64>((n_waves + 3) / 4, 64);
         for (u64 w = 0; w < n_waves; w += per_chunk) {
             u64 cnt = std::min<u64>(per_chunk, n_waves - w);
-            launch_full(cnt * 64, RemapFunctor{ent_val.ptr(), number_len.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr(), w, (u32)RB, nullptr, true});
+            launch_full(cnt * 64, RemapFunctor{ent_val.ptr(), number_len_text.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr(), w, (u32)RB, nullptr, true});
             if (want_paths) {
                 u64 b = w * RB, e2 = std::min<u64>((w + cnt) * RB, n_ent);
                 side.after_main();

@@ -14,6 +14,7 @@
 // The same kernel source runs under the lockstep emulation (AC_EMU): its workgroups run one after the other in ticket order, so a look-back
 // always finds its predecessors complete.
 #pragma once
+#include <type_traits>
 
 namespace ac {
 
@@ -90,8 +91,11 @@ enum { CTX_SCANPOOL = 7 };
 inline ScanPool& scan_pool() { return ctx_object<ScanPool>(CTX_SCANPOOL); }
 
 // out[i] = op over in[0 .. i] (INCL) or in[0 .. i) (exclusive; identity 0).  Values (and their running totals) stay below 2^46 (the pipeline's are counts and byte offsets of a text of < 2^40 positions).
-template <class T, int OP, bool INCL>
-AC_KERNEL void __launch_bounds__(256) scan_kernel(const T* in, T* out, u64 n, u64* pool, u64 epoch, u64 ticket_base) {
+// SRC: where the items come from — ScanPtr<T> (an array: 16-byte loads), or a functor computing item i on the fly (round 6: a producer
+// kernel and its array saved; the functor may store what it computes).
+template <class T> struct ScanPtr { const T* p; };
+template <class T, int OP, bool INCL, class SRC>
+AC_KERNEL void __launch_bounds__(256) scan_kernel(SRC src, T* out, u64 n, u64* pool, u64 epoch, u64 ticket_base) {
     AC_SHARED u64 s_wave[4];
     AC_SHARED u64 s_prefix;
     AC_SHARED u64 s_tile;
@@ -103,14 +107,20 @@ AC_KERNEL void __launch_bounds__(256) scan_kernel(const T* in, T* out, u64 n, u6
     const u64 tile = s_tile;
     const u64 base = tile * SCAN_TILE + (u64)tid * SCAN_ITEMS;
     alignas(16) T v[SCAN_ITEMS];
-    if (base + SCAN_ITEMS <= n && (((uintptr_t)(in + base)) & 15u) == 0) {      // whole and aligned: 16-byte loads
-        const PrimV16* p = (const PrimV16*)(in + base);
-        PrimV16* q = (PrimV16*)v;
+    if constexpr (std::is_same<SRC, ScanPtr<T>>::value) {
+        const T* in = src.p;
+        if (base + SCAN_ITEMS <= n && (((uintptr_t)(in + base)) & 15u) == 0) {      // whole and aligned: 16-byte loads
+            const PrimV16* p = (const PrimV16*)(in + base);
+            PrimV16* q = (PrimV16*)v;
 #pragma unroll
-        for (u32 j = 0; j < SCAN_ITEMS * sizeof(T) / 16; j++) q[j] = p[j];
+            for (u32 j = 0; j < SCAN_ITEMS * sizeof(T) / 16; j++) q[j] = p[j];
+        } else {
+#pragma unroll
+            for (u32 j = 0; j < SCAN_ITEMS; j++) v[j] = base + j < n ? in[base + j] : (T)0;
+        }
     } else {
 #pragma unroll
-        for (u32 j = 0; j < SCAN_ITEMS; j++) v[j] = base + j < n ? in[base + j] : (T)0;
+        for (u32 j = 0; j < SCAN_ITEMS; j++) v[j] = base + j < n ? (T)src(base + j) : (T)0;
     }
     u64 tsum = 0;
 #pragma unroll
@@ -172,15 +182,19 @@ AC_KERNEL void __launch_bounds__(256) scan_kernel(const T* in, T* out, u64 n, u6
         for (u32 j = 0; j < SCAN_ITEMS; j++) if (base + j < n) out[base + j] = o[j];
     }
 }
-template <class T, int OP, bool INCL> inline void scan_launch(const T* in, T* out, size_t n, stream_t s) {
+template <class T, int OP, bool INCL, class SRC> inline void scan_launch_src(SRC src, T* out, size_t n, stream_t s) {
     if (!n) return;
     if (s != 0) throw DeviceError("scan: stream 0 only (the state pool's tickets are stream-ordered)");
     const u64 tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     u64 epoch = 0, ticket_base = 0;
     ScanPool& pool = scan_pool();
     pool.take(tiles, &epoch, &ticket_base);
-    launch_wave_kernel(scan_kernel<T, OP, INCL>, tiles, s, in, out, (u64)n, pool.words, epoch, ticket_base);
+    launch_wave_kernel(scan_kernel<T, OP, INCL, SRC>, tiles, s, src, out, (u64)n, pool.words, epoch, ticket_base);
 }
+template <class T, int OP, bool INCL> inline void scan_launch(const T* in, T* out, size_t n, stream_t s) { scan_launch_src<T, OP, INCL, ScanPtr<T>>(ScanPtr<T>{in}, out, n, s); }
+// out[i] = the sum of src(0) .. src(i) (inclusive) / src(0) .. src(i - 1) (exclusive): the items are computed, not loaded
+template <class SRC> inline void inclusive_scan_u32_of(SRC src, u32* out, size_t n) { scan_launch_src<u32, SCAN_ADD, true, SRC>(src, out, n, 0); }
+template <class SRC> inline void exclusive_scan_u32_of(SRC src, u32* out, size_t n) { scan_launch_src<u32, SCAN_ADD, false, SRC>(src, out, n, 0); }
 inline void inclusive_scan_u32(const u32* in, u32* out, size_t n, stream_t s = 0) { scan_launch<u32, SCAN_ADD, true>(in, out, n, s); }
 inline void inclusive_max_scan_u32(const u32* in, u32* out, size_t n, stream_t s = 0) { scan_launch<u32, SCAN_MAX, true>(in, out, n, s); }
 inline void exclusive_scan_u32(const u32* in, u32* out, size_t n, stream_t s = 0) { scan_launch<u32, SCAN_ADD, false>(in, out, n, s); }
@@ -318,14 +332,28 @@ AC_KERNEL void __launch_bounds__(256) radix_pass_kernel(const u64* kin, const V*
         if (i < n) { const u32 dst = s_base[wave * 256 + (int)dig[r]] + rank[r]; kout[dst] = key[r]; vout[dst] = val[r]; }
     }
 }
-template <class V> inline void radix_sort_pairs_impl(DBuf<u64>& keys, DBuf<V>& vals, size_t n, int begin_bit, int end_bit, stream_t s) {
+// What a sort needs cleared before it starts (digit histograms, tile states, tile tickets).  A caller that knows its sorts ahead of time
+// prepare()s their scratch before its next launch, so that the clears leave with the fills of that launch's batch instead of as a launch of
+// their own right before every sort (round 6: a build ran four such launches).  One use per prepare().
+struct RadixScratch {
+    DBuf<u32> hist; DBuf<u64> state, ticket; size_t n = 0; int passes = 0; bool ready = false;
+    void prepare(size_t n_items, int key_bits, stream_t s = 0) {
+        n = n_items; passes = std::min<int>((key_bits + 7) / 8, (int)8); ready = n > 1 && passes > 0;
+        if (!ready) return;
+        hist.alloc((size_t)passes * 256); state.alloc(((n + 2047) / 2048) * 256); ticket.alloc(8);
+        hist.fill_bytes(0, s); state.fill_bytes(0, s); ticket.fill_bytes(0, s);
+    }
+};
+template <class V> inline void radix_sort_pairs_impl(DBuf<u64>& keys, DBuf<V>& vals, size_t n, int begin_bit, int end_bit, stream_t s, RadixScratch* pre = nullptr) {
     if (n <= 1 || end_bit <= begin_bit) return;
     if (n >= 0xFFFFFFF0ULL) throw DeviceError("radix sort: more than 2^32 items");
     const int passes = (end_bit - begin_bit + 7) / 8;
     const u64 tiles = (n + RS_TILE - 1) / RS_TILE;
     DBuf<u64> k2(n); DBuf<V> v2(n);
-    DBuf<u32> hist((size_t)passes * 256); DBuf<u64> state(tiles * 256), ticket(RS_MAX_PASSES);
-    hist.fill_bytes(0, s); state.fill_bytes(0, s); ticket.fill_bytes(0, s);
+    RadixScratch own;
+    if (!(pre && pre->ready && pre->n >= n && pre->passes >= passes)) { own.prepare(n, end_bit - begin_bit, s); pre = &own; }
+    pre->ready = false;
+    DBuf<u32>& hist = pre->hist; DBuf<u64>& state = pre->state; DBuf<u64>& ticket = pre->ticket;
     launch_wave_kernel(radix_hist_kernel<0>, tiles, s, (const u64*)keys.ptr(), (u64)n, passes, begin_bit, end_bit, hist.ptr());
     u64* ka = keys.ptr(); u64* kb = k2.ptr(); V* va = vals.ptr(); V* vb = v2.ptr();
     for (int p = 0; p < passes; p++) {
@@ -338,7 +366,7 @@ template <class V> inline void radix_sort_pairs_impl(DBuf<u64>& keys, DBuf<V>& v
     if (passes & 1) { keys = std::move(k2); vals = std::move(v2); }
 }
 // (bits below begin_bit and from end_bit up do not take part: the order among keys that agree on [begin_bit, end_bit) is the input's)
-inline void sort_pairs_u64_u32(DBuf<u64>& keys, DBuf<u32>& vals, size_t n, int end_bit, stream_t s = 0, int begin_bit = 0) { radix_sort_pairs_impl<u32>(keys, vals, n, begin_bit, end_bit, s); }
+inline void sort_pairs_u64_u32(DBuf<u64>& keys, DBuf<u32>& vals, size_t n, int end_bit, stream_t s = 0, int begin_bit = 0, RadixScratch* pre = nullptr) { radix_sort_pairs_impl<u32>(keys, vals, n, begin_bit, end_bit, s, pre); }
 inline void sort_pairs_u64_i32(DBuf<u64>& keys, DBuf<int32_t>& vals, size_t n, int end_bit, stream_t s = 0, int begin_bit = 0) { radix_sort_pairs_impl<int32_t>(keys, vals, n, begin_bit, end_bit, s); }
 
 // ---- fallback paths ---------------------------------------------------------------------------------------------------------------

@@ -628,8 +628,10 @@ struct GraphBuilder::Impl {
     DBuf<u32> depth, minpos_fwd, minpos_rev; DBuf<u64> path_off; DBuf<int32_t> ent_val; u64 n_ent = 0;
     // the walk's own numbering is TEXT order (kernels_paths.inc): its successor table, and its outputs before walk_to_seed_order
     DBuf<u64> wl_text; DBuf<u32> depth_u, minpos_fwd_u, minpos_rev_u, run_start, run_end;
-    void walk_tables(bool filter, bool plain);      // wl_text + the working arrays (plain: with the stretch counters of the plain walk)
+    void walk_arrays();                             // the working arrays (allocated, their clears queued)
+    void walk_tables(bool filter);                  // wl_text, the smallest positions' start value
     void walk_to_seed_order();                      // depth / smallest positions by seed-order index, for the tail
+    bool walked_plain = false;                      // the plain walk ran (its stretch counters hold depth), not the copying one
     DBuf<u8> fs0, fe0;
     // single-device builds: smallest positions beyond it are kept as a lower bound only (kernels_tail.inc exp_avoid_start_of_path); all ones = exact
     u32 pos_cap_now = 0xFFFFFFFFu; bool exact_positions = false;
@@ -665,7 +667,7 @@ struct GraphBuilder::Impl {
     // The plan of a copying walk (walk_copy_prepare): the usable pieces, the gaps between them cut into walkers.  A sharded build makes it
     // before the walk-start keys go to their owners (the walkers ARE the gap walkers then) and walks when the answers are back.
     struct CopyPlan { bool ok = false; u64 R = 0, NW = 0, Rb = 0; DBuf<RunRec> rr; DBuf<u32> rseq; DBuf<u64> wfirst, w_begin, w_end; DBuf<u32> w_gap; } cplan;
-    void occupancy_bitmap(const DBuf<u64>& sl, u64 c, DBuf<u64>* occ_out, const u64* sflags_in, u64* sib_out);
+    void occupancy_bitmap(const DBuf<u64>& sl, u64 c, DBuf<u64>* occ_out, const u64* sflags_in, u64* sib_out, stream_t s = 0);
     DBuf<u64> occ;             // slot-occupancy bitmap of the graph table
     DBuf<u64> sib;             // sibling bits of the graph table's real k-mers, two per text position (MarkFunctor); empty = not used
     DBuf<u64> sibn; bool sib_pending = false;      // sharded builds: the sibling bits by NOVEL INDEX (SibByRankFunctor) — this rank's, then the ranks' sum; pending = not summed yet
@@ -754,59 +756,56 @@ struct GraphBuilder::Impl {
 };
 
 // Slot-occupancy bitmap of a finished table (one ballot word per wavefront of the scan; no atomics).
-inline void GraphBuilder::Impl::occupancy_bitmap(const DBuf<u64>& sl, u64 c, DBuf<u64>* occ_out, const u64* sflags_in, u64* sib_out) {
+inline void GraphBuilder::Impl::occupancy_bitmap(const DBuf<u64>& sl, u64 c, DBuf<u64>* occ_out, const u64* sflags_in, u64* sib_out, stream_t s) {
     occ_out->alloc((c + 63) / 64);
 #ifdef AC_EMU
     occ_out->fill_bytes(0);      // the serial emulation ORs bit by bit; the device writes whole ballot words
 #endif
-    launch_full(c, MarkFunctor{sl.ptr(), occ_out->ptr(), sflags_in, sib_out});
+    launch_full(c, MarkFunctor{sl.ptr(), occ_out->ptr(), sflags_in, sib_out}, s);
 }
 // K3: novel-position bitmap -> sorted novel list + rank support.  known_n = the number of set bits if the caller knows it (the
 // single-device insert counted its claims), 0 = count them here.
 inline void GraphBuilder::Impl::novel_list(u64 known_n) {
     PackedText& g = *G;
     u64 n_bm_words = g.n_text / 64 + 1;
-    DBuf<u32> wcnt(n_bm_words);
-    wprefix.alloc(n_bm_words);
-    launch(n_bm_words, PopcFunctor{bm.ptr(), wcnt.ptr()});
-    exclusive_scan_u32(wcnt.ptr(), wprefix.ptr(), n_bm_words);
+    wprefix.alloc(n_bm_words + 1);
+    exclusive_scan_u32_of(PopcSrc{bm.ptr(), n_bm_words}, wprefix.ptr(), n_bm_words + 1);      // (the counts are the scan's source: no array, no kernel of their own; [n_bm_words] = the total)
     if (known_n) N = known_n;
     else {
-        u32 last[2];
-        ReadBatch rb;
-        rb.add(&last[0], wprefix.ptr() + (n_bm_words - 1), 4);
-        rb.add(&last[1], wcnt.ptr() + (n_bm_words - 1), 4);
-        rb.run();
-        N = (u64)last[0] + last[1];
+        N = read_scalar(wprefix.ptr() + n_bm_words);
         if (N == 0) throw DeviceError("internal error: no k-mers in the union of the shards");
         tm->n_distinct = N;
     }
     npos.alloc(N);
     launch_wave_kernel(fill_novel_wave_kernel<0>, (n_bm_words + 255) / 256, 0, (const u64*)bm.ptr(), (const u32*)wprefix.ptr(), npos.ptr(), n_bm_words);
     kinfo.alloc(N, true);
+    // (K7's arrays here, so that their one-entry tails are cleared in the batch that clears kinfo: HeadFunctor and the scan write 0 .. N - 1)
+    head.alloc(N + 1); scan.alloc(N + 1);
+    head.fill_bytes_from(N * 4, 0); scan.fill_bytes_from(N * 4, 0);
     lap(&tm->collect_sort);
 }
 
-// The walk's tables in text-order numbering (kernels_paths.inc): the successor table permuted, the outputs' working arrays.
-inline void GraphBuilder::Impl::walk_tables(bool filter, bool plain) {
-    launch((u64)U * 10, WlinkFlagFunctor{filter ? maybe_dest.ptr() : nullptr, wlinks.ptr(), counters.ptr() + 4});
+// The walk's tables in text-order numbering (kernels_paths.inc).  walk_arrays: the working arrays, allocated (and their clears queued) before
+// the stage's first launch; walk_tables: the successor table permuted (+ the smallest positions' start value).
+inline void GraphBuilder::Impl::walk_arrays() {
     wl_text.alloc((u64)U * 10);
-    launch((u64)U * 10, WlinkTextOrderFunctor{wlinks.ptr(), rank.ptr(), order.ptr(), wl_text.ptr()});
     depth_u.alloc(U, true); minpos_fwd_u.alloc(U); minpos_rev_u.alloc(U);
-    if (pos_cap_now == 0xFFFFFFFFu) { minpos_fwd_u.fill_bytes(0xFF); minpos_rev_u.fill_bytes(0xFF); }
-    else launch(U, FillU32PairFunctor{minpos_fwd_u.ptr(), minpos_rev_u.ptr(), (pos_cap_now + 1) | POS_BOUND});
-    if (plain) { run_start.alloc((u64)U + 1, true); run_end.alloc((u64)U + 1, true); }
-    else { run_start = DBuf<u32>(); run_end = DBuf<u32>(); }
+    run_start.alloc((u64)U + 1, true); run_end.alloc((u64)U + 1, true);
+}
+inline void GraphBuilder::Impl::walk_tables(bool filter) {
+    launch((u64)U * 10, WlinkFlagFunctor{filter ? maybe_dest.ptr() : nullptr, wlinks.ptr(), counters.ptr() + 4});
+    const u32 pos_init = pos_cap_now == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((pos_cap_now + 1) | POS_BOUND);
+    launch((u64)U * 10, WlinkTextOrderFunctor{wlinks.ptr(), rank.ptr(), order.ptr(), wl_text.ptr(), minpos_fwd_u.ptr(), minpos_rev_u.ptr(), pos_init});
 }
 inline void GraphBuilder::Impl::walk_to_seed_order() {
     depth.alloc(U); minpos_fwd.alloc(U); minpos_rev.alloc(U);
     DBuf<u32> started, ended;
-    if (run_start.size()) {
+    if (walked_plain) {
         started.alloc((u64)U + 1); ended.alloc((u64)U + 1);
         inclusive_scan_u32(run_start.ptr(), started.ptr(), (u64)U + 1);      // stretches that began at or before u
         exclusive_scan_u32(run_end.ptr(), ended.ptr(), (u64)U + 1);          // ... and those that ended before u
     }
-    launch(U, WalkToSeedOrderFunctor{order.ptr(), depth_u.ptr(), run_start.size() ? started.ptr() : nullptr, run_start.size() ? ended.ptr() : nullptr,
+    launch(U, WalkToSeedOrderFunctor{order.ptr(), depth_u.ptr(), walked_plain ? started.ptr() : nullptr, walked_plain ? ended.ptr() : nullptr,
                                      minpos_fwd_u.ptr(), minpos_rev_u.ptr(), depth.ptr(), minpos_fwd.ptr(), minpos_rev.ptr()});
 }
 

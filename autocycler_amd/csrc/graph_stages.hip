@@ -11,17 +11,19 @@ namespace ac {
 [[maybe_unused]] static u32 renum_max_group() { return knobs().renum_max_group; }      // tests: smaller groups take the fallbacks
 // deferred: do not wait for the "group too large" flag (a host round trip per renumbering) — the caller reads it with the build's last
 // read-back and repeats the build with checked sorts if it was ever set (GraphBuilder::build; the flag is sticky then: never cleared here).
-[[maybe_unused]] static void renumber_sort(DBuf<u32>& order, u32 U, const u32* len, const u64* off, const u8* seq, const u32* depth, u32* flag, bool deferred = false) {
+// sc: the sort's scratch if the caller prepared it (RadixScratch); len_bits: no unitig is 2^len_bits long or longer (the keys' leading
+// field is ~length: its bits above that are ones in every key and need no pass)
+[[maybe_unused]] static void renumber_sort(DBuf<u32>& order, u32 U, const u32* len, const u64* off, const u8* seq, const u32* depth, u32* flag, bool deferred = false,
+                                           RadixScratch* sc = nullptr, int len_bits = 32) {
     if (U <= 1) return;
     DBuf<u32> backup(deferred && !renum_two_pass() ? 0 : U);      // (the order to fall back from: only a checked sort ever does)
     if (backup.size()) copy_d2d(backup.ptr(), order.ptr(), (size_t)U * 4);
     DBuf<u64> prefix(U), key(U);
-    launch(U, RenumKeyFunctor{len, off, seq, prefix.ptr()});
     UnitigLess less{len, off, seq, depth};
     u32 zero = 0;
     if (!renum_two_pass()) {      // one sort on (length | 16 bases), ties by the comparator
-        launch(U, RenumPassFunctor{order.ptr(), len, depth, prefix.ptr(), 2, key.ptr()});
-        sort_pairs_u64_u32(key, order, U, 64);
+        launch(U, RenumKeyPassFunctor{RenumKeyFunctor{len, off, seq, prefix.ptr()}, RenumPassFunctor{order.ptr(), len, depth, prefix.ptr(), 2, key.ptr()}});
+        sort_pairs_u64_u32(key, order, U, 32 + std::min(std::max(len_bits, 1), 32), 0, 0, sc);
         launch(U, RenumTieFunctor{order.ptr(), U, len, depth, prefix.ptr(), less, flag, 0, renum_max_group()});
 #ifdef AC_EMU
         if (knobs().degree_diag) {
@@ -40,6 +42,7 @@ namespace ac {
         copy_d2d(order.ptr(), backup.ptr(), (size_t)U * 4);      // a large group of unitigs sharing length and 16 bases: the two-pass form
         copy_h2d(flag, &zero, 4);
     }
+    if (renum_two_pass()) launch(U, RenumKeyFunctor{len, off, seq, prefix.ptr()});      // (else the one-pass attempt above left the prefixes)
     for (int pass = 0; pass < 2; pass++) {
         launch(U, RenumPassFunctor{order.ptr(), len, depth, prefix.ptr(), pass, key.ptr()});
         sort_pairs_u64_u32(key, order, U, 64);
@@ -340,6 +343,21 @@ template <int W> void GraphBuilder::Impl::table() {
     if (sib_by_pos) { sib.alloc(2 * (g.n_text / 64 + 2)); sib.fill_bytes(0); }
     else sib = DBuf<u64>();
     sibn = DBuf<u64>(); sib_pending = false;
+#ifndef AC_EMU
+    if (n_owners <= 1) {
+        // Round 6: the table scan (occupancy bitmap + sibling bits: 8 bytes per SLOT, config C 268 MB) on the side stream, beside the novel
+        // list (bitmap -> rank support -> sorted list: 1/8 + 8 bytes per position) — neither reads what the other writes, each alone runs at
+        // a third of the device's bandwidth.  Stream 0 waits for the scan before the degree stage, its first reader.
+        SideStream& side = SideStream::get();
+        side.after_main();      // (the insert, and the fill of `sib`, are done)
+        occupancy_bitmap(slots, cap, &occ, sib_by_pos ? sflags.ptr() : nullptr, sib_by_pos ? sib.ptr() : nullptr, side.stream());
+        void* scanned = side.mark();
+        novel_list(N);
+        flush_fills();
+        AC_HIP_CHECK(hipStreamWaitEvent(0, (hipEvent_t)scanned, 0));
+        return;
+    }
+#endif
     occupancy_bitmap(slots, cap, &occ, sib_by_pos ? sflags.ptr() : nullptr, sib_by_pos ? sib.ptr() : nullptr);
     if (n_owners <= 1) novel_list(N);      // a sharded build first sums the ranks' (disjoint) bitmaps: bitmap_import
 }
@@ -364,8 +382,9 @@ template <int W> void GraphBuilder::Impl::degrees() {
         endset_bloom.alloc(2 * ENDSET_BLOOM_WORDS);
         endset_bloom.fill_bytes(0);
         es = EndSet{endset.ptr(), endset_mask, endset_bloom.ptr(), endset_bloom.ptr() + ENDSET_BLOOM_WORDS};
-        launch(2 * (u64)g.n_seqs, EndSetFunctor<W>{g.ctx((int)k), es});
     }
+    // (launched below, behind the allocations of whichever branch runs: their fills then leave in one batch with the set's own)
+    auto fill_end_set = [&] { if (es.keys) launch(2 * (u64)g.n_seqs, EndSetFunctor<W>{g.ctx((int)k), es}); };
     const u8* fflags = g.has_flags ? g.seq_flags.ptr() : nullptr;
     if (sib_ptr && degree_flags() == 1 && (!g.any_dots || es.keys)) {      // settle what the sibling bits settle, queue the rest, probe the queues
         // Sharded builds (round 5): the light step is the same on every rank (it reads the text and the summed bit planes only) and its
@@ -379,6 +398,7 @@ template <int W> void GraphBuilder::Impl::degrees() {
             pend.fill_bytes_from(N * 4, 0);
             fslot.alloc((u64)g.n_seqs + 1);
             DBuf<u32> fcnt((u64)g.n_seqs + 1);
+            fill_end_set();
             launch((u64)g.n_seqs + 1, FirstSlotCountFunctor{fflags, g.n_seqs, fcnt.ptr()});
             exclusive_scan_u32(fcnt.ptr(), fslot.ptr(), (u64)g.n_seqs + 1);
         }
@@ -392,6 +412,7 @@ template <int W> void GraphBuilder::Impl::degrees() {
         DBuf<u64> items(wk.words()); DBuf<u32> counts(DEG_LISTS * (DEG_REGIONS + 1));
         counts.fill_bytes(0);
         wk.items = items.ptr(); wk.counts = counts.ptr();
+        if (!by_index) fill_end_set();
         const u64 n_thr = (((N + DEG_BATCH - 1) / DEG_BATCH) + 63) & ~63ULL;
         launch_full(n_thr, DegreeLightFunctor<W>{g.ctx((int)k), npos.ptr(), kinfo.ptr(), g.any_dots, bm.ptr(), sib_ptr, es, wk, N, n_thr, by_index ? 1 : 0,
                                                  by_index ? pend.ptr() : nullptr});
@@ -440,8 +461,10 @@ template <int W> void GraphBuilder::Impl::degrees() {
             lap(&tm->degree);
             return;
         }
-    } else
+    } else {
+        fill_end_set();
         launch(N, DegreeFunctor<W>{g.ctx((int)k), tb, npos.ptr(), kinfo.ptr(), g.any_dots, 0, bm.ptr(), sib.size() && n_owners <= 1 ? sib.ptr() : nullptr, es});
+    }
     launch(g.n_seqs, FirstFunctor<W>{g.ctx((int)k), tb, nv, kout, fflags, nullptr, nullptr});
     lap(&tm->degree);
 }
@@ -453,12 +476,15 @@ template <int W> void GraphBuilder::Impl::unitigs() {
     Table tb = graph_table();
     Novel nv{bm.ptr(), wprefix.ptr()};
     // K7 heads -> unitig ids
-    head.alloc(N + 1); scan.alloc(N + 1);      // (HeadFunctor and the scan write entries 0 .. N - 1)
-    head.fill_bytes_from(N * 4, 0); scan.fill_bytes_from(N * 4, 0);
-    launch(N, HeadFunctor{npos.ptr(), kinfo.ptr(), head.ptr(), N});
-    inclusive_scan_u32(head.ptr(), scan.ptr(), N);
+    // (head / scan: allocated, and their tails cleared, by novel_list)
+    inclusive_scan_u32_of(HeadSrc{HeadFunctor{npos.ptr(), kinfo.ptr(), head.ptr(), N}}, scan.ptr(), N);      // (K7's flags computed, stored and summed by the scan itself)
     U = read_scalar(scan.ptr() + (N - 1));
     ustart.alloc((u64)U + 1);
+    // (what the seed order needs cleared — its sort's scratch, the flag of its tie-break — now, with this launch's batch)
+    int seed_keep = seed_prefix_bits();
+    if (seed_keep <= 0) { int lg = 1; while ((1ULL << lg) < (u64)U) lg++; seed_keep = std::min(64, ((2 * lg + 8 + 7) / 8) * 8); }
+    RadixScratch seed_rs; DBuf<u32> seed_big(1, true);
+    if (seed_prefix_sort()) seed_rs.prepare(U, seed_keep);
     launch(N, UnitigStartFunctor{head.ptr(), scan.ptr(), ustart.ptr(), N});
     lap(&tm->segment);
 
@@ -495,18 +521,16 @@ template <int W> void GraphBuilder::Impl::unitigs() {
 
     // K9 seed order = rank of the smallest k-mer
     order.alloc(U);
-    launch(U, IotaFunctor{order.ptr()});
     bool seeds_ordered = false;
     if (seed_prefix_sort()) {      // one sort on a 64-bit prefix of the seed keys, ties on full keys: any key width, any number of unitigs
         DBuf<u64> wkey(U);
         // as many leading bits of the prefix as tell U seeds apart with a few ties to spare (twice log2 U, and a byte for the bias of a
         // MINIMUM towards small values): the ties are ranked on full keys anyway (SeedTieFunctor), and every digit less is a pass less
-        int keep = seed_prefix_bits();
-        if (keep <= 0) { int lg = 1; while ((1ULL << lg) < (u64)U) lg++; keep = std::min(64, ((2 * lg + 8 + 7) / 8) * 8); }
+        const int keep = seed_keep;
         DBuf<u32> by_prefix(U);
         launch(U, SeedPrefixFunctor<W>{umin.ptr(), (int)k, wkey.ptr(), keep, by_prefix.ptr()});      // (... and the identity the sort permutes)
-        sort_pairs_u64_u32(wkey, by_prefix, U, 64, 0, 64 - keep);
-        DBuf<u32> settled(U), big(1, true);
+        sort_pairs_u64_u32(wkey, by_prefix, U, 64, 0, 64 - keep, &seed_rs);
+        DBuf<u32> settled(U); DBuf<u32>& big = seed_big;
         // (a single-device build does not wait for the "group too large" flag: it is read with the build's last read-back, and a build in
         // which it was set is repeated with checked sorts — one host round trip less here, two in the renumberings)
         const bool defer = deferred_sort_checks();
@@ -519,6 +543,7 @@ template <int W> void GraphBuilder::Impl::unitigs() {
             seeds_ordered = true;
         }      // else: a huge group of equal prefixes — `order` is still the identity: the full-key sorts below
     }
+    if (!seeds_ordered) launch(U, IotaFunctor{order.ptr()});      // (the full-key sorts permute the identity)
     if (seeds_ordered) {
     } else if constexpr (W <= 4) {
         if ((u64)U >= seed_radix_limit() || seed_prefix_sort()) {      // many unitigs (or the prefix sort's fallback) (mixed-species graphs: millions): W stable LSD radix passes over the key words
@@ -564,10 +589,8 @@ template <int W> void GraphBuilder::Impl::walk_queries() {
     cplan = CopyPlan();
     if (run_rows && loc_bm.size() && PC <= 65535) {
         const u64 nw = loc.n_text / 64 + 1;
-        DBuf<u32> wcnt(nw);
-        loc_wprefix.alloc(nw);
-        launch(nw, PopcFunctor{loc_bm.ptr(), wcnt.ptr()});
-        exclusive_scan_u32(wcnt.ptr(), loc_wprefix.ptr(), nw);
+        loc_wprefix.alloc(nw + 1);
+        exclusive_scan_u32_of(PopcSrc{loc_bm.ptr(), nw}, loc_wprefix.ptr(), nw + 1);
         if (walk_copy_prepare<W>(PC, Novel{loc_bm.ptr(), loc_wprefix.ptr()})) n_walkers = cplan.NW;
     }
     n_queries = n_walkers + loc.n_seqs;
@@ -654,7 +677,8 @@ template <int W> void GraphBuilder::Impl::walk_copy_finish(u32 PC) {
     DBuf<u32> seq_tid(loc.n_seqs), seq_j(loc.n_seqs);
     wcount.fill_bytes(0);
     const bool filter = maybe_dest_valid;
-    walk_tables(filter, /*plain=*/false);
+    walk_tables(filter);
+    walked_plain = false;
     DBuf<V16> uinfo(U);
     launch(U, WalkInfoFunctor{uc, filter ? maybe_dest.ptr() : nullptr, uinfo.ptr()});
     launch(NW, PathWalkFunctor<W>{t, g, tb, nv, uc, uinfo.ptr(), wl_text.ptr(), PC, stage.ptr(), wcount.ptr(), seq_tid.ptr(), seq_j.ptr(),
@@ -706,19 +730,22 @@ template <int W> void GraphBuilder::Impl::walk() {
     path_off.alloc((u64)loc.n_seqs + 1);
     const bool filter = path_filter();
     maybe_dest_valid = filter;
-    if (filter) { maybe_dest.alloc((u64)U * 2); launch((u64)U * 2, MaybeDestFunctor{links.ptr(), maybe_dest.ptr()}); }
     fs0.alloc(U, true); fe0.alloc(U, true);
+    walk_arrays();      // (everything the stage needs cleared is queued before its first launch: one fill batch)
+    DBuf<u64> wcount_plain(n_walkers + 1);      // (the plain walk's counts; a copying walk sizes its own)
+    wcount_plain.fill_bytes(0);
+    if (filter) { maybe_dest.alloc((u64)U * 2); launch((u64)U * 2, MaybeDestFunctor{links.ptr(), maybe_dest.ptr()}); }
     if (walk_answers) {      // a sharded build planned (or not) before the walk-start keys went out (walk_queries)
         if (cplan.ok) { walk_copy_finish<W>(PC); lap(&tm->paths); return; }
     } else if (run_rows && n_owners <= 1 && G == &loc && PC <= 65535 && walk_copy_prepare<W>(PC, nv)) { walk_copy_finish<W>(PC); lap(&tm->paths); return; }
-    walk_tables(filter, /*plain=*/true);      // (before the mark: the tables and working arrays outlive the staging area)
+    walk_tables(filter);
+    walked_plain = true;
     // everything from here to the compaction is the walk's own: 4 bytes of staging per text position (configs[4]: 20 GB) go back to
     // the arena once the entries are compacted — they are compacted into the staging area's own first bytes
     const Arena::Mark walk_mark = Arena::device().mark();
     DBuf<int32_t> stage(((n_walkers + 63) / 64) * 64 * PC);
-    DBuf<u64> wcount(n_walkers + 1), woff(n_walkers + 1);
+    DBuf<u64>& wcount = wcount_plain; DBuf<u64> woff(n_walkers + 1);
     DBuf<u32> seq_tid(loc.n_seqs), seq_j(loc.n_seqs);
-    wcount.fill_bytes(0);
     DBuf<V16> uinfo(U);
     launch(U, WalkInfoFunctor{uc, filter ? maybe_dest.ptr() : nullptr, uinfo.ptr()});
     launch(n_walkers, PathWalkFunctor<W>{t, g, tb, nv, uc, uinfo.ptr(), wl_text.ptr(), PC, stage.ptr(), wcount.ptr(), seq_tid.ptr(), seq_j.ptr(),
@@ -732,7 +759,7 @@ template <int W> void GraphBuilder::Impl::walk() {
     {
         DBuf<int32_t> packed(n_ent);      // (beyond the staging area: the compaction reads rows that later wavefronts' outputs would overwrite)
         launch_full(((n_walkers + 63) / 64) * 64, PathCompactFunctor{stage.ptr(), wcount.ptr(), woff.ptr(), PC, n_walkers, packed.ptr()});
-        stage = DBuf<int32_t>(); wcount = DBuf<u64>(); woff = DBuf<u64>(); seq_tid = DBuf<u32>(); seq_j = DBuf<u32>(); uinfo = DBuf<V16>();
+        stage = DBuf<int32_t>(); woff = DBuf<u64>(); seq_tid = DBuf<u32>(); seq_j = DBuf<u32>(); uinfo = DBuf<V16>();
         Arena::device().rewind(walk_mark);
         ent_val.alloc(n_ent);             // where the staging area began; `packed` lies behind the staging area's end (n_ent <= its size)
         if (ent_val.ptr() != packed.ptr()) copy_d2d(ent_val.ptr(), packed.ptr(), n_ent * 4);
@@ -785,6 +812,21 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         if (mode == 0) launch_wave_kernel(seq_write_kernel<0>, (n_blocks + 255) / 256, 0, q, e0, off, (const u32*)first.ptr(), U, n_bytes, dst);
         else launch_wave_kernel(seq_write_kernel<1>, (n_blocks + 255) / 256, 0, q, *es, off, (const u32*)first.ptr(), U, n_bytes, dst);
     };
+    // Round 6: every buffer of the tail that starts out cleared — and the scratch of its two renumbering sorts — is allocated HERE, before the
+    // tail's first launch, so that their fills leave as one batch with it (a buffer cleared right before its first use cost a fill launch
+    // each: fourteen of them between here and the last read-back of a config C build).
+    const u64 J = (u64)U * 2;
+    DBuf<u8> fixed_start(U, true), fixed_end(U, true), cand((u64)U * 2);
+    DBuf<u32> renum_flag(1, true), cflag(J + 1), pool_used(EXP_SUBPOOLS + 1);
+    cflag.fill_bytes(0);       // [J] = 0: the exclusive scan then ends with the total
+    pool_used.fill_bytes(0);
+    static const u32 SHIFT_CHECKS = 64;      // host checks of the pass loop whose "moved something" words are cleared up front (two words per check)
+    DBuf<u64> shifted2(2 * SHIFT_CHECKS), lcount((u64)U + 1), sums(n_seqs);
+    shifted2.fill_bytes(0); lcount.fill_bytes(0); sums.fill_bytes(0);
+    RadixScratch sort1, sort2;
+    int len_bits = 32;      // no unitig is longer than the longest sequence of a text whose sequences this build knows
+    if (G == &loc && !loc.h_len.empty()) { u32 mx = 0; for (u32 l : loc.h_len) mx = std::max(mx, l); len_bits = 1; while (len_bits < 32 && (mx >> len_bits)) len_bits++; }
+    if (!renum_two_pass()) { sort1.prepare(U, 32 + len_bits); sort2.prepare(U, 32 + len_bits); }
     write_seqs(0, nullptr, useq_off.ptr(), total, useq.ptr());
     lap(&tm->seqs);
 
@@ -792,23 +834,21 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     DBuf<int32_t> lord((u64)U * 10); DBuf<u8> lcnt((u64)U * 2);
     launch((u64)U * 2, LinkOrderFunctor{links.ptr(), lord.ptr(), lcnt.ptr(), counters.ptr() + 5});
     OrderedLinks L{lord.ptr(), lcnt.ptr()};
-    DBuf<u8> fixed_start(U, true), fixed_end(U, true), cand((u64)U * 2);
     launch(U, FixedSpreadFunctor{fs0.ptr(), fe0.ptr(), L, fixed_start.ptr(), fixed_end.ptr()});
     launch((u64)U * 2, CandFunctor{L, fixed_start.ptr(), fixed_end.ptr(), cand.ptr()});
     if (maybe_dest_valid)      // the walk only collected smallest positions where maybe_dest says so: every real candidate must be covered
         launch((u64)U * 2, CandCoveredFunctor{cand.ptr(), maybe_dest.ptr(), counters.ptr() + 4});
     DBuf<u32> order1(U);
     launch(U, IotaFunctor{order1.ptr()});
-    DBuf<u32> renum_flag(1, true);
     const bool defer_sorts = deferred_sort_checks();
-    renumber_sort(order1, U, ulen.ptr(), useq_off.ptr(), useq.ptr(), depth.ptr(), defer_sorts ? sort_flags.ptr() + 1 : renum_flag.ptr(), defer_sorts);
+    renumber_sort(order1, U, ulen.ptr(), useq_off.ptr(), useq.ptr(), depth.ptr(), defer_sorts ? sort_flags.ptr() + 1 : renum_flag.ptr(), defer_sorts, &sort1, len_bits);
     lap(&tm->analysis);
 
     // K17 expand_repeats, level-scheduled (see the kernels)
     DBuf<u64> coff(U), len64((u64)U + 1), noff((u64)U + 1);
     DBuf<u32> clen(U); DBuf<ExpU> ev(U);      // the views of expand_repeats (one 32-byte record per unitig); coff / clen: offsets and lengths as plain arrays for what follows
     DBuf<u8> seq_alt(total), pool(std::min<u64>(8 * total + (1u << 20), 0xFFFFFFF0ULL)), dirty((u64)U * 2);
-    DBuf<u64> shifted(1); DBuf<u32> pool_used(EXP_SUBPOOLS + 1);
+    DBuf<u64> shifted(1);
     launch(U, ExpInitFunctor{useq_off.ptr(), ulen.ptr(), cand.ptr(), ev.ptr(), coff.ptr(), clen.ptr(), dirty.ptr()});      // core views = the unitigs, dirty = the candidates (three copies, one launch)
     u8* cur = useq.ptr(); u8* alt = seq_alt.ptr();
     u64 final_total = total;
@@ -818,9 +858,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     DBuf<u8> jowner; DBuf<u32> owned_count, gpre, gpost;
     u32 n_cand_owned = 0;
     {
-        u64 J = (u64)U * 2;
-        DBuf<u32> cflag(J + 1), cpos(J + 1), prio(J);
-        cflag.fill_bytes(0);       // [J] = 0: the exclusive scan then ends with the total
+        DBuf<u32> cpos(J + 1), prio(J);
         launch(J, CandFlagFunctor{order1.ptr(), cand.ptr(), cflag.ptr()});
         exclusive_scan_u32(cflag.ptr(), cpos.ptr(), J + 1);
         n_cand = read_scalar(cpos.ptr() + J);
@@ -830,9 +868,12 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             u64 C = n_cand;
             DBuf<u32> clist(C), level(C);
             prio.fill_bytes(0xFF);
+            DBuf<u32> changed(9), preds(C * MAX_PREDS); DBuf<u8> npred(C);
+            changed.fill_bytes(0);      // (the first round of sweeps: cleared with this batch)
+            RadixScratch sort_lv;
+            sort_lv.prepare(C, 32);
             launch(J, CandListFunctor{order1.ptr(), cflag.ptr(), cpos.ptr(), clist.ptr(), prio.ptr()});
             launch(C, FillU32Functor{level.ptr(), 1u});
-            DBuf<u32> changed(9), preds(C * MAX_PREDS); DBuf<u8> npred(C);
             DBuf<V16> touch(U);      // the candidate junctions touching each unitig: for the conflict lists here and for every junction that moves something
             launch(U, TouchFunctor{L, cand.ptr(), touch.ptr()});
             launch(C, LevelPredsFunctor{L, cand.ptr(), clist.ptr(), prio.ptr(), C, preds.ptr(), npred.ptr(), touch.ptr()});
@@ -846,8 +887,8 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                 gpre.alloc(U, true); gpost.alloc(U, true);
             }
             u32 max_level = 1;
-            for (;;) {   // longest-path levels of the conflict DAG, settled front to back (LevelRelaxFunctor); eight sweeps per host
-                changed.fill_bytes(0);       // check, done when the last of them left no candidate open (a sweep settles one more level)
+            for (int round = 0;; round++) {   // longest-path levels of the conflict DAG, settled front to back (LevelRelaxFunctor); eight sweeps per host
+                if (round) changed.fill_bytes(0);       // check, done when the last of them left no candidate open (a sweep settles one more level)
                 for (int it = 0; it < 8; it++)
                     launch(C, LevelRelaxFunctor{preds.ptr(), npred.ptr(), C, level.ptr(), changed.ptr() + it, it ? changed.ptr() + it - 1 : nullptr, changed.ptr() + 8});
                 const std::vector<u32> hc = to_host(changed, 9);
@@ -858,7 +899,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             launch(C, LevelKeyFunctor{level.ptr(), lkey.ptr()});
             int level_bits = 1;
             while (level_bits < 32 && (max_level >> level_bits)) level_bits++;
-            sort_pairs_u64_u32(lkey, clist, C, level_bits);      // (the highest level came back with the convergence flags: one or two digits)
+            sort_pairs_u64_u32(lkey, clist, C, level_bits, 0, 0, &sort_lv);      // (the highest level came back with the convergence flags: one or two digits)
             // first index of every level; [0] = number of levels (levels beyond the table: a second, exact read)
             const u32 LV_TABLE = expand_level_table();
             DBuf<u32> bstart((u64)LV_TABLE + 2);
@@ -873,13 +914,11 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             hb.resize((size_t)n_levels + 2);
             hb[n_levels + 1] = (u32)C;
             ExpState e{cur, ev.ptr(), pool.ptr(), pool_used.ptr(), minpos_fwd.ptr(), minpos_rev.ptr(), dirty.ptr(), cand.ptr(), L, shifted.ptr(), touch.ptr()};
-            pool_used.fill_bytes(0);
             u64 moved = 0, moved_since_rewrite = 0;
-            DBuf<u64> shifted2(2);
             // Rewrites the sequences contiguously (gained pieces folded into the core views) and empties the pool.  Once after the
             // last pass — and in between whenever the pool is a quarter full: a side that gains again gets a new piece holding its
             // old one as well, so without this the pool use of a many-pass input grows with the square of the passes.
-            auto rewrite = [&] {
+            auto rewrite = [&](bool last) {
                 if (partitioned) launch(U, ExpFoldFunctor{e, gpre.ptr(), gpost.ptr()});      // (what the fold makes of the gained pieces: the merge below)
                 launch((u64)U + 1, ExpLenFunctor{e, len64.ptr(), U});
                 exclusive_scan_u64(len64.ptr(), noff.ptr(), (u64)U + 1);
@@ -888,7 +927,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                 launch(U, ExpResetFunctor{e, noff.ptr(), coff.ptr(), clen.ptr()});
                 std::swap(cur, alt);
                 e.cur = cur;
-                pool_used.fill_bytes(0);
+                if (!last) pool_used.fill_bytes(0);      // (nothing allocates from the pool after the last rewrite)
                 moved_since_rewrite = 0;
             };
             const u32 sub_limit = (u32)(pool.size() / 2 / EXP_SUBPOOLS / 2);      // a region half full (or anything in the overflow half) asks for a rewrite
@@ -899,17 +938,18 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                 // wins from config C to mixed-species graphs)
                 if (cnt) launch_wave_kernel(expand_wave_kernel<W, 16>, (cnt * 16 + 255) / 256, 0, e, (const u32*)clist.ptr(), (u64)hb[lv], cnt, (u32)pool.size(), counters.ptr() + 7);
             };
-            for (;;) {   // two passes per host check: if the first moved nothing the second is an (uncounted) no-op
-                shifted2.fill_bytes(0);
+            for (u32 check = 0;; check++) {   // two passes per host check: if the first moved nothing the second is an (uncounted) no-op
+                u64* const sh_words = shifted2.ptr() + 2 * (u64)(check % SHIFT_CHECKS);
+                if (check && check % SHIFT_CHECKS == 0) shifted2.fill_bytes(0);      // (the words cleared up front are used up)
                 for (int half = 0; half < 2; half++) {
-                    e.shifted = shifted2.ptr() + half;
+                    e.shifted = sh_words + half;
                     for (u32 lv = 1; lv <= n_levels; lv++) run_level(lv);
                 }
                 u64 sh[2]; u32 used = 0;
                 {
                     std::vector<u32> pu(EXP_SUBPOOLS + 1);
                     ReadBatch rb;
-                    rb.add(sh, shifted2.ptr(), 16);
+                    rb.add(sh, sh_words, 16);
                     rb.add(pu.data(), pool_used.ptr(), (EXP_SUBPOOLS + 1) * 4);
                     rb.run();
                     for (u32 q = 0; q < EXP_SUBPOOLS; q++) used = std::max(used, pu[q]);
@@ -919,9 +959,9 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                 if (sh[0] == 0) { passes += 1; break; }
                 passes += 2;
                 if (sh[1] == 0) break;
-                if (used > sub_limit || expand_rewrite_always()) rewrite();
+                if (used > sub_limit || expand_rewrite_always()) rewrite(false);
             }
-            if (!partitioned) { if (moved_since_rewrite) rewrite(); }
+            if (!partitioned) { if (moved_since_rewrite) rewrite(true); }
             else {
                 // every rank ran its own junctions: merge what they did to the unitigs, field by field (kernels_tail.inc), and agree on
                 // the number of passes (the reference's count is that of the component that needed most)
@@ -971,15 +1011,14 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     }
     DBuf<u32> order2(U);
     copy_d2d(order2.ptr(), order1.ptr(), (size_t)U * 4);
-    renumber_sort(order2, U, clen.ptr(), coff.ptr(), cur, depth.ptr(), defer_sorts ? sort_flags.ptr() + 1 : renum_flag.ptr(), defer_sorts);
-    DBuf<u64> number_len(U), number_len_text(U), lcount((u64)U + 1), loff((u64)U + 1);      // (_text: by text-order index, what the path entries are in)
+    renumber_sort(order2, U, clen.ptr(), coff.ptr(), cur, depth.ptr(), defer_sorts ? sort_flags.ptr() + 1 : renum_flag.ptr(), defer_sorts, &sort2, len_bits);
+    DBuf<u64> number_len(U), number_len_text(U), loff((u64)U + 1);      // (_text: by text-order index, what the path entries are in)
     DBuf<u32> number_only(host_remap ? U : 0);
     DBuf<u8> meta((size_t)U * 24);
     u64* d_seq_begin = (u64*)meta.ptr();
     double* d_depth = (double*)(meta.ptr() + (size_t)U * 8);
     u32* d_seq_len = (u32*)(meta.ptr() + (size_t)U * 16);
     u32* d_seed_index = (u32*)(meta.ptr() + (size_t)U * 20);
-    lcount.fill_bytes(0);
     out->k = k;
     out->n_kmers = 2 * (u64)N;
     out->n_unitigs = U;
@@ -1011,8 +1050,6 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         side.after_main();
         copy_d2h_async(out->links_block.p, links_out.ptr(), n_links * sizeof(Link), side.stream());
     }
-    DBuf<u64> sums(n_seqs);
-    sums.fill_bytes(0);
     if (host_remap) {      // the device only checks that every path spells its sequence's length (the sums), it stores nothing
         const u64 RB = remap_block();
         const u64 n_waves = (n_ent + RB - 1) / RB;

@@ -14,7 +14,6 @@
 // The same kernel source runs under the lockstep emulation (AC_EMU): its workgroups run one after the other in ticket order, so a look-back
 // always finds its predecessors complete.
 #pragma once
-#include <type_traits>
 
 namespace ac {
 
@@ -91,11 +90,8 @@ enum { CTX_SCANPOOL = 7 };
 inline ScanPool& scan_pool() { return ctx_object<ScanPool>(CTX_SCANPOOL); }
 
 // out[i] = op over in[0 .. i] (INCL) or in[0 .. i) (exclusive; identity 0).  Values (and their running totals) stay below 2^46 (the pipeline's are counts and byte offsets of a text of < 2^40 positions).
-// SRC: where the items come from — ScanPtr<T> (an array: 16-byte loads), or a functor computing item i on the fly (round 6: a producer
-// kernel and its array saved; the functor may store what it computes).
-template <class T> struct ScanPtr { const T* p; };
-template <class T, int OP, bool INCL, class SRC>
-AC_KERNEL void __launch_bounds__(256) scan_kernel(SRC src, T* out, u64 n, u64* pool, u64 epoch, u64 ticket_base) {
+template <class T, int OP, bool INCL>
+AC_KERNEL void __launch_bounds__(256) scan_kernel(const T* in, T* out, u64 n, u64* pool, u64 epoch, u64 ticket_base) {
     AC_SHARED u64 s_wave[4];
     AC_SHARED u64 s_prefix;
     AC_SHARED u64 s_tile;
@@ -107,20 +103,14 @@ AC_KERNEL void __launch_bounds__(256) scan_kernel(SRC src, T* out, u64 n, u64* p
     const u64 tile = s_tile;
     const u64 base = tile * SCAN_TILE + (u64)tid * SCAN_ITEMS;
     alignas(16) T v[SCAN_ITEMS];
-    if constexpr (std::is_same<SRC, ScanPtr<T>>::value) {
-        const T* in = src.p;
-        if (base + SCAN_ITEMS <= n && (((uintptr_t)(in + base)) & 15u) == 0) {      // whole and aligned: 16-byte loads
-            const PrimV16* p = (const PrimV16*)(in + base);
-            PrimV16* q = (PrimV16*)v;
+    if (base + SCAN_ITEMS <= n && (((uintptr_t)(in + base)) & 15u) == 0) {      // whole and aligned: 16-byte loads
+        const PrimV16* p = (const PrimV16*)(in + base);
+        PrimV16* q = (PrimV16*)v;
 #pragma unroll
-            for (u32 j = 0; j < SCAN_ITEMS * sizeof(T) / 16; j++) q[j] = p[j];
-        } else {
-#pragma unroll
-            for (u32 j = 0; j < SCAN_ITEMS; j++) v[j] = base + j < n ? in[base + j] : (T)0;
-        }
+        for (u32 j = 0; j < SCAN_ITEMS * sizeof(T) / 16; j++) q[j] = p[j];
     } else {
 #pragma unroll
-        for (u32 j = 0; j < SCAN_ITEMS; j++) v[j] = base + j < n ? (T)src(base + j) : (T)0;
+        for (u32 j = 0; j < SCAN_ITEMS; j++) v[j] = base + j < n ? in[base + j] : (T)0;
     }
     u64 tsum = 0;
 #pragma unroll
@@ -182,19 +172,15 @@ AC_KERNEL void __launch_bounds__(256) scan_kernel(SRC src, T* out, u64 n, u64* p
         for (u32 j = 0; j < SCAN_ITEMS; j++) if (base + j < n) out[base + j] = o[j];
     }
 }
-template <class T, int OP, bool INCL, class SRC> inline void scan_launch_src(SRC src, T* out, size_t n, stream_t s) {
+template <class T, int OP, bool INCL> inline void scan_launch(const T* in, T* out, size_t n, stream_t s) {
     if (!n) return;
     if (s != 0) throw DeviceError("scan: stream 0 only (the state pool's tickets are stream-ordered)");
     const u64 tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     u64 epoch = 0, ticket_base = 0;
     ScanPool& pool = scan_pool();
     pool.take(tiles, &epoch, &ticket_base);
-    launch_wave_kernel(scan_kernel<T, OP, INCL, SRC>, tiles, s, src, out, (u64)n, pool.words, epoch, ticket_base);
+    launch_wave_kernel(scan_kernel<T, OP, INCL>, tiles, s, in, out, (u64)n, pool.words, epoch, ticket_base);
 }
-template <class T, int OP, bool INCL> inline void scan_launch(const T* in, T* out, size_t n, stream_t s) { scan_launch_src<T, OP, INCL, ScanPtr<T>>(ScanPtr<T>{in}, out, n, s); }
-// out[i] = the sum of src(0) .. src(i) (inclusive) / src(0) .. src(i - 1) (exclusive): the items are computed, not loaded
-template <class SRC> inline void inclusive_scan_u32_of(SRC src, u32* out, size_t n) { scan_launch_src<u32, SCAN_ADD, true, SRC>(src, out, n, 0); }
-template <class SRC> inline void exclusive_scan_u32_of(SRC src, u32* out, size_t n) { scan_launch_src<u32, SCAN_ADD, false, SRC>(src, out, n, 0); }
 inline void inclusive_scan_u32(const u32* in, u32* out, size_t n, stream_t s = 0) { scan_launch<u32, SCAN_ADD, true>(in, out, n, s); }
 inline void inclusive_max_scan_u32(const u32* in, u32* out, size_t n, stream_t s = 0) { scan_launch<u32, SCAN_MAX, true>(in, out, n, s); }
 inline void exclusive_scan_u32(const u32* in, u32* out, size_t n, stream_t s = 0) { scan_launch<u32, SCAN_ADD, false>(in, out, n, s); }

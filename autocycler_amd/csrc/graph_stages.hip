@@ -343,21 +343,8 @@ template <int W> void GraphBuilder::Impl::table() {
     if (sib_by_pos) { sib.alloc(2 * (g.n_text / 64 + 2)); sib.fill_bytes(0); }
     else sib = DBuf<u64>();
     sibn = DBuf<u64>(); sib_pending = false;
-#ifndef AC_EMU
-    if (n_owners <= 1) {
-        // Round 6: the table scan (occupancy bitmap + sibling bits: 8 bytes per SLOT, config C 268 MB) on the side stream, beside the novel
-        // list (bitmap -> rank support -> sorted list: 1/8 + 8 bytes per position) — neither reads what the other writes, each alone runs at
-        // a third of the device's bandwidth.  Stream 0 waits for the scan before the degree stage, its first reader.
-        SideStream& side = SideStream::get();
-        side.after_main();      // (the insert, and the fill of `sib`, are done)
-        occupancy_bitmap(slots, cap, &occ, sib_by_pos ? sflags.ptr() : nullptr, sib_by_pos ? sib.ptr() : nullptr, side.stream());
-        void* scanned = side.mark();
-        novel_list(N);
-        flush_fills();
-        AC_HIP_CHECK(hipStreamWaitEvent(0, (hipEvent_t)scanned, 0));
-        return;
-    }
-#endif
+    // (round 6 ran this table scan on the side stream beside the novel list — neither reads what the other writes — and took it back: both are
+    // bandwidth-bound, collect + degree took 0.51 ms together instead of 0.45 on config C and the same as before on E' / mini-E, r14c)
     occupancy_bitmap(slots, cap, &occ, sib_by_pos ? sflags.ptr() : nullptr, sib_by_pos ? sib.ptr() : nullptr);
     if (n_owners <= 1) novel_list(N);      // a sharded build first sums the ranks' (disjoint) bitmaps: bitmap_import
 }
@@ -477,7 +464,8 @@ template <int W> void GraphBuilder::Impl::unitigs() {
     Novel nv{bm.ptr(), wprefix.ptr()};
     // K7 heads -> unitig ids
     // (head / scan: allocated, and their tails cleared, by novel_list)
-    inclusive_scan_u32_of(HeadSrc{HeadFunctor{npos.ptr(), kinfo.ptr(), head.ptr(), N}}, scan.ptr(), N);      // (K7's flags computed, stored and summed by the scan itself)
+    launch(N, HeadFunctor{npos.ptr(), kinfo.ptr(), head.ptr(), N});
+    inclusive_scan_u32(head.ptr(), scan.ptr(), N);
     U = read_scalar(scan.ptr() + (N - 1));
     ustart.alloc((u64)U + 1);
     // (what the seed order needs cleared — its sort's scratch, the flag of its tie-break — now, with this launch's batch)
@@ -589,8 +577,10 @@ template <int W> void GraphBuilder::Impl::walk_queries() {
     cplan = CopyPlan();
     if (run_rows && loc_bm.size() && PC <= 65535) {
         const u64 nw = loc.n_text / 64 + 1;
+        DBuf<u32> wcnt(nw + 1);
         loc_wprefix.alloc(nw + 1);
-        exclusive_scan_u32_of(PopcSrc{loc_bm.ptr(), nw}, loc_wprefix.ptr(), nw + 1);
+        launch(nw + 1, PopcFunctor{loc_bm.ptr(), wcnt.ptr(), nw});
+        exclusive_scan_u32(wcnt.ptr(), loc_wprefix.ptr(), nw + 1);
         if (walk_copy_prepare<W>(PC, Novel{loc_bm.ptr(), loc_wprefix.ptr()})) n_walkers = cplan.NW;
     }
     n_queries = n_walkers + loc.n_seqs;

@@ -623,29 +623,34 @@ class SideStream {
     static SideStream& get() { return ctx_object<SideStream>(CTX_SIDE); }
     SideStream() {}
     ~SideStream() { destroy(); }
-    stream_t stream() {
+    // which: 0 = the side stream; 1 = a second one (round 6: large device -> host copies alternate between the two — a copy queue of its own each)
+    stream_t stream(int which = 0) {
 #ifndef AC_EMU
         int dev = 0;
         AC_HIP_CHECK(hipGetDevice(&dev));
         if (!created_ || dev != dev_) {
             destroy();
             AC_HIP_CHECK(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
+            AC_HIP_CHECK(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
             for (auto& e : ev_) AC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             created_ = true; dev_ = dev;
         }
-        return s_;
+        return which ? s2_ : s_;
 #else
+        (void)which;
         return 0;
 #endif
     }
     // Everything enqueued on stream 0 so far happens before whatever is enqueued on the side stream from now on.
-    void after_main() {
+    void after_main(int which = 0) {
 #ifndef AC_EMU
-        stream_t s = stream();
+        stream_t s = stream(which);
         hipEvent_t e = ev_[next_++ % 16];
         flush_fills();
         AC_HIP_CHECK(hipEventRecord(e, 0));
         AC_HIP_CHECK(hipStreamWaitEvent(s, e, 0));
+#else
+        (void)which;
 #endif
     }
     // An event that fires when everything enqueued on the side stream so far is done (valid until 16 more events were taken).
@@ -661,7 +666,7 @@ class SideStream {
     }
     void sync() noexcept {
 #ifndef AC_EMU
-        if (created_) (void)hipStreamSynchronize(s_);
+        if (created_) { (void)hipStreamSynchronize(s_); (void)hipStreamSynchronize(s2_); }
 #endif
     }
     struct Guard { ~Guard() { SideStream::get().sync(); } };   // no copy may outlive the scope that owns its destination
@@ -669,11 +674,11 @@ class SideStream {
   private:
     void destroy() {
 #ifndef AC_EMU
-        if (created_) { (void)hipStreamDestroy(s_); for (auto& e : ev_) (void)hipEventDestroy(e); created_ = false; }
+        if (created_) { (void)hipStreamDestroy(s_); (void)hipStreamDestroy(s2_); for (auto& e : ev_) (void)hipEventDestroy(e); created_ = false; }
 #endif
     }
 #ifndef AC_EMU
-    hipStream_t s_ = nullptr;
+    hipStream_t s_ = nullptr, s2_ = nullptr;
     hipEvent_t ev_[16];
 #endif
     bool created_ = false;

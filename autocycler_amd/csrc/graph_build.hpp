@@ -42,6 +42,7 @@ struct BuildTimings {                   // seconds; device stages are bracketed 
     uint64_t n_local_distinct = 0, n_fragments = 0, fragment_bytes = 0;
     double upload_device_ms = 0;        // host entry: first copy issued -> last chunk landed and packed (HIP events)
     double insert_rest_known = 0;       // share of a sample of the insert's one-launch rest found in the table after the first two stretches (sizes its chunks)
+    uint64_t path_stretches = 0;        // the paths crossed to the host as this many stretches of consecutive text-order numbers (0: as entries)
     double insert_rest_sampled = 0;     // ... and the share of that rest the sample could cover (the text that was on the device when it was taken)
     uint32_t sort_retries = 0;          // builds repeated with checked sorts (a deferred "group too large" flag of the seed sort / a renumbering was set)
     uint32_t position_retries = 0;      // builds repeated with exact smallest positions (AC_POS_CAP; kernels_tail.inc exp_avoid_start_of_path)

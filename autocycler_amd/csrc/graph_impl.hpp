@@ -301,6 +301,9 @@ struct alignas(16) V16 { u32 a, b, c, d; };
 // block while the remaining results (unitig records, links) are still crossing.  (unitig_graph.rs:renumber_unitigs only permutes.)
 struct PathRemapJob {
     int32_t* path = nullptr; u64 n_ent = 0;
+    // stretch mode (round 6, kernels_paths.inc): the entries did not cross the link, their stretches did — rec_val[s] = first value of
+    // stretch s (a text-order number, signed), rec_pos[s] = its first entry's index; the threads WRITE path[] from the number table
+    const int32_t* rec_val = nullptr; const u32* rec_pos = nullptr; u64 n_rec = 0;
     const u32* number = nullptr; u32 n_unitigs = 0;      // pinned: final number of seed index r at [r]
     void* landed = nullptr;                              // event: entries and number table are in host memory
     int dev = 0;
@@ -309,6 +312,7 @@ struct PathRemapJob {
     u64 ticket = 0; bool started = false;
 };
 void path_remap_range(int32_t* p, u64 n, const u32* number, u32 n_unitigs, std::atomic<u32>* bad);
+void path_stretch_range(const PathRemapJob& j, u64 s0, u64 s1, std::atomic<u32>* bad);      // stretches [s0, s1) written out
 bool path_remap_is_wide();      // the host has the 16-lane gather (without it a thread renumbers ~5x slower and the device keeps the job)
 void path_remap_start(PathRemapJob& j, int threads);      // returns at once; the work runs on the packing threads' pool
 void path_remap_finish(PathRemapJob& j) noexcept;         // until every thread is done (idempotent)
@@ -410,7 +414,7 @@ struct Knobs {
         k.run_piece = [&]() -> u64 { const char* e = getenv("AC_RUN_PIECE"); const long v = e ? atol(e) : 0; return v > 0 ? (u64)v : 4096; }();
         k.pos_cap = [&]() -> u32 { const char* e = getenv("AC_POS_CAP"); const long v = e ? atol(e) : 65536; return v < 0 ? 0u : (u32)std::min<long>(v, 0x3FFFFFFF); }();
         k.path_filter = [&]() -> bool { const char* e = getenv("AC_PATH_FILTER"); return e ? atoi(e) != 0 : true; }();
-        k.host_remap_mode = [&]() -> int { const char* e = getenv("AC_HOST_REMAP"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+        k.host_remap_mode = [&]() -> int { const char* e = getenv("AC_HOST_REMAP"); return e ? (atoi(e) == 2 ? 2 : (atoi(e) != 0 ? 1 : 0)) : -1; }();
         k.remap_block = [&]() -> u32 { const char* e = getenv("AC_REMAP_BLOCK"); int v = e ? atoi(e) : 4096; v = v < 64 ? 64 : (v > 65536 ? 65536 : v); return (u32)(v & ~63); }();
         k.minkey_prefix_bases = [&]() -> int { const char* e = getenv("AC_MINKEY_PREFIX_BASES"); int v = e ? atoi(e) : 31; return v < 1 ? 1 : (v > 31 ? 31 : v); }();
         k.seed_prefix_sort = [&]() -> bool { const char* e = getenv("AC_SEED_PREFIX_SORT"); return e ? atoi(e) != 0 : true; }();
@@ -493,7 +497,7 @@ void knobs_refresh();        // re-reads the environment if AC_TUNING_FOLLOW_ENV
     return pc;
 }
 // Path entries leave the device in seed numbers right after the walk and get their final numbers on the host (single-device builds):
-// 1 always, 0 never, otherwise when the number table (4 bytes per unitig) stays in the host's caches — up to 8 M unitigs — and there is
+// 1 always, 0 never, 2 = always as STRETCHES (round 6; tests), otherwise when the number table (4 bytes per unitig) stays in the host's caches — up to 8 M unitigs — and there is
 // enough to hide.  Measured (r10p/q): config C 4.50 -> 3.93 ms, E' 18.5 -> 17.7, mini-E (6.5 M unitigs) 69.8 -> 64.5; with 26 M unitigs
 // (8 species) 277 -> 321 ms and with 82 M (configs[4]) 0.89 -> 1.29 s: random gathers from a table in DRAM are slower than the link.
 [[maybe_unused]] static int host_remap_mode() { return knobs().host_remap_mode; }
@@ -799,7 +803,7 @@ inline void GraphBuilder::Impl::walk_arrays() {
 inline void GraphBuilder::Impl::walk_tables(bool filter) {
     launch((u64)U * 10, WlinkFlagFunctor{filter ? maybe_dest.ptr() : nullptr, wlinks.ptr(), counters.ptr() + 4});
     const u32 pos_init = pos_cap_now == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((pos_cap_now + 1) | POS_BOUND);
-    launch((u64)U * 10, WlinkTextOrderFunctor{wlinks.ptr(), rank.ptr(), order.ptr(), wl_text.ptr(), minpos_fwd_u.ptr(), minpos_rev_u.ptr(), pos_init});
+    launch((u64)U * 10, WlinkTextOrderFunctor{wlinks.ptr(), rank.ptr(), order.ptr(), uorient.ptr(), wl_text.ptr(), minpos_fwd_u.ptr(), minpos_rev_u.ptr(), pos_init});
 }
 inline void GraphBuilder::Impl::walk_to_seed_order() {
     depth.alloc(U); minpos_fwd.alloc(U); minpos_rev.alloc(U);

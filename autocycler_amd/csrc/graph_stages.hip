@@ -14,7 +14,7 @@ namespace ac {
 // sc: the sort's scratch if the caller prepared it (RadixScratch); len_bits: no unitig is 2^len_bits long or longer (the keys' leading
 // field is ~length: its bits above that are ones in every key and need no pass)
 [[maybe_unused]] static void renumber_sort(DBuf<u32>& order, u32 U, const u32* len, const u64* off, const u8* seq, const u32* depth, u32* flag, bool deferred = false,
-                                           RadixScratch* sc = nullptr, int len_bits = 32) {
+                                           RadixScratch* sc = nullptr, int len_bits = 32, bool order_is_identity = false) {
     if (U <= 1) return;
     DBuf<u32> backup(deferred && !renum_two_pass() ? 0 : U);      // (the order to fall back from: only a checked sort ever does)
     if (backup.size()) copy_d2d(backup.ptr(), order.ptr(), (size_t)U * 4);
@@ -22,7 +22,14 @@ namespace ac {
     UnitigLess less{len, off, seq, depth};
     u32 zero = 0;
     if (!renum_two_pass()) {      // one sort on (length | 16 bases), ties by the comparator
-        launch(U, RenumKeyPassFunctor{RenumKeyFunctor{len, off, seq, prefix.ptr()}, RenumPassFunctor{order.ptr(), len, depth, prefix.ptr(), 2, key.ptr()}});
+        // (one kernel where `order` is still the identity — the first renumbering: element i IS unitig i and the sequences are read front to
+        // back; the second renumbering's order is by length, and a fused kernel would gather its prefixes from all over the sequences:
+        // mini-E's finalize stage 4.4 -> 5.7 ms when it did, r14d)
+        if (order_is_identity) launch(U, RenumKeyPassFunctor{RenumKeyFunctor{len, off, seq, prefix.ptr()}, RenumPassFunctor{order.ptr(), len, depth, prefix.ptr(), 2, key.ptr()}});
+        else {
+            launch(U, RenumKeyFunctor{len, off, seq, prefix.ptr()});
+            launch(U, RenumPassFunctor{order.ptr(), len, depth, prefix.ptr(), 2, key.ptr()});
+        }
         sort_pairs_u64_u32(key, order, U, 32 + std::min(std::max(len_bits, 1), 32), 0, 0, sc);
         launch(U, RenumTieFunctor{order.ptr(), U, len, depth, prefix.ptr(), less, flag, 0, renum_max_group()});
 #ifdef AC_EMU
@@ -703,7 +710,7 @@ template <int W> void GraphBuilder::Impl::walk_copy_finish(u32 PC) {
     tm->n_path_entries = n_ent;
     tm->path_runs_copied = R; tm->path_entries_walked = NE;
     copy_h2d(path_off.ptr() + loc.n_seqs, &n_ent, 8);
-    launch(loc.n_seqs, PathEndsFunctor{ent_val.ptr(), path_off.ptr(), fs0.ptr(), fe0.ptr(), rank.ptr()});
+    launch(loc.n_seqs, PathEndsFunctor{ent_val.ptr(), path_off.ptr(), fs0.ptr(), fe0.ptr(), rank.ptr(), uorient.ptr()});
     walk_to_seed_order();
 }
 
@@ -754,7 +761,7 @@ template <int W> void GraphBuilder::Impl::walk() {
         ent_val.alloc(n_ent);             // where the staging area began; `packed` lies behind the staging area's end (n_ent <= its size)
         if (ent_val.ptr() != packed.ptr()) copy_d2d(ent_val.ptr(), packed.ptr(), n_ent * 4);
     }
-    launch(loc.n_seqs, PathEndsFunctor{ent_val.ptr(), path_off.ptr(), fs0.ptr(), fe0.ptr(), rank.ptr()});
+    launch(loc.n_seqs, PathEndsFunctor{ent_val.ptr(), path_off.ptr(), fs0.ptr(), fe0.ptr(), rank.ptr(), uorient.ptr()});
     walk_to_seed_order();
     lap(&tm->paths);
 }
@@ -772,7 +779,39 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                             (host_remap_mode() == 1 || (host_remap_mode() < 0 && n_ent >= (1u << 18) && U <= (8u << 20) && path_remap_is_wide()));
     PathRemapJob remap_job;
     struct RemapJoin { PathRemapJob& j; ~RemapJoin() { path_remap_finish(j); } } remap_join{remap_job};      // (the threads are done before the guard and the table go)
-    paths_in_seed_numbers = host_remap;
+    // Round 6: where that table would be too large for the host's caches (more than 8 M unitigs: a mixed-species job) the entries cross as
+    // STRETCHES of consecutive text-order numbers (kernels_paths.inc) — 8 bytes per stretch instead of 4 per entry — and the host writes
+    // the final numbers out from the table front to back: configs[4]'s 4.8 GB of entries took 165 ms behind everything else at the
+    // 30 GB/s the link gives device -> host.  Taken when it at least halves the bytes (one more read-back, on a build of seconds).
+    HostBlock rec_val_block, rec_pos_block;
+    u64 n_stretch = 0;
+    bool host_stretch = false;
+    if (!host_remap && want_paths && host_remap_allowed && n_ent > 0 && n_ent < 0xFFFFFFF0ULL &&
+        (host_remap_mode() == 2 || (host_remap_mode() < 0 && n_ent >= ((u64)1 << 24)))) {
+        const bool always = host_remap_mode() == 2;
+        const Arena::Mark all_mark = Arena::device().mark();
+        const u64 rec_cap = always ? n_ent : n_ent / 4 + 1;      // (taken when it at least halves the bytes: at most n_ent / 4 records)
+        DBuf<int32_t> rv(rec_cap); DBuf<u32> rp(rec_cap);         // (stay until the build ends: the copies below read them)
+        const Arena::Mark scratch_mark = Arena::device().mark();
+        DBuf<u32> sflag(n_ent + 1), sat(n_ent + 1);
+        launch(n_ent + 1, StretchFlagFunctor{ent_val.ptr(), n_ent, sflag.ptr()});
+        exclusive_scan_u32(sflag.ptr(), sat.ptr(), n_ent + 1);
+        n_stretch = read_scalar(sat.ptr() + n_ent);
+        if (n_stretch <= rec_cap) {
+            launch(n_ent, StretchRecordFunctor{ent_val.ptr(), n_ent, sflag.ptr(), sat.ptr(), rv.ptr(), rp.ptr()});
+            rec_val_block = PinnedPool::get().alloc(n_stretch * 4); rec_pos_block = PinnedPool::get().alloc(n_stretch * 4);
+            out->path_block = PinnedPool::get().alloc(n_ent * 4);      // (written by the host's threads, not by a copy)
+            side.after_main();
+            copy_d2h_async(rec_val_block.p, rv.ptr(), n_stretch * 4, side.stream());
+            copy_d2h_async(rec_pos_block.p, rp.ptr(), n_stretch * 4, side.stream());
+            host_stretch = true;
+        }
+        sflag = DBuf<u32>(); sat = DBuf<u32>();
+        Arena::device().rewind(host_stretch ? scratch_mark : all_mark);      // (stream 0 reuses the scratch only behind the kernels that read it)
+        if (!host_stretch) { rv = DBuf<int32_t>(); rp = DBuf<u32>(); }
+    }
+    const bool host_numbers = host_remap || host_stretch;      // the device only checks the paths' length sums; the host writes the final numbers
+    paths_in_seed_numbers = host_numbers;
     if (host_remap) {
         out->path_block = PinnedPool::get().alloc(n_ent * 4);
         side.after_main();
@@ -831,7 +870,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     DBuf<u32> order1(U);
     launch(U, IotaFunctor{order1.ptr()});
     const bool defer_sorts = deferred_sort_checks();
-    renumber_sort(order1, U, ulen.ptr(), useq_off.ptr(), useq.ptr(), depth.ptr(), defer_sorts ? sort_flags.ptr() + 1 : renum_flag.ptr(), defer_sorts, &sort1, len_bits);
+    renumber_sort(order1, U, ulen.ptr(), useq_off.ptr(), useq.ptr(), depth.ptr(), defer_sorts ? sort_flags.ptr() + 1 : renum_flag.ptr(), defer_sorts, &sort1, len_bits, /*order_is_identity=*/true);
     lap(&tm->analysis);
 
     // K17 expand_repeats, level-scheduled (see the kernels)
@@ -1003,7 +1042,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     copy_d2d(order2.ptr(), order1.ptr(), (size_t)U * 4);
     renumber_sort(order2, U, clen.ptr(), coff.ptr(), cur, depth.ptr(), defer_sorts ? sort_flags.ptr() + 1 : renum_flag.ptr(), defer_sorts, &sort2, len_bits);
     DBuf<u64> number_len(U), number_len_text(U), loff((u64)U + 1);      // (_text: by text-order index, what the path entries are in)
-    DBuf<u32> number_only(host_remap ? U : 0);
+    DBuf<u32> number_only(host_numbers ? U : 0);
     DBuf<u8> meta((size_t)U * 24);
     u64* d_seq_begin = (u64*)meta.ptr();
     double* d_depth = (double*)(meta.ptr() + (size_t)U * 8);
@@ -1013,12 +1052,13 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     out->n_kmers = 2 * (u64)N;
     out->n_unitigs = U;
     launch(U, FinalMetaFunctor{order2.ptr(), coff.ptr(), clen.ptr(), depth.ptr(), lcnt.ptr(), number_len.ptr(), d_seq_begin, d_depth,
-                               d_seq_len, lcount.ptr(), host_remap ? number_only.ptr() : nullptr, d_seed_index, order.ptr(), number_len_text.ptr()});
-    if (host_remap) {      // the number table first: the host threads start on the entries while the rest is still crossing
+                               d_seq_len, lcount.ptr(), host_numbers ? number_only.ptr() : nullptr, d_seed_index, order.ptr(), number_len_text.ptr(), uorient.ptr()});
+    if (host_numbers) {      // the number table first: the host threads start on the entries while the rest is still crossing
         number_block = PinnedPool::get().alloc((size_t)U * 4);
         side.after_main();
         copy_d2h_async(number_block.p, number_only.ptr(), (size_t)U * 4, side.stream());
         remap_job.path = (int32_t*)out->path_block.p; remap_job.n_ent = n_ent;
+        if (host_stretch) { remap_job.rec_val = (const int32_t*)rec_val_block.p; remap_job.rec_pos = (const u32*)rec_pos_block.p; remap_job.n_rec = n_stretch; }
         remap_job.number = (const u32*)number_block.p; remap_job.n_unitigs = U;
         remap_job.landed = side.mark();
 #ifndef AC_EMU
@@ -1040,7 +1080,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         side.after_main();
         copy_d2h_async(out->links_block.p, links_out.ptr(), n_links * sizeof(Link), side.stream());
     }
-    if (host_remap) {      // the device only checks that every path spells its sequence's length (the sums), it stores nothing
+    if (host_numbers) {      // the device only checks that every path spells its sequence's length (the sums), it stores nothing
         const u64 RB = remap_block();
         const u64 n_waves = (n_ent + RB - 1) / RB;
         launch_full(n_waves * 64, RemapFunctor{ent_val.ptr(), number_len_text.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr(), 0, (u32)RB, nullptr, false});
@@ -1050,14 +1090,19 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         const u64 n_waves = (n_ent + RB - 1) / RB;
         // Four chunks, each copied while the next is renumbered (the kernel storing straight into the pinned block measured equal, r08j:
         // either way the 4 bytes per entry cross PCIe after the final numbering exists — 42 MB = 0.7 ms on config C)
-        const u64 per_chunk = std::max<u64>((n_waves + 3) / 4, 64);
+        // (round 6: from 256 MB of entries on, eight chunks alternating between two copy streams — configs[4] moves 4.8 GB here, and one copy
+        // queue alone ran at 33 GB/s)
+        const u64 n_chunks = n_ent * 4 >= ((u64)256 << 20) ? 8 : 4;
+        const u64 per_chunk = std::max<u64>((n_waves + n_chunks - 1) / n_chunks, 64);
+        int turn = 0;
         for (u64 w = 0; w < n_waves; w += per_chunk) {
             u64 cnt = std::min<u64>(per_chunk, n_waves - w);
             launch_full(cnt * 64, RemapFunctor{ent_val.ptr(), number_len_text.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr(), w, (u32)RB, nullptr, true});
             if (want_paths) {
                 u64 b = w * RB, e2 = std::min<u64>((w + cnt) * RB, n_ent);
-                side.after_main();
-                copy_d2h_async((int32_t*)out->path_block.p + b, ent_val.ptr() + b, (e2 - b) * 4, side.stream());
+                const int which = n_chunks == 8 ? (turn++ & 1) : 0;
+                side.after_main(which);
+                copy_d2h_async((int32_t*)out->path_block.p + b, ent_val.ptr() + b, (e2 - b) * 4, side.stream(which));
             }
         }
     }
@@ -1078,12 +1123,14 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         rb.run();                                   // synchronises stream 0 (once)
     }
     side.sync();                                    // ... and the copies: everything above has landed
-    if (host_remap) {
+    if (host_numbers) {
 #ifdef AC_EMU
-        path_remap_range(remap_job.path, n_ent, remap_job.number, U, &remap_job.bad);
+        if (host_stretch) path_stretch_range(remap_job, 0, n_stretch, &remap_job.bad);
+        else path_remap_range(remap_job.path, n_ent, remap_job.number, U, &remap_job.bad);
 #endif
         path_remap_finish(remap_job);
     }
+    tm->path_stretches = host_stretch ? n_stretch : 0;
     if (loc.pack_bad.size()) loc.verify_alphabet(pack_bad);      // before any internal check: a text with foreign bytes explains them all
     if (errs[7] & 128u) throw NeedExactPositions();      // (before anything else: a repeat of the build settles it)
     if (h_sort_flags[0] || h_sort_flags[1]) {

@@ -209,6 +209,29 @@ __attribute__((target("avx512f"))) static void path_remap_avx512(int32_t* p, u64
     path_remap_scalar(p + i, n - i, number, n_unitigs, bad);
 }
 #endif
+// Stretch s covers entries [rec_pos[s], rec_pos[s + 1]) (the last one: up to n_ent) with the values v0, v0 + 1, ...: positive ones are the
+// final numbers of consecutive table entries, front to back; negative ones walk the table backwards, negated.
+void path_stretch_range(const PathRemapJob& j, u64 s0, u64 s1, std::atomic<u32>* bad) {
+    u32 wrong = 0;
+    for (u64 s = s0; s < s1; s++) {
+        const int64_t v0 = j.rec_val[s];
+        const u64 b = j.rec_pos[s], e = s + 1 < j.n_rec ? (u64)j.rec_pos[s + 1] : j.n_ent, len = e - b;
+        int32_t* out = j.path + b;
+        if (e > j.n_ent || e <= b) { wrong++; continue; }
+        if (v0 > 0) {
+            const u64 first = (u64)v0 - 1;
+            if (first + len > (u64)j.n_unitigs) { wrong++; continue; }
+            const u32* src = j.number + first;
+            for (u64 i = 0; i < len; i++) out[i] = (int32_t)src[i];
+        } else {
+            const u64 first = (u64)(-v0) - 1;      // values v0, v0 + 1, ... = -(first + 1), -first, ...
+            if (v0 == 0 || first >= (u64)j.n_unitigs || len > first + 1) { wrong++; continue; }
+            const u32* src = j.number + first;
+            for (u64 i = 0; i < len; i++) out[i] = -(int32_t)*(src - i);
+        }
+    }
+    if (wrong) bad->fetch_add(wrong);
+}
 bool path_remap_is_wide() {
 #if defined(__x86_64__)
     static const bool wide = __builtin_cpu_supports("avx512f") && getenv("AC_PACK_SCALAR") == nullptr && getenv("AC_PACK_AVX2") == nullptr;
@@ -226,7 +249,8 @@ void path_remap_range(int32_t* p, u64 n, const u32* number, u32 n_unitigs, std::
 #ifndef AC_EMU
 void path_remap_start(PathRemapJob& j, int threads) {
     const u64 BLOCK = (u64)1 << 15;
-    const int T = (int)std::max<u64>(1, std::min<u64>({(j.n_ent + BLOCK - 1) / BLOCK, (u64)std::max(threads, 1), (u64)std::max(1u, std::thread::hardware_concurrency())}));
+    const u64 work_items = j.rec_val ? (j.n_rec + 4095) / 4096 : (j.n_ent + BLOCK - 1) / BLOCK;
+    const int T = (int)std::max<u64>(1, std::min<u64>({work_items, (u64)std::max(threads, 1), (u64)std::max(1u, std::thread::hardware_concurrency())}));
     PathRemapJob* job = &j;
     j.started = true;
     j.ticket = UploadPool::get().start(T, [job, BLOCK] {
@@ -238,6 +262,11 @@ void path_remap_start(PathRemapJob& j, int threads) {
             while (job->ready.load(std::memory_order_acquire) < 2) std::this_thread::yield();
         }
         if (job->ready.load(std::memory_order_acquire) != 2) { job->bad.fetch_add(1); return; }
+        if (job->rec_val) {      // stretch mode: blocks of stretches
+            const u64 SB = 4096;
+            for (u64 b; (b = job->next.fetch_add(SB)) < job->n_rec;) path_stretch_range(*job, b, std::min(b + SB, job->n_rec), &job->bad);
+            return;
+        }
         for (u64 b; (b = job->next.fetch_add(BLOCK)) < job->n_ent;)
             path_remap_range(job->path + b, std::min(BLOCK, job->n_ent - b), job->number, job->n_unitigs, &job->bad);
     });

@@ -73,6 +73,7 @@ typedef struct {
     uint64_t sort_retries;       /* builds repeated because a sort's "group too large" flag, read with the last read-back, was set */
     double insert_rest_known;    /* share of a sample of the insert's one-launch rest that the first two stretches already held (sizes the rest's chunks); 0 = no such rest */
     double insert_rest_sampled;  /* share of that rest the sample could cover: only text that was on the device when it was taken (an upload still in flight: its first chunks) */
+    uint64_t path_stretches;     /* > 0: the path entries crossed to the host as this many stretches of consecutive text-order numbers (8 bytes each) and were written out there */
 } ac_timings;
 
 /* Replaces compress.rs:42-44.  k: --kmer (odd).  assembly_count: the reference's capacity hint

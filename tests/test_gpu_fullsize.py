@@ -214,7 +214,7 @@ def test_config_e_full_size_k51():
     lib.ac_release_memory()
 
 
-@pytest.mark.parametrize("golden_name", ["configC_k51", "configDprime_k101", "configB_k51", "configEprime_k51", "configE2_k51"])
+@pytest.mark.parametrize("golden_name", ["configC_k51", "configDprime_k101", "configB_k51", "configEprime_k51", "configE2_k51", "configDprime_k201"])
 def test_gfa_digest_equals_the_oracle(golden_name):
     """Bit-exact parity at full size: the GFA built on the device (end repair on the device text, build, GFA text — the flow of
     tools/ab_knobs.py, run here as the same torch-free process) has the md5 the ORACLE produced for the same FASTA files on the CPU
@@ -223,7 +223,9 @@ def test_gfa_digest_equals_the_oracle(golden_name):
     scaled replica of configs[3] (24 x ~10 Mbp, k = 101: four-word keys); configB_k51 = BASELINE configs[1] (12 x ~5 Mbp, k = 51);
     configEprime_k51 = the scaled replica of configs[4] (mixed species: 5 species x 20 strains 1 % apart x ~1 Mbp = 100 assemblies,
     1.73 M unitigs, a 310 MB GFA; tests/golden/make_golden.py, 32 minutes of the oracle); configE2_k51 = the same model with ~2 Mbp
-    genomes (203 M bp, 3.46 M unitigs; 69 minutes and 38 GB of the oracle: about the largest mixed-species input it can hold here)."""
+    genomes (203 M bp, 3.46 M unitigs; 69 minutes and 38 GB of the oracle: about the largest mixed-species input it can hold here);
+    configDprime_k201 = D' again at k = 201 (round 6: SEVEN-word keys, i.e. the 8-word instantiation of every kernel — the reference's
+    --kmer range goes to 501, compress.rs:56-60)."""
     import json
     import os
     import subprocess

@@ -1063,7 +1063,8 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         remap_job.landed = side.mark();
 #ifndef AC_EMU
         AC_HIP_CHECK(hipGetDevice(&remap_job.dev));
-        path_remap_start(remap_job, (int)upload_threads());
+        // (writing the stretches out is bound by the host's memory, not by its cores' arithmetic: twice the packing threads — configs[4] writes 4.8 GB)
+        path_remap_start(remap_job, (int)(host_stretch ? 2 * upload_threads() : upload_threads()));
 #endif
     }
     if (want_graph) {

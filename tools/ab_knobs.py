@@ -138,9 +138,10 @@ def main():
                               "Mbp_s_median": bases / 1e3 / ts_sorted[len(ts) // 2], "insert_kernel_ms": sum(ins) / len(ins),
                               **({"upload_device_ms": sorted(u[0] for u in upl)[len(upl) // 2], "upload_host_side_ms": sorted(u[1] for u in upl)[len(upl) // 2],
                                   "build_ms": sorted(u[2] for u in upl)[len(upl) // 2]} if hviews is not None else {}),
-                              "stages_ms": {a: round(b * 1e3, 3) for a, b in tm.items() if isinstance(b, float) and b > 2e-5 and a != "insert_kernel_ms"},
+                              "stages_ms": {a: round(b * 1e3, 3) for a, b in tm.items() if isinstance(b, float) and b > 2e-5 and a not in ("insert_kernel_ms", "insert_rest_known", "insert_rest_sampled")},
                               "table_capacity": tm["table_capacity"], "insert_launches": tm["insert_launches"], "launches": tm.get("launches"), "readbacks": tm.get("readbacks"), "unitigs": st["unitigs"], "gfa_md5": dg,
                               "path_runs_copied": tm["path_runs_copied"], "path_entries_walked": tm["path_entries_walked"], "position_retries": tm["position_retries"],
+                              "path_entries": tm.get("n_path_entries"), "path_stretches": tm.get("path_stretches"),
                               "expand": {q: tm[q] for q in ("n_candidates", "n_levels", "simplify_passes") if q in tm}}), flush=True)
         except Exception as e:      # a variant that fails must not take the others with it
             print(json.dumps({"variant": variant, "error": str(e)}), flush=True)

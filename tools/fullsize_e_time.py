@@ -39,7 +39,7 @@ def main():
                       "bases": job["bases"], "n_text": job["n_text"], "generate_s": round(t_gen, 1), "end_repair_s": repair_s,
                       "build_s": [round(t, 4) for t in times], "first_build_s_not_counted": round(times[0], 4),
                       "Gbp_per_s_best": round(job["bases"] / 1e9 / min(times[1:]), 2), "stages_ms_last_build": stages,
-                      "insert_kernel_ms": tm.get("insert_kernel_ms"), "launches": tm.get("launches"), "round_trips": tm.get("readbacks"),
+                      "insert_kernel_ms": tm.get("insert_kernel_ms"), "launches": tm.get("launches"), "round_trips": tm.get("readbacks"), "path_stretches": tm.get("path_stretches"),
                       "unitigs": r["unitigs"], "path_entries": r["path_entries"], "verify_failed": r["failed"], "kmers": g.kmer_count}))
     g.close()
 

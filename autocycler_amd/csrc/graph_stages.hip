@@ -821,13 +821,13 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     u64 total = N;   // sum of unitig lengths == number of distinct canonical k-mers
     DBuf<u8> useq(total);
     // (both sequence writers: one thread per 64 output bytes; on the device through the block index + LDS tile of seq_write_kernel)
-    auto write_seqs = [&](int mode, const ExpState* es, const u64* off, u64 n_bytes, u8* dst) {
+    auto write_seqs = [&](int mode, const ExpState* es, const u64* off, u64 n_bytes, u8* dst, bool total_on_device = false) {
         // the indexed / LDS-tiled writer pays for its index (four small launches) from ~16 MB of output on: config C (7.8 MB) 6.02 vs
         // 5.97 ms per build with it, E' (45 MB) 24.9 vs 26.6, config D (126 MB): see DESIGN.md §6
         if (seq_writer_plain() || (n_bytes < ((u64)16 << 20) && !seq_writer_forced())) {
             const u32 per = 16;      // output bytes per thread (r06n: 64 left most of the chip idle on 7.8 MB)
             if (mode == 0) launch((n_bytes + per - 1) / per, SeqFunctor{g.bits.ptr(), off, ustartpos.ptr(), ulen.ptr(), uorient.ptr(), U, n_bytes, (int)(k / 2), dst, per});
-            else launch((n_bytes + per - 1) / per, MaterializeFunctor{*es, off, U, n_bytes, dst, per});
+            else launch((n_bytes + per - 1) / per, MaterializeFunctor{*es, off, U, n_bytes, dst, per, total_on_device});
             return;
         }
         const u64 n_blocks = (n_bytes + 63) / 64;
@@ -850,8 +850,8 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     cflag.fill_bytes(0);       // [J] = 0: the exclusive scan then ends with the total
     pool_used.fill_bytes(0);
     static const u32 SHIFT_CHECKS = 64;      // host checks of the pass loop whose "moved something" words are cleared up front (two words per check)
-    DBuf<u64> shifted2(2 * SHIFT_CHECKS), lcount((u64)U + 1), sums(n_seqs);
-    shifted2.fill_bytes(0); lcount.fill_bytes(0); sums.fill_bytes(0);
+    DBuf<u64> shifted2(2 * SHIFT_CHECKS), lcount((u64)U + 1), sums(n_seqs), n_links_dev(1);
+    shifted2.fill_bytes(0); lcount.fill_bytes(0); sums.fill_bytes(0); n_links_dev.fill_bytes(0);
     RadixScratch sort1, sort2;
     int len_bits = 32;      // no unitig is longer than the longest sequence of a text whose sequences this build knows
     if (G == &loc && !loc.h_len.empty()) { u32 mx = 0; for (u32 l : loc.h_len) mx = std::max(mx, l); len_bits = 1; while (len_bits < 32 && (mx >> len_bits)) len_bits++; }
@@ -861,7 +861,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
 
     // K13 link push order, K14 static analysis for expand_repeats, K15 first renumber_unitigs
     DBuf<int32_t> lord((u64)U * 10); DBuf<u8> lcnt((u64)U * 2);
-    launch((u64)U * 2, LinkOrderFunctor{links.ptr(), lord.ptr(), lcnt.ptr(), counters.ptr() + 5});
+    launch((u64)U * 2, LinkOrderFunctor{links.ptr(), lord.ptr(), lcnt.ptr(), counters.ptr() + 5, n_links_dev.ptr()});
     OrderedLinks L{lord.ptr(), lcnt.ptr()};
     launch(U, FixedSpreadFunctor{fs0.ptr(), fe0.ptr(), L, fixed_start.ptr(), fixed_end.ptr()});
     launch((u64)U * 2, CandFunctor{L, fixed_start.ptr(), fixed_end.ptr(), cand.ptr()});
@@ -881,6 +881,8 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     launch(U, ExpInitFunctor{useq_off.ptr(), ulen.ptr(), cand.ptr(), ev.ptr(), coff.ptr(), clen.ptr(), dirty.ptr()});      // core views = the unitigs, dirty = the candidates (three copies, one launch)
     u8* cur = useq.ptr(); u8* alt = seq_alt.ptr();
     u64 final_total = total;
+    bool final_total_pending = false;      // the last rewrite's sum is read with the build's last batch (small outputs: MaterializeFunctor takes it from the device)
+    u64 n_links = 0;
     int passes = 0;
     u32 n_cand = 0, n_levels = 0;
     const bool partitioned = n_owners > 1 && (bool)tail_xchg;      // (decided by the driver: the same on every rank)
@@ -890,7 +892,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         DBuf<u32> cpos(J + 1), prio(J);
         launch(J, CandFlagFunctor{order1.ptr(), cand.ptr(), cflag.ptr()});
         exclusive_scan_u32(cflag.ptr(), cpos.ptr(), J + 1);
-        n_cand = read_scalar(cpos.ptr() + J);
+        { ReadBatch rb; rb.add(&n_cand, cpos.ptr() + J, 4); rb.add(&n_links, n_links_dev.ptr(), 8); rb.run(); }      // (... and the number of links, for the buffers of K16)
         if (n_cand == 0) {
             passes = 1;   // the reference's single pass that moves nothing (the same on every rank of a sharded build: nothing to merge)
         } else {
@@ -951,8 +953,11 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                 if (partitioned) launch(U, ExpFoldFunctor{e, gpre.ptr(), gpost.ptr()});      // (what the fold makes of the gained pieces: the merge below)
                 launch((u64)U + 1, ExpLenFunctor{e, len64.ptr(), U});
                 exclusive_scan_u64(len64.ptr(), noff.ptr(), (u64)U + 1);
-                final_total = read_scalar(noff.ptr() + U);
-                write_seqs(1, &e, noff.ptr(), final_total, alt);
+                // (expand_repeats only ever shortens the total — n >= 2 sources lose what ONE destination gains — so the last total is a bound for
+                // this one: the last rewrite of a small output launches over the bound and lets the kernel read the sum, one round trip less)
+                const bool defer_total = last && !partitioned && (seq_writer_plain() || (final_total < ((u64)16 << 20) && !seq_writer_forced()));
+                if (defer_total) { write_seqs(1, &e, noff.ptr(), final_total, alt, /*total_on_device=*/true); final_total_pending = true; }
+                else { final_total = read_scalar(noff.ptr() + U); write_seqs(1, &e, noff.ptr(), final_total, alt); }
                 launch(U, ExpResetFunctor{e, noff.ptr(), coff.ptr(), clen.ptr()});
                 std::swap(cur, alt);
                 e.cur = cur;
@@ -1073,8 +1078,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         copy_d2h_async(out->meta_block.p, meta.ptr(), (size_t)U * 24, side.stream());
     }
     exclusive_scan_u64(lcount.ptr(), loff.ptr(), (u64)U + 1);
-    u64 n_links = read_scalar(loff.ptr() + U);
-    DBuf<Link> links_out(n_links);
+    DBuf<Link> links_out(n_links);      // (n_links: counted by LinkOrderFunctor, read with the candidate count)
     launch(U, LinkOutFunctor{order2.ptr(), L, number_len.ptr(), loff.ptr(), links_out.ptr()});
     if (want_graph) {
         out->links_block = PinnedPool::get().alloc(n_links * sizeof(Link));
@@ -1114,12 +1118,15 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     std::vector<u32> errs(8);
     u32 pack_bad[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
     u32 h_sort_flags[2] = {0, 0};
+    u64 n_links_check = 0, final_total_read = 0;
     {
         ReadBatch rb;
         rb.add(h_sums.data(), sums.ptr(), (size_t)n_seqs * 8);
         rb.add(out->path_off.data(), path_off.ptr(), ((size_t)n_seqs + 1) * 8);
         rb.add(errs.data(), counters.ptr(), 8 * 4);
         rb.add(h_sort_flags, sort_flags.ptr(), 8);
+        rb.add(&n_links_check, loff.ptr() + U, 8);
+        if (final_total_pending) rb.add(&final_total_read, noff.ptr() + U, 8);
         if (loc.check_alphabet && loc.pack_bad.size()) rb.add(pack_bad, loc.pack_bad.ptr(), 8);
         rb.run();                                   // synchronises stream 0 (once)
     }
@@ -1139,6 +1146,8 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         throw NeedCheckedSorts();      // (the order the flagged sort left is a permutation, not THE order: everything behind it is void)
     }
     if (errs[7]) throw DeviceError("internal error: expand_repeats pool overflow");
+    if (n_links_check != n_links) throw DeviceError("internal error: link counts disagree");
+    if (final_total_pending) { if (final_total_read > final_total) throw DeviceError("internal error: expand_repeats lengthened the sequences"); final_total = final_total_read; }
     if (errs[3] || errs[4])
         throw DeviceError("internal error: inconsistent unitig ends (codes " + std::to_string(errs[3]) + "/" + std::to_string(errs[4]) + ")");
     if (remap_job.bad.load()) throw DeviceError("internal error: path entries without a unitig");

@@ -850,7 +850,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     cflag.fill_bytes(0);       // [J] = 0: the exclusive scan then ends with the total
     pool_used.fill_bytes(0);
     static const u32 SHIFT_CHECKS = 64;      // host checks of the pass loop whose "moved something" words are cleared up front (two words per check)
-    DBuf<u64> shifted2(2 * SHIFT_CHECKS), lcount((u64)U + 1), sums(n_seqs), n_links_dev(1);
+    DBuf<u64> shifted2(2 * SHIFT_CHECKS), lcount((u64)U + 1), sums(n_seqs), n_links_dev(256);
     shifted2.fill_bytes(0); lcount.fill_bytes(0); sums.fill_bytes(0); n_links_dev.fill_bytes(0);
     RadixScratch sort1, sort2;
     int len_bits = 32;      // no unitig is longer than the longest sequence of a text whose sequences this build knows
@@ -892,7 +892,12 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         DBuf<u32> cpos(J + 1), prio(J);
         launch(J, CandFlagFunctor{order1.ptr(), cand.ptr(), cflag.ptr()});
         exclusive_scan_u32(cflag.ptr(), cpos.ptr(), J + 1);
-        { ReadBatch rb; rb.add(&n_cand, cpos.ptr() + J, 4); rb.add(&n_links, n_links_dev.ptr(), 8); rb.run(); }      // (... and the number of links, for the buffers of K16)
+        {      // (... and the number of links, for the buffers of K16)
+            u64 part[256];
+            ReadBatch rb; rb.add(&n_cand, cpos.ptr() + J, 4); rb.add(part, n_links_dev.ptr(), sizeof part); rb.run();
+            n_links = 0;
+            for (u64 v : part) n_links += v;
+        }
         if (n_cand == 0) {
             passes = 1;   // the reference's single pass that moves nothing (the same on every rank of a sharded build: nothing to merge)
         } else {

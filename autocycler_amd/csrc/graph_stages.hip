@@ -861,7 +861,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
 
     // K13 link push order, K14 static analysis for expand_repeats, K15 first renumber_unitigs
     DBuf<int32_t> lord((u64)U * 10); DBuf<u8> lcnt((u64)U * 2);
-    launch((u64)U * 2, LinkOrderFunctor{links.ptr(), lord.ptr(), lcnt.ptr(), counters.ptr() + 5, n_links_dev.ptr()});
+    launch_full((u64)U * 2, LinkOrderFunctor{links.ptr(), lord.ptr(), lcnt.ptr(), counters.ptr() + 5, n_links_dev.ptr()});
     OrderedLinks L{lord.ptr(), lcnt.ptr()};
     launch(U, FixedSpreadFunctor{fs0.ptr(), fe0.ptr(), L, fixed_start.ptr(), fixed_end.ptr()});
     launch((u64)U * 2, CandFunctor{L, fixed_start.ptr(), fixed_end.ptr(), cand.ptr()});

@@ -27,10 +27,11 @@
 #define AC_D __device__ inline
 #endif
 
-// Loops over the W words of a key: fully unrolled for the common narrow keys (the key then lives in registers with constant
-// indices), left as loops for wide keys (k > 123) where straight-line code for 8 or 16 words per operation inlined into every
-// kernel made the compile take tens of minutes.
-#define AC_UNROLL_W _Pragma("unroll (W <= 4 ? 4 : 1)")
+// Loops over the W words of a key: fully unrolled for every width, so that a key lives in registers with constant indices.  (Until round 6
+// the wide keys — k > 123: 8 or 16 words — kept them as loops, because straight-line code for every operation inlined into every kernel of the
+// ONE translation unit made the compile take tens of minutes; the looped keys lived in scratch memory: 736 bytes per lane in the insert,
+// 27x its needed traffic on D' at k = 201.  With the stages in a unit of their own the unrolled 8- and 16-word builds take 50-60 s.)
+#define AC_UNROLL_W _Pragma("unroll (W <= 16 ? 16 : 1)")
 #define AC_UNROLL_FULL _Pragma("unroll")
 
 namespace ac {

@@ -793,12 +793,13 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         const u64 rec_cap = always ? n_ent : n_ent / 4 + 1;      // (taken when it at least halves the bytes: at most n_ent / 4 records)
         DBuf<int32_t> rv(rec_cap); DBuf<u32> rp(rec_cap);         // (stay until the build ends: the copies below read them)
         const Arena::Mark scratch_mark = Arena::device().mark();
-        DBuf<u32> sflag(n_ent + 1), sat(n_ent + 1);
-        launch(n_ent + 1, StretchFlagFunctor{ent_val.ptr(), n_ent, sflag.ptr()});
-        exclusive_scan_u32(sflag.ptr(), sat.ptr(), n_ent + 1);
-        n_stretch = read_scalar(sat.ptr() + n_ent);
+        const u64 n_groups = (n_ent + 63) / 64;
+        DBuf<u32> sflag(n_groups + 1), sat(n_groups + 1);      // (stretch starts per group of 64 entries; [n_groups] = 0: the scan ends with the total)
+        launch_full((n_groups + 1) * 64, StretchCountFunctor{ent_val.ptr(), n_ent, sflag.ptr()});
+        exclusive_scan_u32(sflag.ptr(), sat.ptr(), n_groups + 1);
+        n_stretch = read_scalar(sat.ptr() + n_groups);
         if (n_stretch <= rec_cap) {
-            launch(n_ent, StretchRecordFunctor{ent_val.ptr(), n_ent, sflag.ptr(), sat.ptr(), rv.ptr(), rp.ptr()});
+            launch_full(n_groups * 64, StretchRecordFunctor{ent_val.ptr(), n_ent, sat.ptr(), rv.ptr(), rp.ptr()});
             rec_val_block = PinnedPool::get().alloc(n_stretch * 4); rec_pos_block = PinnedPool::get().alloc(n_stretch * 4);
             out->path_block = PinnedPool::get().alloc(n_ent * 4);      // (written by the host's threads, not by a copy)
             side.after_main();

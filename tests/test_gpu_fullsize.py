@@ -204,6 +204,9 @@ def test_config_e_full_size_k51():
     r = g.verify_device(d_text.data_ptr(), job["n_text"], job["off"], job["lens"])
     assert r["failed"] == 0 and r["bases_checked"] == job["bases"], r
     assert r["checks"] == 15, r      # round 6: L-line order (with seed numbers), maximality and expand_repeats' fixed point ran on all 81.9 M unitigs
+    tm = g.timings()
+    # round 6: above 8 M unitigs the path entries reach the host as stretches of consecutive text-order numbers — at least 4x fewer records than entries
+    assert 0 < tm["path_stretches"] * 4 <= tm["n_path_entries"], (tm["path_stretches"], tm["n_path_entries"])
     if os.environ.get("AC_TEST_TORCH_CHECK"):
         lib.ac_release_memory()
         fullsize_e.check_on_device(g, job, d_text, log=print)

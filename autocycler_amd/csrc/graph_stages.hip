@@ -781,8 +781,8 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     struct RemapJoin { PathRemapJob& j; ~RemapJoin() { path_remap_finish(j); } } remap_join{remap_job};      // (the threads are done before the guard and the table go)
     // Round 6: where that table would be too large for the host's caches (more than 8 M unitigs: a mixed-species job) the entries cross as
     // STRETCHES of consecutive text-order numbers (kernels_paths.inc) — 8 bytes per stretch instead of 4 per entry — and the host writes
-    // the final numbers out from the table front to back: configs[4]'s 4.8 GB of entries took 165 ms behind everything else at the
-    // 30 GB/s the link gives device -> host.  Taken when it at least halves the bytes (one more read-back, on a build of seconds).
+    // the final numbers out from the table front to back: configs[4]'s 4.8 GB of entries are 84 ms of the 57 GB/s the link gives device ->
+    // host (tools/microbench/d2h_probe.hip), behind 3 GB of other late results.  Taken when it at least halves the bytes (one more read-back, on a build of seconds).
     HostBlock rec_val_block, rec_pos_block;
     u64 n_stretch = 0;
     bool host_stretch = false;

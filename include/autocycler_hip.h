@@ -375,7 +375,7 @@ int ac_compress_seqs(uint32_t k, const ac_seqs*, int device, ac_graph** out);
 int ac_compress_dir(const char* assemblies_dir, const char* autocycler_dir, uint32_t k, uint32_t max_contigs,
                     int threads, int device, ac_graph** graph_out, double* times);
 
-/* The same over several devices (ac_compress_build_multi behind the host loader and the host end repair). */
+/* The same over several devices (ac_compress_build_multi behind the host loader; end repair on devices[0]). */
 int ac_compress_dir_multi(const char* assemblies_dir, const char* autocycler_dir, uint32_t k, uint32_t max_contigs, int threads,
                           const int* devices, int n_devices, ac_graph** graph_out, double* times);
 

@@ -45,7 +45,8 @@ class Timings(C.Structure):
                 ("fragments", C.c_double), ("union_pack", C.c_double), ("union_insert", C.c_double),
                 ("n_local_distinct", C.c_uint64), ("n_fragments", C.c_uint64), ("fragment_bytes", C.c_uint64),
                 ("upload_device_ms", C.c_double), ("path_runs_copied", C.c_uint64), ("path_entries_walked", C.c_uint64), ("position_retries", C.c_uint64), ("n_candidates_owned", C.c_uint32),
-                ("launches", C.c_uint32), ("readbacks", C.c_uint32), ("n_degrees_open", C.c_uint64), ("sort_retries", C.c_uint64), ("insert_rest_known", C.c_double), ("insert_rest_sampled", C.c_double), ("path_stretches", C.c_uint64)]
+                ("launches", C.c_uint32), ("readbacks", C.c_uint32), ("n_degrees_open", C.c_uint64), ("sort_retries", C.c_uint64), ("insert_rest_known", C.c_double), ("insert_rest_sampled", C.c_double), ("path_stretches", C.c_uint64),
+                ("expand_sparse_sweeps", C.c_uint32), ("expand_sparse_start", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -930,6 +930,7 @@ int ac_timings_get(const ac_graph* g, ac_timings* o) {
     o->n_candidates_owned = t.n_candidates_owned;
     o->launches = t.launches; o->readbacks = t.readbacks; o->n_degrees_open = t.n_degrees_open; o->sort_retries = t.sort_retries;
     o->insert_rest_known = t.insert_rest_known; o->insert_rest_sampled = t.insert_rest_sampled; o->path_stretches = t.path_stretches;
+    o->expand_sparse_sweeps = t.expand_sparse_sweeps; o->expand_sparse_start = t.expand_sparse_start;
     return 0;
 }
 // The same for a caller that was compiled against another version of the header: at most out_size bytes are written (the struct only

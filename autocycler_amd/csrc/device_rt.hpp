@@ -56,6 +56,8 @@ inline void atomic_min32(u32* p, u32 v) { if (v < *p) *p = v; }
 inline void atomic_max32(u32* p, u32 v) { if (v > *p) *p = v; }
 inline u32 atomic_cas32(u32* p, u32 expected, u32 desired) { u32 old = *p; if (old == expected) *p = desired; return old; }
 inline u32 atomic_load32(const u32* p) { return *p; }
+inline u32 atomic_fetch_or32(u32* p, u32 v) { u32 o = *p; *p |= v; return o; }
+inline u32 atomic_fetch_and32(u32* p, u32 v) { u32 o = *p; *p &= v; return o; }
 #else
 __device__ inline u64 atomic_cas64(u64* p, u64 expected, u64 desired) {
     return (u64)atomicCAS((unsigned long long*)p, (unsigned long long)expected, (unsigned long long)desired);
@@ -71,6 +73,8 @@ __device__ inline void atomic_min32(u32* p, u32 v) { atomicMin(p, v); }
 __device__ inline void atomic_max32(u32* p, u32 v) { atomicMax(p, v); }
 __device__ inline u32 atomic_cas32(u32* p, u32 expected, u32 desired) { return atomicCAS(p, expected, desired); }
 __device__ inline u32 atomic_load32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }      // (past this CU's L1: another CU's store is seen)
+__device__ inline u32 atomic_fetch_or32(u32* p, u32 v) { return atomicOr(p, v); }
+__device__ inline u32 atomic_fetch_and32(u32* p, u32 v) { return atomicAnd(p, v); }
 #endif
 
 // ---- per-thread counters of what a build asks of the runtime (ac_timings.launches / .readbacks) ---------------------------------------
@@ -770,19 +774,20 @@ template <class F> void launch_full(u64 n, const F& f, stream_t s = 0) {
 }
 // A kernel of 256-thread workgroups that uses the wavefront primitives of wave_rt.hpp: hipLaunchKernelGGL on the device, the lockstep
 // emulation under AC_EMU — the same kernel source either way.
-template <class K, class... A> void launch_wave_kernel(K kernel, u64 blocks, stream_t s, A... args) {
+template <class K, class... A> void launch_wave_kernel_sized(K kernel, u64 blocks, unsigned threads, stream_t s, A... args) {
     if (blocks == 0) return;
     if (blocks > 0xFFFFFFULL) throw DeviceError("grid too large");
 #ifdef AC_EMU
     (void)s;
-    wv::launch_kernel(kernel, (unsigned)blocks, 256u, args...);
+    wv::launch_kernel(kernel, (unsigned)blocks, threads, args...);
 #else
     if (s == 0) flush_fills();
     rt_counters().launches++;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), 0, s, args...);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(threads), 0, s, args...);
     AC_HIP_CHECK(hipGetLastError());
 #endif
 }
+template <class K, class... A> void launch_wave_kernel(K kernel, u64 blocks, stream_t s, A... args) { launch_wave_kernel_sized(kernel, blocks, 256u, s, args...); }
 // Bump allocation from a device counter with ONE atomic per wavefront (a counter hit by every lane serialises in L2).
 // All 64 lanes must call it (amount may be 0).  Returns this lane's offset.
 AC_D u32 wave_alloc32(u32* counter, u32 amount) {

@@ -43,6 +43,8 @@ struct BuildTimings {                   // seconds; device stages are bracketed 
     double upload_device_ms = 0;        // host entry: first copy issued -> last chunk landed and packed (HIP events)
     double insert_rest_known = 0;       // share of a sample of the insert's one-launch rest found in the table after the first two stretches (sizes its chunks)
     uint64_t path_stretches = 0;        // the paths crossed to the host as this many stretches of consecutive text-order numbers (0: as entries)
+    uint32_t expand_sparse_sweeps = 0;  // passes of expand_repeats that the one-workgroup tail ran from the list of dirty junctions (kernels_tail.inc expand_mopup_kernel)
+    uint32_t expand_sparse_start = 0;   // ... and the dirty junctions on that list when it took over
     double insert_rest_sampled = 0;     // ... and the share of that rest the sample could cover (the text that was on the device when it was taken)
     uint32_t sort_retries = 0;          // builds repeated with checked sorts (a deferred "group too large" flag of the seed sort / a renumbering was set)
     uint32_t position_retries = 0;      // builds repeated with exact smallest positions (AC_POS_CAP; kernels_tail.inc exp_avoid_start_of_path)

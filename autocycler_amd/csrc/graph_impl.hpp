@@ -388,6 +388,7 @@ struct Knobs {
     u32 expand_level_table;
     bool shard_path_copy;
     bool expand_rewrite_always;
+    u32 expand_sparse_max, expand_sparse_list, expand_sparse_batch;
     bool seq_writer_plain;
     bool seq_writer_forced;
     u64 seed_radix_limit;
@@ -431,6 +432,9 @@ struct Knobs {
         k.expand_level_table = [&]() -> u32 { const char* e = getenv("AC_EXPAND_LEVEL_TABLE"); int v = e ? atoi(e) : 1024; return (u32)(v < 1 ? 1 : v); }();
         k.shard_path_copy = [&]() -> bool { const char* e = getenv("AC_SHARD_PATH_COPY"); return !(e && atoi(e) == 0); }();
         k.expand_rewrite_always = [&]() -> bool { return getenv("AC_EXPAND_REWRITE_ALWAYS") != nullptr; }();
+        k.expand_sparse_max = [&]() -> u32 { const char* e = getenv("AC_EXPAND_SPARSE_MAX"); int v = e ? atoi(e) : 256; return (u32)(v < 0 ? 0 : v); }();
+        k.expand_sparse_list = [&]() -> u32 { const char* e = getenv("AC_EXPAND_SPARSE_LIST"); int v = e ? atoi(e) : 0; return (u32)(v < 0 ? 0 : v); }();
+        k.expand_sparse_batch = [&]() -> u32 { const char* e = getenv("AC_EXPAND_SPARSE_BATCH"); int v = e ? atoi(e) : 4096; return (u32)(v < 1 ? 1 : v); }();
         k.seq_writer_plain = [&]() -> bool { const char* e = getenv("AC_SEQ_WRITER"); return e && atoi(e) == 0; }();
         k.seq_writer_forced = [&]() -> bool { const char* e = getenv("AC_SEQ_WRITER"); return e && atoi(e) == 1; }();
         k.seed_radix_limit = [&]() -> u64 { const char* e = getenv("AC_SEED_RADIX_LIMIT"); return e ? (u64)atoll(e) : (1u << 19); }();
@@ -530,6 +534,9 @@ static thread_local int tl_upload_threads_cap = 0;      // a rank of a multi-dev
 [[maybe_unused]] static bool insert_profile() { static const bool v = getenv("AC_INSERT_PROFILE") != nullptr; return v; }      // measurement only
 [[maybe_unused]] static u32 expand_level_table() { return knobs().expand_level_table; }      // tests: a table too small for the levels
 [[maybe_unused]] static bool shard_path_copy() { return knobs().shard_path_copy; }      // 0 = a sharded build walks all of its text (rounds 3-4)
+[[maybe_unused]] static u32 expand_sparse_max() { return knobs().expand_sparse_max; }      // expand_repeats: at most this many dirty junctions for the one-workgroup tail (0: level launches to the end)
+[[maybe_unused]] static u32 expand_sparse_list() { return knobs().expand_sparse_list; }      // tests: the list length at which that tail hands back to the level launches (0: 8 x the start limit)
+[[maybe_unused]] static u32 expand_sparse_batch() { return knobs().expand_sparse_batch; }      // tests: junctions of one level the tail stages in LDS (more: straight from the list)
 [[maybe_unused]] static bool expand_rewrite_always() { return knobs().expand_rewrite_always; }      // tests: compact the expand pool after every host check
 [[maybe_unused]] static bool seq_writer_plain() { return knobs().seq_writer_plain; }      // 0 = always the search-per-thread writers
 [[maybe_unused]] static bool seq_writer_forced() { return knobs().seq_writer_forced; }      // 1 = always the indexed / LDS-tiled writers

@@ -885,7 +885,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     bool final_total_pending = false;      // the last rewrite's sum is read with the build's last batch (small outputs: MaterializeFunctor takes it from the device)
     u64 n_links = 0;
     int passes = 0;
-    u32 n_cand = 0, n_levels = 0;
+    u32 n_cand = 0, n_levels = 0, sparse_sweeps = 0, sparse_start = 0;
     const bool partitioned = n_owners > 1 && (bool)tail_xchg;      // (decided by the driver: the same on every rank)
     DBuf<u8> jowner; DBuf<u32> owned_count, gpre, gpost;
     u32 n_cand_owned = 0;
@@ -905,7 +905,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             u64 C = n_cand;
             DBuf<u32> clist(C), level(C);
             prio.fill_bytes(0xFF);
-            DBuf<u32> changed(9), preds(C * MAX_PREDS); DBuf<u8> npred(C);
+            DBuf<u32> changed(16), preds(C * MAX_PREDS); DBuf<u8> npred(C);      // changed[9]: the sparse tail's list length, [10..12]: what it reports (MopState::out)
             changed.fill_bytes(0);      // (the first round of sweeps: cleared with this batch)
             RadixScratch sort_lv;
             sort_lv.prepare(C, 32);
@@ -970,6 +970,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                 if (!last) pool_used.fill_bytes(0);      // (nothing allocates from the pool after the last rewrite)
                 moved_since_rewrite = 0;
             };
+            const u32 sparse_max = expand_sparse_max();
             const u32 sub_limit = (u32)(pool.size() / 2 / EXP_SUBPOOLS / 2);      // a region half full (or anything in the overflow half) asks for a rewrite
             auto run_level = [&](u32 lv) {
                 const u64 cnt = (u64)(hb[lv + 1] - hb[lv]);
@@ -985,12 +986,18 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                     e.shifted = sh_words + half;
                     for (u32 lv = 1; lv <= n_levels; lv++) run_level(lv);
                 }
-                u64 sh[2]; u32 used = 0;
+                if (sparse_max) {      // the dirty junctions listed, and — if they are few and the second pass moved something — all remaining passes by one workgroup (kernels_tail.inc)
+                    launch_full((C + 63) & ~63ULL, MopCompactFunctor{clist.ptr(), lkey.ptr(), dirty.ptr(), (u64*)preds.ptr(), changed.ptr() + 9, C});
+                    const MopState ms{(u64*)preds.ptr(), changed.ptr() + 9, prio.ptr(), level.ptr(), sh_words, changed.ptr() + 10, sparse_max, expand_sparse_list() ? expand_sparse_list() : 8 * sparse_max, sub_limit, std::min(MOP_BATCH, expand_sparse_batch())};
+                    launch_wave_kernel_sized(expand_mopup_kernel<W>, 1, MOP_THREADS, 0, e, ms, (u32)pool.size(), counters.ptr() + 7);
+                }
+                u64 sh[2]; u32 used = 0; u32 mop[3] = {0, 0, 0};
                 {
                     std::vector<u32> pu(EXP_SUBPOOLS + 1);
                     ReadBatch rb;
                     rb.add(sh, sh_words, 16);
                     rb.add(pu.data(), pool_used.ptr(), (EXP_SUBPOOLS + 1) * 4);
+                    if (sparse_max) rb.add(mop, changed.ptr() + 10, 12);
                     rb.run();
                     for (u32 q = 0; q < EXP_SUBPOOLS; q++) used = std::max(used, pu[q]);
                     if (pu[EXP_SUBPOOLS]) used = 0xFFFFFFFFu;
@@ -999,6 +1006,11 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                 if (sh[0] == 0) { passes += 1; break; }
                 passes += 2;
                 if (sh[1] == 0) break;
+                if (mop[0]) {      // the one-workgroup tail ran: its sweeps are passes of the reference (the last one of a finished tail moved nothing)
+                    passes += (int)mop[1];
+                    sparse_sweeps += mop[1]; sparse_start = mop[2];
+                    if (mop[0] == 1) break;
+                }
                 if (used > sub_limit || expand_rewrite_always()) rewrite(false);
             }
             if (!partitioned) { if (moved_since_rewrite) rewrite(true); }
@@ -1037,6 +1049,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         }
     }
     tm->simplify_passes = (u32)passes; tm->n_candidates = n_cand; tm->n_levels = n_levels;
+    tm->expand_sparse_sweeps = sparse_sweeps; tm->expand_sparse_start = sparse_start;
     tm->n_candidates_owned = partitioned && n_cand ? n_cand_owned : n_cand;
     lap(&tm->expand);
 

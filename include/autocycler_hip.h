@@ -74,6 +74,8 @@ typedef struct {
     double insert_rest_known;    /* share of a sample of the insert's one-launch rest that the first two stretches already held (sizes the rest's chunks); 0 = no such rest */
     double insert_rest_sampled;  /* share of that rest the sample could cover: only text that was on the device when it was taken (an upload still in flight: its first chunks) */
     uint64_t path_stretches;     /* > 0: the path entries crossed to the host as this many stretches of consecutive text-order numbers (8 bytes each) and were written out there */
+    uint32_t expand_sparse_sweeps; /* passes of expand_repeats run by the one-workgroup tail from the list of dirty junctions (0: level launches to the end) */
+    uint32_t expand_sparse_start;  /* ... and the length of that list when it took over */
 } ac_timings;
 
 /* Replaces compress.rs:42-44.  k: --kmer (odd).  assembly_count: the reference's capacity hint

@@ -298,3 +298,27 @@ def test_deferred_sort_flags_repeat_the_build(emu, monkeypatch):
         for kk in knobs:
             monkeypatch.delenv(kk)
 
+
+
+@pytest.mark.parametrize("knobs,ran", [({"AC_EXPAND_SPARSE_MAX": "0"}, False), ({}, True), ({"AC_EXPAND_SPARSE_MAX": "100000"}, True),
+                                       ({"AC_EXPAND_SPARSE_MAX": "100000", "AC_EXPAND_SPARSE_BATCH": "3"}, True),
+                                       ({"AC_EXPAND_SPARSE_MAX": "100000", "AC_EXPAND_SPARSE_LIST": "1"}, True),
+                                       ({"AC_EXPAND_SPARSE_MAX": "100000", "AC_EXPAND_REWRITE_ALWAYS": "1"}, True)],
+                         ids=["off", "default", "always", "tiny_lds_batch", "hands_back_after_a_sweep", "rewrite_every_check"])
+def test_expand_sparse_tail(emu, monkeypatch, knobs, ran):
+    """Round 6: behind the first two passes of expand_repeats ONE workgroup runs the remaining passes from a list of the dirty junctions
+    (kernels_tail.inc expand_mopup_kernel).  The same graph whether it runs, stages a level in LDS or reads it from the list, or stops at a
+    sweep boundary and hands back to the level launches — and the same number of passes as the level launches count."""
+    from autocycler_amd import synth
+    for a, b in knobs.items():
+        monkeypatch.setenv(a, b)
+    for asm in (synth.make_mixed_species(2, 5, genome=40_000, plasmid=2_000, strain_div=2e-2, sub=2e-3, indel=2e-4, seed=7),
+                synth.make_assemblies(8, genome=80_000, plasmid=3_000, sub=2e-3, indel=2e-4, seed=5)):
+        seqs, fn, hd = synth.flatten(asm)
+        g, _, _ = parity_util.check_case(51, [bytes(s) for s in seqs], fn, hd, lib_path=emu)
+        tm = g.timings()
+        assert tm["simplify_passes"] == 4, tm
+        assert (tm["expand_sparse_sweeps"] > 0) == ran and (tm["expand_sparse_start"] > 0) == ran, tm
+        if knobs.get("AC_EXPAND_SPARSE_LIST"):
+            assert tm["expand_sparse_sweeps"] == 1, tm      # (it moved something, the list was longer than 1: back to the level launches)
+        g.close()

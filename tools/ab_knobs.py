@@ -142,7 +142,7 @@ def main():
                               "table_capacity": tm["table_capacity"], "insert_launches": tm["insert_launches"], "launches": tm.get("launches"), "readbacks": tm.get("readbacks"), "unitigs": st["unitigs"], "gfa_md5": dg,
                               "path_runs_copied": tm["path_runs_copied"], "path_entries_walked": tm["path_entries_walked"], "position_retries": tm["position_retries"],
                               "path_entries": tm.get("n_path_entries"), "path_stretches": tm.get("path_stretches"),
-                              "expand": {q: tm[q] for q in ("n_candidates", "n_levels", "simplify_passes") if q in tm}}), flush=True)
+                              "expand": {q: tm[q] for q in ("n_candidates", "n_levels", "simplify_passes", "expand_sparse_sweeps", "expand_sparse_start") if q in tm}}), flush=True)
         except Exception as e:      # a variant that fails must not take the others with it
             print(json.dumps({"variant": variant, "error": str(e)}), flush=True)
     lib.ac_seqs_free(h_seqs)

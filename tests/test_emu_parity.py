@@ -300,6 +300,21 @@ def test_deferred_sort_flags_repeat_the_build(emu, monkeypatch):
 
 
 
+_SPARSE_CASE = {}
+
+
+def _sparse_case():
+    """One mixed-species input and the oracle's answer for it (computed once for the six settings below)."""
+    if not _SPARSE_CASE:
+        import oracle_lib as O
+        from autocycler_amd import synth
+        seqs, fn, hd = synth.flatten(synth.make_mixed_species(2, 5, genome=40_000, plasmid=2_000, strain_div=2e-2, sub=2e-3, indel=2e-4, seed=7))
+        s = O.Seqs.from_raw(51, [bytes(q) for q in seqs], filenames=fn, headers=hd, repair=True)
+        gfa_o, st, _ = s.compress(51)
+        _SPARSE_CASE.update(s=s, gfa=gfa_o, st=st, loaded=s.all())
+    return _SPARSE_CASE
+
+
 @pytest.mark.parametrize("knobs,ran", [({"AC_EXPAND_SPARSE_MAX": "0"}, False), ({}, True), ({"AC_EXPAND_SPARSE_MAX": "100000"}, True),
                                        ({"AC_EXPAND_SPARSE_MAX": "100000", "AC_EXPAND_SPARSE_BATCH": "3"}, True),
                                        ({"AC_EXPAND_SPARSE_MAX": "100000", "AC_EXPAND_SPARSE_LIST": "1"}, True),
@@ -309,16 +324,18 @@ def test_expand_sparse_tail(emu, monkeypatch, knobs, ran):
     """Round 6: behind the first two passes of expand_repeats ONE workgroup runs the remaining passes from a list of the dirty junctions
     (kernels_tail.inc expand_mopup_kernel).  The same graph whether it runs, stages a level in LDS or reads it from the list, or stops at a
     sweep boundary and hands back to the level launches — and the same number of passes as the level launches count."""
-    from autocycler_amd import synth
+    from autocycler_amd import compress_build
     for a, b in knobs.items():
         monkeypatch.setenv(a, b)
-    for asm in (synth.make_mixed_species(2, 5, genome=40_000, plasmid=2_000, strain_div=2e-2, sub=2e-3, indel=2e-4, seed=7),
-                synth.make_assemblies(8, genome=80_000, plasmid=3_000, sub=2e-3, indel=2e-4, seed=5)):
-        seqs, fn, hd = synth.flatten(asm)
-        g, _, _ = parity_util.check_case(51, [bytes(s) for s in seqs], fn, hd, lib_path=emu)
-        tm = g.timings()
-        assert tm["simplify_passes"] == 4, tm
-        assert (tm["expand_sparse_sweeps"] > 0) == ran and (tm["expand_sparse_start"] > 0) == ran, tm
-        if knobs.get("AC_EXPAND_SPARSE_LIST"):
-            assert tm["expand_sparse_sweeps"] == 1, tm      # (it moved something, the list was longer than 1: back to the level launches)
-        g.close()
+    c = _sparse_case()
+    loaded, st = c["loaded"], c["st"]
+    g = compress_build(51, c["s"].assembly_count, [(q["fwd"], q["length"], q["id"]) for q in loaded], lib_path=emu)
+    gfa_g = g.gfa([q["filename"] for q in loaded], [q["header"] for q in loaded])
+    assert g.stats_post == dict(unitigs=st["unitigs_post"], links=st["links_post"], total_length=st["length_post"])
+    assert gfa_g == c["gfa"], parity_util.first_diff(c["gfa"], gfa_g)
+    tm = g.timings()
+    assert tm["simplify_passes"] == 4, tm
+    assert (tm["expand_sparse_sweeps"] > 0) == ran and (tm["expand_sparse_start"] > 0) == ran, tm
+    if knobs.get("AC_EXPAND_SPARSE_LIST"):
+        assert tm["expand_sparse_sweeps"] == 1, tm      # (it moved something, the list was longer than 1: back to the level launches)
+    g.close()

@@ -28,7 +28,7 @@ class Position(C.Structure):
 
 
 class Link(C.Structure):
-    _fields_ = [("a", C.c_uint32), ("a_fwd", C.c_uint8), ("b", C.c_uint32), ("b_fwd", C.c_uint8)]
+    _fields_ = [("a", C.c_int32), ("b", C.c_int32)]      # signed unitig numbers: +n forward strand, -n reverse (ABI 7)
 
 
 class Stats(C.Structure):
@@ -185,7 +185,7 @@ class Graph:
     def links(self):
         p, n = C.POINTER(Link)(), C.c_uint64()
         _check(self._lib, self._lib.ac_links(self._h, C.byref(p), C.byref(n)))
-        return [(p[i].a, bool(p[i].a_fwd), p[i].b, bool(p[i].b_fwd)) for i in range(n.value)]
+        return [(abs(p[i].a), p[i].a > 0, abs(p[i].b), p[i].b > 0) for i in range(n.value)]      # (unitig, forward?) pairs like UnitigStrand
 
     def path(self, seq_index):
         p, n = C.POINTER(C.c_int32)(), C.c_uint32()
@@ -193,8 +193,8 @@ class Graph:
         return p[:n.value]
 
     def bulk(self):
-        """Zero-copy numpy views (valid while this handle lives): seq_bytes, seq_begin, seq_len, depth, links (structured: a, a_fwd, b,
-        b_fwd), path_entries, path_off."""
+        """Zero-copy numpy views (valid while this handle lives): seq_bytes, seq_begin, seq_len, depth, links (structured: a, b — signed
+        unitig numbers, negative = reverse strand), path_entries, path_off."""
         import numpy as np
         U = self.unitig_count
         sb, bg, ln, dp = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
@@ -205,7 +205,7 @@ class Graph:
         seq_bytes = view(sb, total, C.c_uint8)
         lp, n = C.POINTER(Link)(), C.c_uint64()
         _check(self._lib, self._lib.ac_links(self._h, C.byref(lp), C.byref(n)))
-        ldt = np.dtype([("a", "<u4"), ("a_fwd", "u1"), ("_p0", "u1", (3,)), ("b", "<u4"), ("b_fwd", "u1"), ("_p1", "u1", (3,))])
+        ldt = np.dtype([("a", "<i4"), ("b", "<i4")])
         assert ldt.itemsize == C.sizeof(Link)
         links = np.frombuffer((C.c_uint8 * (n.value * C.sizeof(Link))).from_address(C.addressof(lp.contents)), dtype=ldt) if n.value else np.zeros(0, dtype=ldt)
         pe, po, ne = C.c_void_p(), C.c_void_p(), C.c_uint64()

@@ -73,11 +73,14 @@ void load_gfa(const char* text, size_t len, FinalGraph* g, std::vector<SeqMeta>*
                 case 'L': {   // build_links_from_gfa (unitig_graph.rs:91-115)
                     if (f.size() < 6 || f[5].second != 2 || memcmp(f[5].first, "0M", 2))
                         throw GfaError("non-zero overlap found on the GFA link line.\nAre you sure this is an Autocycler-generated GFA file?");
+                    // (numbers beyond what a signed entry holds name no unitig of a graph this library can hold: kept as 0x7FFFFFFF, refused below)
+                    const uint64_t na = std::min<uint64_t>(to_u64(f[1].first, f[1].second, "segment 1 as integer"), 0x7FFFFFFFu);
+                    const uint64_t nb = std::min<uint64_t>(to_u64(f[3].first, f[3].second, "segment 2 as integer"), 0x7FFFFFFFu);
+                    if (na == 0) throw GfaError("link refers to nonexistent unitig: 0");
+                    if (nb == 0) throw GfaError("link refers to nonexistent unitig: 0");
                     Link l;
-                    l.a = (uint32_t)to_u64(f[1].first, f[1].second, "segment 1 as integer");
-                    l.b = (uint32_t)to_u64(f[3].first, f[3].second, "segment 2 as integer");
-                    l.a_fwd = (f[2].second == 1 && f[2].first[0] == '+') ? 1 : 0;
-                    l.b_fwd = (f[4].second == 1 && f[4].first[0] == '+') ? 1 : 0;
+                    l.a = (f[2].second == 1 && f[2].first[0] == '+') ? (int32_t)na : -(int32_t)na;
+                    l.b = (f[4].second == 1 && f[4].first[0] == '+') ? (int32_t)nb : -(int32_t)nb;
                     links.push_back(l);
                     break;
                 }
@@ -122,12 +125,12 @@ void load_gfa(const char* text, size_t len, FinalGraph* g, std::vector<SeqMeta>*
     g->seq_begin = seq_begin; g->depth = depth; g->seq_len = seq_len;
     // link vectors are per unitig strand in file order; save_gfa walks the unitigs: forward_next, then reverse_next
     for (auto& l : links) {
-        if (l.a == 0 || l.a > U) throw GfaError("link refers to nonexistent unitig: " + std::to_string(l.a));
-        if (l.b == 0 || l.b > U) throw GfaError("link refers to nonexistent unitig: " + std::to_string(l.b));
+        if (l.na() == 0 || l.na() > U) throw GfaError("link refers to nonexistent unitig: " + std::to_string(l.na()));
+        if (l.nb() == 0 || l.nb() > U) throw GfaError("link refers to nonexistent unitig: " + std::to_string(l.nb()));
     }
     std::stable_sort(links.begin(), links.end(), [](const Link& x, const Link& y) {
-        if (x.a != y.a) return x.a < y.a;
-        return x.a_fwd > y.a_fwd;
+        if (x.na() != y.na()) return x.na() < y.na();
+        return x.a_fwd() > y.a_fwd();
     });
     g->links_block = heap_block(links.size() * sizeof(Link));
     if (!links.empty()) memcpy(g->links_block.p, links.data(), links.size() * sizeof(Link));
@@ -157,7 +160,7 @@ void load_gfa(const char* text, size_t len, FinalGraph* g, std::vector<SeqMeta>*
     g->path = (const int32_t*)g->path_block.p;
     g->n_path = ent.size();
     uint64_t self_mirror = 0;
-    for (auto& l : links) if (l.a == l.b && l.a_fwd != l.b_fwd) self_mirror++;
+    for (auto& l : links) if (l.a == -l.b) self_mirror++;
     GraphStats st{(uint32_t)U, (links.size() + self_mirror) / 2, total};
     g->pre = st; g->post = st;
 }

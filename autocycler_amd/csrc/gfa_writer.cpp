@@ -55,8 +55,8 @@ static void l_lines(const FinalGraph& g, uint64_t a, uint64_t b, std::string& ou
     Out o(out);
     for (uint64_t li = a; li < b; li++) {
         const Link& l = g.links[li];
-        AC_LIT(o, "L\t"); o.u64(l.a); if (l.a_fwd) AC_LIT(o, "\t+\t"); else AC_LIT(o, "\t-\t"); o.u64(l.b);
-        if (l.b_fwd) AC_LIT(o, "\t+\t0M\n"); else AC_LIT(o, "\t-\t0M\n");
+        AC_LIT(o, "L\t"); o.u64(l.na()); if (l.a_fwd()) AC_LIT(o, "\t+\t"); else AC_LIT(o, "\t-\t"); o.u64(l.nb());
+        if (l.b_fwd()) AC_LIT(o, "\t+\t0M\n"); else AC_LIT(o, "\t-\t0M\n");
     }
 }
 

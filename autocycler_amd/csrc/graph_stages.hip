@@ -1149,7 +1149,9 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         if (loc.check_alphabet && loc.pack_bad.size()) rb.add(pack_bad, loc.pack_bad.ptr(), 8);
         rb.run();                                   // synchronises stream 0 (once)
     }
+    const double t_main_done = now_s();
     side.sync();                                    // ... and the copies: everything above has landed
+    const double t_copies_done = now_s();
     if (host_numbers) {
 #ifdef AC_EMU
         if (host_stretch) path_stretch_range(remap_job, 0, n_stretch, &remap_job.bad);
@@ -1158,6 +1160,10 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         path_remap_finish(remap_job);
     }
     tm->path_stretches = host_stretch ? n_stretch : 0;
+    if (knobs().debug_arena)      // (where the d2h stage goes: stream 0 drained -> the copies landed -> the host's renumbering threads done)
+        fprintf(stderr, "d2h: copies landed %.3f ms after stream 0 drained, host renumbering done %.3f ms later; late results %.1f MB (sequences %.1f, unitig records %.1f, links %.1f, number table %.1f), entries %.1f MB\n",
+                (t_copies_done - t_main_done) * 1e3, (now_s() - t_copies_done) * 1e3, (final_total + (double)U * 24 + n_links * sizeof(Link) + (host_numbers ? (double)U * 4 : 0)) / 1e6,
+                final_total / 1e6, (double)U * 24 / 1e6, n_links * sizeof(Link) / 1e6, host_numbers ? (double)U * 4 / 1e6 : 0.0, n_ent * 4 / 1e6);
     if (loc.pack_bad.size()) loc.verify_alphabet(pack_bad);      // before any internal check: a text with foreign bytes explains them all
     if (errs[7] & 128u) throw NeedExactPositions();      // (before anything else: a repeat of the build settles it)
     if (h_sort_flags[0] || h_sort_flags[1]) {

@@ -26,7 +26,29 @@ struct HostBlock {
 
 struct GraphStats { uint32_t unitigs = 0; uint64_t links_one_way = 0; uint64_t total_length = 0; };
 
-struct Link { uint32_t a; uint8_t a_fwd; uint32_t b; uint8_t b_fwd; };
+// A link a -> b as two SIGNED unitig numbers: +n = the forward strand of unitig n, -n = its reverse strand (the form the reference's own
+// path entries have, get_unitig_path_for_sequence_i32).  8 bytes (round 6; rounds 1-5 carried {u32, u8, u32, u8} = 16 with padding: the link
+// array is the largest late result of a mixed-species build — 307 of 648 MB on mini-E — and crosses PCIe behind everything else).
+// 0 is no unitig (a GFA that names one: the verifier's range check).
+struct Link {
+    int32_t a, b;
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    uint32_t na() const { return a < 0 ? (uint32_t)(-(int64_t)a) : (uint32_t)a; }
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    uint32_t nb() const { return b < 0 ? (uint32_t)(-(int64_t)b) : (uint32_t)b; }
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    bool a_fwd() const { return a > 0; }
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    bool b_fwd() const { return b > 0; }
+};
 
 struct Position { uint32_t pos; uint16_t seq_id_and_strand; };   // position.rs:18-22
 

@@ -38,7 +38,11 @@ typedef struct {
 } ac_seq_view;
 
 typedef struct { uint32_t pos; uint16_t seq_id_and_strand; } ac_position; /* position.rs:18-22; strand = bit 15 */
-typedef struct { uint32_t a; uint8_t a_fwd; uint32_t b; uint8_t b_fwd; } ac_link;
+/* A link a -> b (UnitigStrand pairs, unitig_graph.rs:234-287) as two SIGNED unitig numbers: +n = the forward strand of unitig n, -n = its
+ * reverse strand — the form of the reference's own path entries (get_unitig_path_for_sequence_i32).  ABI 7: 8 bytes; ABI <= 6 carried
+ * { uint32_t a; uint8_t a_fwd; uint32_t b; uint8_t b_fwd; } = 16 bytes with padding (the link array is the largest late result of a
+ * mixed-species build and crosses PCIe behind everything else). */
+typedef struct { int32_t a; int32_t b; } ac_link;
 typedef struct { uint32_t unitigs; uint64_t links_one_way; uint64_t total_length; } ac_stats;
 
 /* Seconds spent in each stage of the last build.  The per-stage fields are only filled while stage timing is on
@@ -398,8 +402,9 @@ const char* ac_version(void);
  *   5: ac_shard_*: sib_export / all-reduce / ac_shard_degrees between ac_shard_build_novel and the degree exchange whenever
  *      ac_shard_sib_words() > 0; degree buffers are ac_shard_degree_bytes() bytes; ac_shard_paths_export fails after
  *      ac_shard_finish(want & 2) (the rank's own paths were renumbered on the host: read them from the handle).
- *   6: ac_verify_report grew (checks, first_bad_junction; failed bits 2048 / 4096 / 8192). */
-#define AC_ABI_VERSION 6
+ *   6: ac_verify_report grew (checks, first_bad_junction; failed bits 2048 / 4096 / 8192).
+ *   7: ac_link is two signed unitig numbers (8 bytes; it was { u32 a; u8 a_fwd; u32 b; u8 b_fwd } = 16). */
+#define AC_ABI_VERSION 7
 int ac_abi_version(void);
 const char* ac_source_hash(void);   /* 16 hex digits: digest of the sources this library was built from (csrc/Makefile; tools/source_hash.py) */
 

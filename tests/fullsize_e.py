@@ -118,8 +118,8 @@ def check_on_device(g, job, d_text_t, chunk=1 << 26, log=lambda *a: None):
     # --- links: unique, reverse-complement pairs, one-way count as link_count() defines it (unitig_graph.rs:478-507)
     lk = b["links"]
     n_links = len(lk)
-    la = torch.from_numpy(lk["a"].astype(np.int64)).to(dev) * torch.from_numpy(np.where(lk["a_fwd"] != 0, 1, -1).astype(np.int64)).to(dev)
-    lb = torch.from_numpy(lk["b"].astype(np.int64)).to(dev) * torch.from_numpy(np.where(lk["b_fwd"] != 0, 1, -1).astype(np.int64)).to(dev)
+    la = torch.from_numpy(lk["a"].astype(np.int64)).to(dev)      # (signed unitig numbers: ABI 7)
+    lb = torch.from_numpy(lk["b"].astype(np.int64)).to(dev)
     assert bool(((la.abs() >= 1) & (la.abs() <= U) & (lb.abs() >= 1) & (lb.abs() <= U)).all())
     code = lambda x, y: (x + (1 << 31)) * (1 << 32) + (y + (1 << 31))
     lset = torch.sort(code(la, lb)).values

@@ -80,8 +80,7 @@ def names_the_damage(lib_path, k=21):
     assert g.verify(triples)["failed"] == 0
     # one dropped link (overwritten by its neighbour): a duplicate, a mirror without partner, and path steps that are no links any more
     used = {(int(x), int(y)) for p0, p1 in zip(b["path_off"][:-1], b["path_off"][1:]) for x, y in zip(b["path_entries"][int(p0):int(p1) - 1], b["path_entries"][int(p0) + 1:int(p1)])}
-    sgn = lambda n, f: int(n) if f else -int(n)
-    li = next(i for i in range(len(b["links"]) - 1) if (sgn(b["links"][i]["a"], b["links"][i]["a_fwd"]), sgn(b["links"][i]["b"], b["links"][i]["b_fwd"])) in used)
+    li = next(i for i in range(len(b["links"]) - 1) if (int(b["links"][i]["a"]), int(b["links"][i]["b"])) in used)
     keep = b["links"][li].copy()
     b["links"][li] = b["links"][li + 1]
     rep = check(F_LINK_DUP | F_LINK_MIRROR | F_PATH_STEP, must_not=F_SPELL | F_DEPTH)
@@ -213,7 +212,7 @@ def names_order_sensitive_damage(lib_path, k=21):
     # --- (iii) L lines: two neighbours of different groups, then two of one group, swapped in the handle's own array (seed numbers at hand)
     b = g.bulk()
     L = b["links"]; L.setflags(write=True)
-    grp = lambda l: (int(l["a"]), 1 - int(l["a_fwd"]))
+    grp = lambda l: (abs(int(l["a"])), 0 if int(l["a"]) > 0 else 1)
     i_diff = next(i for i in range(len(L) - 1) if grp(L[i]) != grp(L[i + 1]))
     i_same = next(i for i in range(len(L) - 1) if grp(L[i]) == grp(L[i + 1]))
     for i in (i_diff, i_same):

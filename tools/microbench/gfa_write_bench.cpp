@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
     for (uint32_t i = 0; i < U; i++) { seq_begin[i] = off; seq_len[i] = 1 + (uint32_t)(rng() % 71); depth[i] = 1 + (double)(rng() % 96); off += seq_len[i]; }
     bases.resize(off); for (auto& c : bases) c = "ACGT"[rng() & 3];
     std::vector<Link> links(NL);
-    for (auto& l : links) { l.a = 1 + (uint32_t)(rng() % U); l.b = 1 + (uint32_t)(rng() % U); l.a_fwd = rng() & 1; l.b_fwd = rng() & 1; }
+    for (auto& l : links) { l.a = 1 + (int32_t)(rng() % U); l.b = 1 + (int32_t)(rng() % U); if (rng() & 1) l.a = -l.a; if (rng() & 1) l.b = -l.b; }
     std::vector<int32_t> path(NP);
     for (auto& v : path) { int32_t u = 1 + (int32_t)(rng() % U); v = (rng() & 1) ? u : -u; }
     FinalGraph g; g.k = 51; g.n_unitigs = U; g.seq_block.p = (void*)bases.data(); g.seq_begin = seq_begin.data(); g.depth = depth.data(); g.seq_len = seq_len.data();

@@ -246,7 +246,8 @@ class PinnedPool {
             size_t cap = bytes + bytes / 8 + 4096;
             if (getenv("AC_DEBUG_ARENA")) fprintf(stderr, "pinned pool: new block of %zu bytes (%zu free entries)\n", cap, free_.size());
 #ifdef AC_EMU
-            b.p = malloc(cap);
+            cap = (cap + 4095) & ~(size_t)4095;
+            b.p = aligned_alloc(4096, cap);      // (page-aligned like hipHostMalloc's blocks: the streaming stretch writer wants whole 64-byte lines)
             if (!b.p) throw DeviceError("out of host memory");
 #else
             AC_HIP_CHECK(hipHostMalloc(&b.p, cap, hipHostMallocDefault));

@@ -305,11 +305,13 @@ struct PathRemapJob {
     // stretch s (a text-order number, signed), rec_pos[s] = its first entry's index; the threads WRITE path[] from the number table
     const int32_t* rec_val = nullptr; const u32* rec_pos = nullptr; u64 n_rec = 0;
     const u32* number = nullptr; u32 n_unitigs = 0;      // pinned: final number of seed index r at [r]
+    u64 ent_limit = ~0ULL;                               // stretch mode: stretches that begin at or behind this entry are not the host's (the device renumbers that share and sends it over)
     void* landed = nullptr;                              // event: entries and number table are in host memory
     int dev = 0;
     std::atomic<u64> next{0}; std::atomic<int> ready{0};      // ready: 0 nobody waits yet, 1 one thread waits for `landed`, 2 go, 3 failed
     std::atomic<u32> bad{0};                             // entries that name no unitig (never, short of a bug: reported as an internal error)
     u64 ticket = 0; bool started = false;
+    std::atomic<double> t_ready{0}, t_last{0};      // diagnostics (AC_DEBUG_ARENA): when the copies the job waits for had landed, when its last block was done (now_s clock)
 };
 void path_remap_range(int32_t* p, u64 n, const u32* number, u32 n_unitigs, std::atomic<u32>* bad);
 void path_stretch_range(const PathRemapJob& j, u64 s0, u64 s1, std::atomic<u32>* bad);      // stretches [s0, s1) written out
@@ -389,6 +391,7 @@ struct Knobs {
     bool shard_path_copy;
     bool expand_rewrite_always;
     u32 expand_sparse_max, expand_sparse_list, expand_sparse_batch;
+    u32 stretch_device_share;
     bool seq_writer_plain;
     bool seq_writer_forced;
     u64 seed_radix_limit;
@@ -433,6 +436,7 @@ struct Knobs {
         k.shard_path_copy = [&]() -> bool { const char* e = getenv("AC_SHARD_PATH_COPY"); return !(e && atoi(e) == 0); }();
         k.expand_rewrite_always = [&]() -> bool { return getenv("AC_EXPAND_REWRITE_ALWAYS") != nullptr; }();
         k.expand_sparse_max = [&]() -> u32 { const char* e = getenv("AC_EXPAND_SPARSE_MAX"); int v = e ? atoi(e) : 256; return (u32)(v < 0 ? 0 : v); }();
+        k.stretch_device_share = [&]() -> u32 { const char* e = getenv("AC_STRETCH_DEVICE_SHARE"); int v = e ? atoi(e) : 40; return (u32)(v < 0 ? 0 : v); }();
         k.expand_sparse_list = [&]() -> u32 { const char* e = getenv("AC_EXPAND_SPARSE_LIST"); int v = e ? atoi(e) : 0; return (u32)(v < 0 ? 0 : v); }();
         k.expand_sparse_batch = [&]() -> u32 { const char* e = getenv("AC_EXPAND_SPARSE_BATCH"); int v = e ? atoi(e) : 4096; return (u32)(v < 1 ? 1 : v); }();
         k.seq_writer_plain = [&]() -> bool { const char* e = getenv("AC_SEQ_WRITER"); return e && atoi(e) == 0; }();
@@ -535,6 +539,7 @@ static thread_local int tl_upload_threads_cap = 0;      // a rank of a multi-dev
 [[maybe_unused]] static u32 expand_level_table() { return knobs().expand_level_table; }      // tests: a table too small for the levels
 [[maybe_unused]] static bool shard_path_copy() { return knobs().shard_path_copy; }      // 0 = a sharded build walks all of its text (rounds 3-4)
 [[maybe_unused]] static u32 expand_sparse_max() { return knobs().expand_sparse_max; }      // expand_repeats: at most this many dirty junctions for the one-workgroup tail (0: level launches to the end)
+[[maybe_unused]] static u32 stretch_device_share() { return knobs().stretch_device_share; }      // paths sent as stretches: per cent of the entries (the last ones) the device renumbers and sends itself (0: the host writes all of them)
 [[maybe_unused]] static u32 expand_sparse_list() { return knobs().expand_sparse_list; }      // tests: the list length at which that tail hands back to the level launches (0: 8 x the start limit)
 [[maybe_unused]] static u32 expand_sparse_batch() { return knobs().expand_sparse_batch; }      // tests: junctions of one level the tail stages in LDS (more: straight from the list)
 [[maybe_unused]] static bool expand_rewrite_always() { return knobs().expand_rewrite_always; }      // tests: compact the expand pool after every host check

@@ -812,6 +812,12 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         if (!host_stretch) { rv = DBuf<int32_t>(); rp = DBuf<u32>(); }
     }
     const bool host_numbers = host_remap || host_stretch;      // the device only checks the paths' length sums; the host writes the final numbers
+    // (stretch mode: the waves of RemapFunctor — remap_block() entries each — from this one on are the DEVICE's share of the renumbering; see K16 below)
+    const u64 stretch_split_wave = [&]() -> u64 {
+        const u64 n_waves = (n_ent + remap_block() - 1) / remap_block();
+        const u32 pct = std::min<u32>(stretch_device_share(), 100u);
+        return host_stretch ? n_waves - (u64)((double)n_waves * pct / 100.0) : n_waves;
+    }();
     paths_in_seed_numbers = host_numbers;
     if (host_remap) {
         out->path_block = PinnedPool::get().alloc(n_ent * 4);
@@ -1084,6 +1090,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         remap_job.path = (int32_t*)out->path_block.p; remap_job.n_ent = n_ent;
         if (host_stretch) { remap_job.rec_val = (const int32_t*)rec_val_block.p; remap_job.rec_pos = (const u32*)rec_pos_block.p; remap_job.n_rec = n_stretch; }
         remap_job.number = (const u32*)number_block.p; remap_job.n_unitigs = U;
+        remap_job.ent_limit = host_stretch ? (u64)stretch_split_wave * remap_block() : ~0ULL;
         remap_job.landed = side.mark();
 #ifndef AC_EMU
         AC_HIP_CHECK(hipGetDevice(&remap_job.dev));
@@ -1104,10 +1111,25 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         side.after_main();
         copy_d2h_async(out->links_block.p, links_out.ptr(), n_links * sizeof(Link), side.stream());
     }
-    if (host_numbers) {      // the device only checks that every path spells its sequence's length (the sums), it stores nothing
+    if (host_numbers) {      // the device only checks that every path spells its sequence's length (the sums), it stores nothing ...
         const u64 RB = remap_block();
         const u64 n_waves = (n_ent + RB - 1) / RB;
-        launch_full(n_waves * 64, RemapFunctor{ent_val.ptr(), number_len_text.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr(), 0, (u32)RB, nullptr, false});
+        const u64 w_split = host_stretch ? std::min<u64>(stretch_split_wave, n_waves) : n_waves;
+        if (w_split) launch_full(w_split * 64, RemapFunctor{ent_val.ptr(), number_len_text.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr(), 0, (u32)RB, nullptr, false});
+        // ... except for the LAST share of a build that sends its paths as stretches (round 6).  The host's threads can only begin when the
+        // number table exists and write configs[4]'s 4.8 GB at ~37 GB/s (a table row fetched per ~10-entry stretch: the host's memory latency,
+        // tools/microbench/host_write_probe.hip), which ends ~65 ms AFTER the link has delivered everything else; so the entries behind
+        // PathRemapJob::ent_limit are renumbered here and follow the other results over the link, and both ends finish together.
+        if (w_split < n_waves) {
+            const u64 n_chunks = 4, per_chunk = std::max<u64>((n_waves - w_split + n_chunks - 1) / n_chunks, 64);
+            for (u64 w = w_split; w < n_waves; w += per_chunk) {
+                const u64 cnt = std::min<u64>(per_chunk, n_waves - w);
+                launch_full(cnt * 64, RemapFunctor{ent_val.ptr(), number_len_text.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr(), w, (u32)RB, nullptr, true});
+                const u64 b = w * RB, e2 = std::min<u64>((w + cnt) * RB, n_ent);
+                side.after_main();
+                copy_d2h_async((int32_t*)out->path_block.p + b, ent_val.ptr() + b, (e2 - b) * 4, side.stream());      // (the one copy stream: behind the unitig records and the links)
+            }
+        }
     } else {
         if (want_paths) out->path_block = PinnedPool::get().alloc(n_ent * 4);
         const u64 RB = remap_block();
@@ -1154,12 +1176,15 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     const double t_copies_done = now_s();
     if (host_numbers) {
 #ifdef AC_EMU
-        if (host_stretch) path_stretch_range(remap_job, 0, n_stretch, &remap_job.bad);
+        if (host_stretch) { for (u64 b = 0; b < n_stretch; b += 7) path_stretch_range(remap_job, b, std::min<u64>(b + 7, n_stretch), &remap_job.bad); }      // (small blocks: the partial lines where two threads' blocks meet)
         else path_remap_range(remap_job.path, n_ent, remap_job.number, U, &remap_job.bad);
 #endif
         path_remap_finish(remap_job);
     }
     tm->path_stretches = host_stretch ? n_stretch : 0;
+    if (knobs().debug_arena && host_numbers)
+        fprintf(stderr, "d2h: the host's renumbering threads started %.3f ms %s stream 0 drained (their table had landed) and were done %.3f ms later\n",
+                std::fabs(remap_job.t_ready.load() - t_main_done) * 1e3, remap_job.t_ready.load() < t_main_done ? "before" : "after", (remap_job.t_last.load() - remap_job.t_ready.load()) * 1e3);
     if (knobs().debug_arena)      // (where the d2h stage goes: stream 0 drained -> the copies landed -> the host's renumbering threads done)
         fprintf(stderr, "d2h: copies landed %.3f ms after stream 0 drained, host renumbering done %.3f ms later; late results %.1f MB (sequences %.1f, unitig records %.1f, links %.1f, number table %.1f), entries %.1f MB\n",
                 (t_copies_done - t_main_done) * 1e3, (now_s() - t_copies_done) * 1e3, (final_total + (double)U * 24 + n_links * sizeof(Link) + (host_numbers ? (double)U * 4 : 0)) / 1e6,

@@ -213,9 +213,15 @@ __attribute__((target("avx512f"))) static void path_remap_avx512(int32_t* p, u64
 // final numbers of consecutive table entries, front to back; negative ones walk the table backwards, negated.
 void path_stretch_range(const PathRemapJob& j, u64 s0, u64 s1, std::atomic<u32>* bad) {
     u32 wrong = 0;
+    // (round 6: a stretch is ~10 entries — the copy loop's exit mispredicts and the out-of-order window does not reach the next stretch's table
+    // row by itself, so a thread waited out one memory latency per stretch; the rows of the stretches AHEAD are prefetched.  Streaming
+    // stores for the output were measured too: no gain — the job is bound by those row fetches, tools/microbench/host_write_probe.hip)
+    const u64 AHEAD = 16;
     for (u64 s = s0; s < s1; s++) {
+        if (s + AHEAD < s1) { const int64_t va = j.rec_val[s + AHEAD]; const u64 fa = (u64)(va > 0 ? va : -va) - 1; if (fa < (u64)j.n_unitigs) __builtin_prefetch(j.number + fa); }
         const int64_t v0 = j.rec_val[s];
         const u64 b = j.rec_pos[s], e = s + 1 < j.n_rec ? (u64)j.rec_pos[s + 1] : j.n_ent, len = e - b;
+        if (b >= j.ent_limit) break;          // (the entries from there on are renumbered on the device: PathRemapJob::ent_limit)
         int32_t* out = j.path + b;
         if (e > j.n_ent || e <= b) { wrong++; continue; }
         if (v0 > 0) {
@@ -257,6 +263,7 @@ void path_remap_start(PathRemapJob& j, int threads) {
         int expect = 0;
         if (job->ready.compare_exchange_strong(expect, 1)) {      // one thread waits for the copies, the others watch it
             const bool ok = hipSetDevice(job->dev) == hipSuccess && hipEventSynchronize((hipEvent_t)job->landed) == hipSuccess;
+            job->t_ready.store(now_s());
             job->ready.store(ok ? 2 : 3, std::memory_order_release);
         } else {
             while (job->ready.load(std::memory_order_acquire) < 2) std::this_thread::yield();
@@ -265,10 +272,12 @@ void path_remap_start(PathRemapJob& j, int threads) {
         if (job->rec_val) {      // stretch mode: blocks of stretches
             const u64 SB = 4096;
             for (u64 b; (b = job->next.fetch_add(SB)) < job->n_rec;) path_stretch_range(*job, b, std::min(b + SB, job->n_rec), &job->bad);
+            job->t_last.store(now_s());
             return;
         }
         for (u64 b; (b = job->next.fetch_add(BLOCK)) < job->n_ent;)
             path_remap_range(job->path + b, std::min(BLOCK, job->n_ent - b), job->number, job->n_unitigs, &job->bad);
+        job->t_last.store(now_s());
     });
 }
 void path_remap_finish(PathRemapJob& j) noexcept {

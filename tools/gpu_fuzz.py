@@ -38,5 +38,5 @@ for seed in range(1000, 1400):
         fails += 1; print("FAIL synthetic seed", seed, "k", k, repr(e)[:300])
         if fails > 5: break
     m += 1
-    if time.time() - t0 > float(sys.argv[1]) if len(sys.argv) > 1 else 240: break
+    if time.time() - t0 > (float(sys.argv[1]) if len(sys.argv) > 1 else 240): break
 print("gpu synthetic sets", m, "fails", fails, "time %.1f" % (time.time() - t0))

@@ -87,7 +87,7 @@ inline RtCounters& rt_counters() { static thread_local RtCounters c; return c; }
 // context (the single-device entries: one build at a time, whatever thread calls).  ac_compress_build_multi runs one host thread per
 // device and gives each of them a context of its own (set_device_ctx), so that N builds drive N devices side by side.
 struct DeviceCtx {
-    static const int SLOTS = 8;
+    static const int SLOTS = 10;
     void* obj[SLOTS] = {}; void (*del[SLOTS])(void*) = {};
     int arena_device = -1;      // the device the arena's blocks live on
     DeviceCtx() {}
@@ -102,7 +102,7 @@ inline DeviceCtx& device_ctx() {      // (the process-wide one is never destroye
     return p ? *p : *process_wide;
 }
 inline void set_device_ctx(DeviceCtx* c) { tl_device_ctx() = c; }      // nullptr: back to the process-wide context
-enum { CTX_ARENA = 0, CTX_FILLS, CTX_MAILBOX, CTX_SIDE, CTX_SCRATCH, CTX_STAGER, CTX_POOL };
+enum { CTX_ARENA = 0, CTX_FILLS, CTX_MAILBOX, CTX_SIDE, CTX_SCRATCH, CTX_STAGER, CTX_POOL, CTX_SCANPOOL_RESERVED, CTX_POOL2 };      // (7: device_prims.hpp's scan pool)
 template <class T> T& ctx_object(int slot) {
     DeviceCtx& c = device_ctx();
     if (!c.obj[slot]) { c.obj[slot] = new T(); c.del[slot] = [](void* p) { delete (T*)p; }; }

@@ -318,6 +318,20 @@ void path_stretch_range(const PathRemapJob& j, u64 s0, u64 s1, std::atomic<u32>*
 bool path_remap_is_wide();      // the host has the 16-lane gather (without it a thread renumbers ~5x slower and the device keeps the job)
 void path_remap_start(PathRemapJob& j, int threads);      // returns at once; the work runs on the packing threads' pool
 void path_remap_finish(PathRemapJob& j) noexcept;         // until every thread is done (idempotent)
+// SeqExpandJob (round 6): the unitig sequences are the largest result that is final only behind the last pass (config D 126 of 150 MB, mini-E
+// 157 of 494) and cross the link with nothing left to hide under — as 2-bit codes (SeqPack2Functor: 32 bases per word, base i in bits 2i, 2i+1;
+// A C G T = 0 1 2 3: trimmed unitig sequences hold no other byte) a quarter of the bytes do, and a few host threads write the bytes of the
+// result block out while the unitig records and the links are still crossing.
+struct SeqExpandJob {
+    const u64* words = nullptr; u8* out = nullptr; u64 total = 0;      // pinned: the codes as they land; the result block (total bytes)
+    void* landed = nullptr; int dev = 0;                                // event: the codes are in host memory
+    std::atomic<u64> next{0}; std::atomic<int> ready{0};
+    u64 ticket = 0; bool started = false;
+    std::atomic<double> t_start{0}, t_ready{0}, t_last{0};      // diagnostics (AC_DEBUG_ARENA): job started / its codes had landed / its last block was done
+};
+void seq_expand_range(const u64* words, u8* out, u64 b, u64 e);      // bytes [b, e) of the sequences from their codes (b a multiple of 32)
+void seq_expand_start(SeqExpandJob& j, int threads);
+void seq_expand_finish(SeqExpandJob& j) noexcept;
 [[maybe_unused]] static int key_words(int k) { int w = words_for_k(k); return w <= 4 ? w : (w <= 8 ? 8 : 16); }
 [[maybe_unused]] static u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 // Device memory one build of an n_text-byte text needs, roughly: packed text + bitmaps (~0.6 B/position), staging slots
@@ -392,6 +406,7 @@ struct Knobs {
     bool expand_rewrite_always;
     u32 expand_sparse_max, expand_sparse_list, expand_sparse_batch;
     u32 stretch_device_share;
+    int seq_codes_transfer;
     bool seq_writer_plain;
     bool seq_writer_forced;
     u64 seed_radix_limit;
@@ -436,6 +451,7 @@ struct Knobs {
         k.shard_path_copy = [&]() -> bool { const char* e = getenv("AC_SHARD_PATH_COPY"); return !(e && atoi(e) == 0); }();
         k.expand_rewrite_always = [&]() -> bool { return getenv("AC_EXPAND_REWRITE_ALWAYS") != nullptr; }();
         k.expand_sparse_max = [&]() -> u32 { const char* e = getenv("AC_EXPAND_SPARSE_MAX"); int v = e ? atoi(e) : 256; return (u32)(v < 0 ? 0 : v); }();
+        k.seq_codes_transfer = [&]() -> int { const char* e = getenv("AC_SEQ_CODES"); return e ? atoi(e) : 1; }();
         k.stretch_device_share = [&]() -> u32 { const char* e = getenv("AC_STRETCH_DEVICE_SHARE"); int v = e ? atoi(e) : 40; return (u32)(v < 0 ? 0 : v); }();
         k.expand_sparse_list = [&]() -> u32 { const char* e = getenv("AC_EXPAND_SPARSE_LIST"); int v = e ? atoi(e) : 0; return (u32)(v < 0 ? 0 : v); }();
         k.expand_sparse_batch = [&]() -> u32 { const char* e = getenv("AC_EXPAND_SPARSE_BATCH"); int v = e ? atoi(e) : 4096; return (u32)(v < 1 ? 1 : v); }();
@@ -539,6 +555,7 @@ static thread_local int tl_upload_threads_cap = 0;      // a rank of a multi-dev
 [[maybe_unused]] static u32 expand_level_table() { return knobs().expand_level_table; }      // tests: a table too small for the levels
 [[maybe_unused]] static bool shard_path_copy() { return knobs().shard_path_copy; }      // 0 = a sharded build walks all of its text (rounds 3-4)
 [[maybe_unused]] static u32 expand_sparse_max() { return knobs().expand_sparse_max; }      // expand_repeats: at most this many dirty junctions for the one-workgroup tail (0: level launches to the end)
+[[maybe_unused]] static int seq_codes_transfer() { return knobs().seq_codes_transfer; }      // 0 = the unitig sequences cross the link as bytes (rounds 1-5), 1 = as 2-bit codes from 1 MB on, 2 = always (tests)
 [[maybe_unused]] static u32 stretch_device_share() { return knobs().stretch_device_share; }      // paths sent as stretches: per cent of the entries (the last ones) the device renumbers and sends itself (0: the host writes all of them)
 [[maybe_unused]] static u32 expand_sparse_list() { return knobs().expand_sparse_list; }      // tests: the list length at which that tail hands back to the level launches (0: 8 x the start limit)
 [[maybe_unused]] static u32 expand_sparse_batch() { return knobs().expand_sparse_batch; }      // tests: junctions of one level the tail stages in LDS (more: straight from the list)

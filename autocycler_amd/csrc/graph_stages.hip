@@ -779,6 +779,8 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                             (host_remap_mode() == 1 || (host_remap_mode() < 0 && n_ent >= (1u << 18) && U <= (8u << 20) && path_remap_is_wide()));
     PathRemapJob remap_job;
     struct RemapJoin { PathRemapJob& j; ~RemapJoin() { path_remap_finish(j); } } remap_join{remap_job};      // (the threads are done before the guard and the table go)
+    HostBlock seq_words_block; SeqExpandJob seq_job; bool seq_as_codes = false;
+    struct SeqJoin { SeqExpandJob& j; ~SeqJoin() { seq_expand_finish(j); } } seq_join{seq_job};
     // Round 6: where that table would be too large for the host's caches (more than 8 M unitigs: a mixed-species job) the entries cross as
     // STRETCHES of consecutive text-order numbers (kernels_paths.inc) — 8 bytes per stretch instead of 4 per entry — and the host writes
     // the final numbers out from the table front to back: configs[4]'s 4.8 GB of entries are 84 ms of the 57 GB/s the link gives device ->
@@ -1063,10 +1065,32 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     // sequences; K16 per-unitig outputs in final order, links in get_links_for_gfa order, paths in final numbers
     // D2H on a second stream, each array as soon as it is final, straight into pinned blocks owned by the result; the
     // paths go in four chunks, each copied while the next is still being renumbered.
+    DBuf<u64> seq_words; DBuf<u32> seq_bad;
     if (want_graph) {
-        out->seq_block = PinnedPool::get().alloc(final_total);
-        side.after_main();     // sequences are final since the materialise step: their copy runs under the second renumbering
-        copy_d2h_async(out->seq_block.p, cur, final_total, side.stream());
+        out->seq_block = PinnedPool::get().alloc(final_total + 64);
+        // As 2-bit codes, written out by host threads (SeqExpandJob): a quarter of the bytes over the link — where the sequences are most of what
+        // is final this late (one species of long genomes: config D 104 of 142 MB, build 24.9 -> 24.3 ms).  Elsewhere the bytes the host's threads
+        // then write slow the device's copies into the same memory down by as much as the link saves (mini-E 55.2 = 55.2 ms, config C 3.70 -> 3.76:
+        // profiles/r15o_*), so the codes are taken only when the sequences outweigh the other late results two to one.
+        const u64 other_late = (u64)U * 28 + n_links * sizeof(Link);
+        if (seq_codes_transfer() == 2 || (seq_codes_transfer() == 1 && final_total >= ((u64)1 << 20) && final_total > 2 * other_late)) {
+            const u64 nw = (final_total + 31) / 32;
+            seq_words.alloc(nw); seq_bad.alloc(1); seq_bad.fill_bytes(0);
+            launch(nw, SeqPack2Functor{cur, final_total, seq_words.ptr(), seq_bad.ptr()});
+            seq_words_block = PinnedPool::get().alloc(nw * 8);
+            side.after_main();
+            copy_d2h_async(seq_words_block.p, seq_words.ptr(), nw * 8, side.stream());
+            seq_job.words = (const u64*)seq_words_block.p; seq_job.out = (u8*)out->seq_block.p; seq_job.total = final_total;
+            seq_job.landed = side.mark();
+#ifndef AC_EMU
+            AC_HIP_CHECK(hipGetDevice(&seq_job.dev));
+            seq_expand_start(seq_job, 12);
+#endif
+            seq_as_codes = true;
+        } else {
+            side.after_main();     // sequences are final since the materialise step: their copy runs under the second renumbering
+            copy_d2h_async(out->seq_block.p, cur, final_total, side.stream());
+        }
     }
     DBuf<u32> order2(U);
     copy_d2d(order2.ptr(), order1.ptr(), (size_t)U * 4);
@@ -1159,7 +1183,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     std::vector<u32> errs(8);
     u32 pack_bad[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
     u32 h_sort_flags[2] = {0, 0};
-    u64 n_links_check = 0, final_total_read = 0;
+    u64 n_links_check = 0, final_total_read = 0; u32 h_seq_bad = 0;
     {
         ReadBatch rb;
         rb.add(h_sums.data(), sums.ptr(), (size_t)n_seqs * 8);
@@ -1169,11 +1193,23 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         rb.add(&n_links_check, loff.ptr() + U, 8);
         if (final_total_pending) rb.add(&final_total_read, noff.ptr() + U, 8);
         if (loc.check_alphabet && loc.pack_bad.size()) rb.add(pack_bad, loc.pack_bad.ptr(), 8);
+        if (seq_as_codes) rb.add(&h_seq_bad, seq_bad.ptr(), 4);
         rb.run();                                   // synchronises stream 0 (once)
     }
     const double t_main_done = now_s();
     side.sync();                                    // ... and the copies: everything above has landed
     const double t_copies_done = now_s();
+    if (seq_as_codes) {
+#ifdef AC_EMU
+        for (u64 b = 0; b < final_total; b += 4096) seq_expand_range(seq_job.words, seq_job.out, b, std::min<u64>(b + 4096, final_total));
+#endif
+        seq_expand_finish(seq_job);
+        if (seq_job.ready.load() == 3) throw DeviceError("internal error: the sequence codes did not reach the host");
+        if (h_seq_bad) {      // (never, short of a bug: a byte that is no base in a trimmed unitig sequence — the bytes themselves, then)
+            copy_d2h_async(out->seq_block.p, cur, final_total, side.stream());
+            side.sync();
+        }
+    }
     if (host_numbers) {
 #ifdef AC_EMU
         if (host_stretch) { for (u64 b = 0; b < n_stretch; b += 7) path_stretch_range(remap_job, b, std::min<u64>(b + 7, n_stretch), &remap_job.bad); }      // (small blocks: the partial lines where two threads' blocks meet)
@@ -1182,6 +1218,9 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         path_remap_finish(remap_job);
     }
     tm->path_stretches = host_stretch ? n_stretch : 0;
+    if (knobs().debug_arena && seq_as_codes)
+        fprintf(stderr, "d2h: sequence codes: job started %.3f ms before stream 0 drained, its codes had landed %.3f ms after that start, %.1f MB written out in %.3f ms more\n",
+                (t_main_done - seq_job.t_start.load()) * 1e3, (seq_job.t_ready.load() - seq_job.t_start.load()) * 1e3, final_total / 1e6, (seq_job.t_last.load() - seq_job.t_ready.load()) * 1e3);
     if (knobs().debug_arena && host_numbers)
         fprintf(stderr, "d2h: the host's renumbering threads started %.3f ms %s stream 0 drained (their table had landed) and were done %.3f ms later\n",
                 std::fabs(remap_job.t_ready.load() - t_main_done) * 1e3, remap_job.t_ready.load() < t_main_done ? "before" : "after", (remap_job.t_last.load() - remap_job.t_ready.load()) * 1e3);

@@ -238,6 +238,65 @@ void path_stretch_range(const PathRemapJob& j, u64 s0, u64 s1, std::atomic<u32>*
     }
     if (wrong) bad->fetch_add(wrong);
 }
+// ---- SeqExpandJob: 2-bit codes -> the bytes of the unitig sequences ----------------------------------------------------------------------
+static void seq_expand_scalar(const u64* words, u8* out, u64 b, u64 e) {
+    for (u64 i = b; i < e; i++) out[i] = (u8)"ACGT"[(words[i >> 5] >> (2 * (i & 31))) & 3];
+}
+#if defined(__x86_64__)
+// sixteen bytes of codes (64 bases) per step: the four 2-bit fields of every byte isolated, interleaved back into base order, looked up in "ACGT"
+__attribute__((target("ssse3"))) static void seq_expand_ssse3(const u64* words, u8* out, u64 b, u64 e) {
+    const __m128i m3 = _mm_set1_epi8(3), lut = _mm_setr_epi8('A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T');
+    const u8* src = (const u8*)words;
+    u64 i = b;
+    for (; i + 64 <= e; i += 64) {
+        const __m128i v = _mm_loadu_si128((const __m128i*)(src + i / 4));
+        const __m128i x0 = _mm_and_si128(v, m3), x1 = _mm_and_si128(_mm_srli_epi16(v, 2), m3), x2 = _mm_and_si128(_mm_srli_epi16(v, 4), m3), x3 = _mm_and_si128(_mm_srli_epi16(v, 6), m3);
+        const __m128i a = _mm_unpacklo_epi8(x0, x1), c = _mm_unpacklo_epi8(x2, x3), d = _mm_unpackhi_epi8(x0, x1), f = _mm_unpackhi_epi8(x2, x3);
+        _mm_storeu_si128((__m128i*)(out + i), _mm_shuffle_epi8(lut, _mm_unpacklo_epi16(a, c)));
+        _mm_storeu_si128((__m128i*)(out + i + 16), _mm_shuffle_epi8(lut, _mm_unpackhi_epi16(a, c)));
+        _mm_storeu_si128((__m128i*)(out + i + 32), _mm_shuffle_epi8(lut, _mm_unpacklo_epi16(d, f)));
+        _mm_storeu_si128((__m128i*)(out + i + 48), _mm_shuffle_epi8(lut, _mm_unpackhi_epi16(d, f)));
+    }
+    seq_expand_scalar(words, out, i, e);
+}
+#endif
+void seq_expand_range(const u64* words, u8* out, u64 b, u64 e) {
+#if defined(__x86_64__)
+    static const bool fast = __builtin_cpu_supports("ssse3") && getenv("AC_PACK_SCALAR") == nullptr;
+    if (fast) { seq_expand_ssse3(words, out, b, e); return; }
+#endif
+    seq_expand_scalar(words, out, b, e);
+}
+#ifndef AC_EMU
+void seq_expand_start(SeqExpandJob& j, int threads) {
+    const u64 BLOCK = (u64)1 << 18;      // bytes of sequence per work item
+    const int T = (int)std::max<u64>(1, std::min<u64>({(j.total + BLOCK - 1) / BLOCK, (u64)std::max(threads, 1), (u64)std::max(1u, std::thread::hardware_concurrency())}));
+    SeqExpandJob* job = &j;
+    j.started = true;
+    j.t_start.store(now_s());
+    j.ticket = UploadPool::second().start(T, [job, BLOCK] {
+        int expect = 0;
+        if (job->ready.compare_exchange_strong(expect, 1)) {      // one thread waits for the copy, the others watch it
+            const bool ok = hipSetDevice(job->dev) == hipSuccess && hipEventSynchronize((hipEvent_t)job->landed) == hipSuccess;
+            job->t_ready.store(now_s());
+            job->ready.store(ok ? 2 : 3, std::memory_order_release);
+        } else {
+            while (job->ready.load(std::memory_order_acquire) < 2) std::this_thread::yield();
+        }
+        if (job->ready.load(std::memory_order_acquire) != 2) return;      // (seq_expand_finish's caller sees ready == 3)
+        for (u64 b; (b = job->next.fetch_add(BLOCK)) < job->total;) seq_expand_range(job->words, job->out, b, std::min(b + BLOCK, job->total));
+        job->t_last.store(now_s());
+    });
+}
+void seq_expand_finish(SeqExpandJob& j) noexcept {
+    if (!j.started) return;
+    UploadPool::second().wait(j.ticket);
+    j.started = false;
+}
+#else
+void seq_expand_start(SeqExpandJob&, int) {}
+void seq_expand_finish(SeqExpandJob&) noexcept {}
+#endif
 bool path_remap_is_wide() {
 #if defined(__x86_64__)
     static const bool wide = __builtin_cpu_supports("avx512f") && getenv("AC_PACK_SCALAR") == nullptr && getenv("AC_PACK_AVX2") == nullptr;

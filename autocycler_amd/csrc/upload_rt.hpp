@@ -17,6 +17,7 @@ namespace ac {
 class UploadPool {
   public:
     static UploadPool& get() { return ctx_object<UploadPool>(CTX_POOL); }
+    static UploadPool& second() { return ctx_object<UploadPool>(CTX_POOL2); }      // a few threads for a job that runs beside one of the first pool's (SeqExpandJob)
     UploadPool() {}
     // Runs fn() on n threads; returns at once.  One run at a time (the C ABI serialises builds).
     u64 start(int n, std::function<void()> fn) {

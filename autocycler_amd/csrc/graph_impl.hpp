@@ -555,7 +555,7 @@ static thread_local int tl_upload_threads_cap = 0;      // a rank of a multi-dev
 [[maybe_unused]] static u32 expand_level_table() { return knobs().expand_level_table; }      // tests: a table too small for the levels
 [[maybe_unused]] static bool shard_path_copy() { return knobs().shard_path_copy; }      // 0 = a sharded build walks all of its text (rounds 3-4)
 [[maybe_unused]] static u32 expand_sparse_max() { return knobs().expand_sparse_max; }      // expand_repeats: at most this many dirty junctions for the one-workgroup tail (0: level launches to the end)
-[[maybe_unused]] static int seq_codes_transfer() { return knobs().seq_codes_transfer; }      // 0 = the unitig sequences cross the link as bytes (rounds 1-5), 1 = as 2-bit codes from 1 MB on, 2 = always (tests)
+[[maybe_unused]] static int seq_codes_transfer() { return knobs().seq_codes_transfer; }      // 0 = the unitig sequences cross the link as bytes (rounds 1-5), 1 = as 2-bit codes where they are >= 32 MB and most of the late results, 2 = always (tests)
 [[maybe_unused]] static u32 stretch_device_share() { return knobs().stretch_device_share; }      // paths sent as stretches: per cent of the entries (the last ones) the device renumbers and sends itself (0: the host writes all of them)
 [[maybe_unused]] static u32 expand_sparse_list() { return knobs().expand_sparse_list; }      // tests: the list length at which that tail hands back to the level launches (0: 8 x the start limit)
 [[maybe_unused]] static u32 expand_sparse_batch() { return knobs().expand_sparse_batch; }      // tests: junctions of one level the tail stages in LDS (more: straight from the list)

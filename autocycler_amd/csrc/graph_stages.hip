@@ -1071,9 +1071,10 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
         // As 2-bit codes, written out by host threads (SeqExpandJob): a quarter of the bytes over the link — where the sequences are most of what
         // is final this late (one species of long genomes: config D 104 of 142 MB, build 24.9 -> 24.3 ms).  Elsewhere the bytes the host's threads
         // then write slow the device's copies into the same memory down by as much as the link saves (mini-E 55.2 = 55.2 ms, config C 3.70 -> 3.76:
-        // profiles/r15o_*), so the codes are taken only when the sequences outweigh the other late results two to one.
+        // profiles/r15o_*), so the codes are taken only when the sequences outweigh the other late results two to one — and are at least 32 MB: on
+        // D' at k = 201 (10 MB of sequences) the job's fixed costs were 0.1 ms more than the link saved.
         const u64 other_late = (u64)U * 28 + n_links * sizeof(Link);
-        if (seq_codes_transfer() == 2 || (seq_codes_transfer() == 1 && final_total >= ((u64)1 << 20) && final_total > 2 * other_late)) {
+        if (seq_codes_transfer() == 2 || (seq_codes_transfer() == 1 && final_total >= ((u64)32 << 20) && final_total > 2 * other_late)) {
             const u64 nw = (final_total + 31) / 32;
             seq_words.alloc(nw); seq_bad.alloc(1); seq_bad.fill_bytes(0);
             launch(nw, SeqPack2Functor{cur, final_total, seq_words.ptr(), seq_bad.ptr()});

@@ -127,6 +127,9 @@ def pairwise_distances(gfa):
     return [[out[a * S + b] for b in range(S)] for a in range(S)]
 
 
+_COMPRESS_MEMO = {}      # digest of a loaded set + k -> (gfa, stats, times) of Seqs.compress
+
+
 class Seqs:
     """Loaded (padded, end-repaired) sequences as the reference has them at compress.rs:41."""
 
@@ -172,7 +175,24 @@ class Seqs:
         return [self.get(i) for i in range(len(self))]
 
     def compress(self, k):
-        """compress.rs:42-47 -> (gfa_text, stats dict, times dict)."""
+        """compress.rs:42-47 -> (gfa_text, stats dict, times dict).  The oracle's answer for one loaded set is computed once per process: the
+        multi-rank and knob tests ask for the same set under many settings (a digest of everything the oracle reads is the key)."""
+        import hashlib
+        hsh = hashlib.blake2b(digest_size=16)
+        hsh.update(b"%d|%d|" % (k, self.assembly_count))
+        for q in self.all():
+            hsh.update(b"%d|%d|" % (q["id"], q["length"])); hsh.update(q["fwd"]); hsh.update(b"|"); hsh.update(q["filename"].encode()); hsh.update(b"|"); hsh.update(q["header"].encode()); hsh.update(b"\n")
+        key = hsh.digest()
+        hit = _COMPRESS_MEMO.get(key)
+        if hit is not None:
+            return hit[0], dict(hit[1]), dict(hit[2])
+        res = self._compress(k)
+        if len(_COMPRESS_MEMO) >= 12:
+            _COMPRESS_MEMO.pop(next(iter(_COMPRESS_MEMO)))
+        _COMPRESS_MEMO[key] = res
+        return res[0], dict(res[1]), dict(res[2])
+
+    def _compress(self, k):
         out = C.c_void_p()
         stats = (C.c_uint64 * 7)()
         times = (C.c_double * 6)()

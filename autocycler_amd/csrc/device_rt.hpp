@@ -625,6 +625,7 @@ template <class T> T read_scalar(const T* dptr, stream_t s = 0) {
 // synchronisation with stream 0; ordering is by events.
 class SideStream {
   public:
+    static const unsigned N_EV = 64;
     static SideStream& get() { return ctx_object<SideStream>(CTX_SIDE); }
     SideStream() {}
     ~SideStream() { destroy(); }
@@ -650,7 +651,7 @@ class SideStream {
     void after_main(int which = 0) {
 #ifndef AC_EMU
         stream_t s = stream(which);
-        hipEvent_t e = ev_[next_++ % 16];
+        hipEvent_t e = ev_[next_++ % N_EV];
         flush_fills();
         AC_HIP_CHECK(hipEventRecord(e, 0));
         AC_HIP_CHECK(hipStreamWaitEvent(s, e, 0));
@@ -658,11 +659,38 @@ class SideStream {
         (void)which;
 #endif
     }
-    // An event that fires when everything enqueued on the side stream so far is done (valid until 16 more events were taken).
+    // An event that fires when everything enqueued on STREAM 0 so far is done, and the host's wait for it (a poll: the caller is about to issue
+    // the copy that needed it — see GraphBuilder::Impl::tail, "late copies").  Valid until N_EV more events were taken.
+    void* main_event() {
+#ifndef AC_EMU
+        (void)stream();
+        hipEvent_t e = ev_[next_++ % N_EV];
+        flush_fills();
+        AC_HIP_CHECK(hipEventRecord(e, 0));
+        return (void*)e;
+#else
+        return nullptr;
+#endif
+    }
+    static void wait_event(void* ev) {
+#ifndef AC_EMU
+        for (;;) {
+            const hipError_t e = hipEventQuery((hipEvent_t)ev);
+            if (e == hipSuccess) return;
+            if (e != hipErrorNotReady) AC_HIP_CHECK(e);
+#if defined(__x86_64__)
+            for (int i = 0; i < 32; i++) __builtin_ia32_pause();
+#endif
+        }
+#else
+        (void)ev;
+#endif
+    }
+    // An event that fires when everything enqueued on the side stream so far is done (valid until N_EV more events were taken).
     void* mark() {
 #ifndef AC_EMU
         stream_t s = stream();
-        hipEvent_t e = ev_[next_++ % 16];
+        hipEvent_t e = ev_[next_++ % N_EV];
         AC_HIP_CHECK(hipEventRecord(e, s));
         return (void*)e;
 #else
@@ -684,7 +712,7 @@ class SideStream {
     }
 #ifndef AC_EMU
     hipStream_t s_ = nullptr, s2_ = nullptr;
-    hipEvent_t ev_[16];
+    hipEvent_t ev_[64];
 #endif
     bool created_ = false;
     int dev_ = -1;

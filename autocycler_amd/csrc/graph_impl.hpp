@@ -407,6 +407,7 @@ struct Knobs {
     u32 expand_sparse_max, expand_sparse_list, expand_sparse_batch;
     u32 stretch_device_share;
     int seq_codes_transfer;
+    int late_copies;
     bool seq_writer_plain;
     bool seq_writer_forced;
     u64 seed_radix_limit;
@@ -451,6 +452,7 @@ struct Knobs {
         k.shard_path_copy = [&]() -> bool { const char* e = getenv("AC_SHARD_PATH_COPY"); return !(e && atoi(e) == 0); }();
         k.expand_rewrite_always = [&]() -> bool { return getenv("AC_EXPAND_REWRITE_ALWAYS") != nullptr; }();
         k.expand_sparse_max = [&]() -> u32 { const char* e = getenv("AC_EXPAND_SPARSE_MAX"); int v = e ? atoi(e) : 256; return (u32)(v < 0 ? 0 : v); }();
+        k.late_copies = [&]() -> int { const char* e = getenv("AC_LATE_COPIES"); return e ? atoi(e) : 1; }();
         k.seq_codes_transfer = [&]() -> int { const char* e = getenv("AC_SEQ_CODES"); return e ? atoi(e) : 1; }();
         k.stretch_device_share = [&]() -> u32 { const char* e = getenv("AC_STRETCH_DEVICE_SHARE"); int v = e ? atoi(e) : 40; return (u32)(v < 0 ? 0 : v); }();
         k.expand_sparse_list = [&]() -> u32 { const char* e = getenv("AC_EXPAND_SPARSE_LIST"); int v = e ? atoi(e) : 0; return (u32)(v < 0 ? 0 : v); }();
@@ -555,6 +557,7 @@ static thread_local int tl_upload_threads_cap = 0;      // a rank of a multi-dev
 [[maybe_unused]] static u32 expand_level_table() { return knobs().expand_level_table; }      // tests: a table too small for the levels
 [[maybe_unused]] static bool shard_path_copy() { return knobs().shard_path_copy; }      // 0 = a sharded build walks all of its text (rounds 3-4)
 [[maybe_unused]] static u32 expand_sparse_max() { return knobs().expand_sparse_max; }      // expand_repeats: at most this many dirty junctions for the one-workgroup tail (0: level launches to the end)
+[[maybe_unused]] static int late_copies() { return knobs().late_copies; }      // the copies of the last results: 0 = queued behind an event of stream 0, 1 = issued by the host when that event has fired (from 256 MB of late results), 2 = always (tests)
 [[maybe_unused]] static int seq_codes_transfer() { return knobs().seq_codes_transfer; }      // 0 = the unitig sequences cross the link as bytes (rounds 1-5), 1 = as 2-bit codes where they are >= 32 MB and most of the late results, 2 = always (tests)
 [[maybe_unused]] static u32 stretch_device_share() { return knobs().stretch_device_share; }      // paths sent as stretches: per cent of the entries (the last ones) the device renumbers and sends itself (0: the host writes all of them)
 [[maybe_unused]] static u32 expand_sparse_list() { return knobs().expand_sparse_list; }      // tests: the list length at which that tail hands back to the level launches (0: 8 x the start limit)

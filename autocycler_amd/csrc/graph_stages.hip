@@ -780,6 +780,18 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     PathRemapJob remap_job;
     struct RemapJoin { PathRemapJob& j; ~RemapJoin() { path_remap_finish(j); } } remap_join{remap_job};      // (the threads are done before the guard and the table go)
     HostBlock seq_words_block; SeqExpandJob seq_job; bool seq_as_codes = false;
+    // Late copies (round 6): a result of the last stage is copied out behind the kernel that made it — through an event of stream 0 the side
+    // stream waits for (after_main), or, AC_LATE_COPIES, ISSUED BY THIS THREAD once that event has fired: it has enqueued every kernel of the
+    // build long before the device gets there and only waits from then on, so it can watch the events in order and hand the copy engine work
+    // whose inputs are ready (on some boxes a copy queue that has to wait for a kernel wakes up late: DESIGN.md §6.2, the 0.800 s builds).
+    struct LateCopy { void* ev; std::function<void()> issue; };
+    std::vector<LateCopy> late;
+    bool late_by_host = false;
+    auto late_copy = [&](std::function<void()> issue) {
+        if (late_by_host) late.push_back(LateCopy{side.main_event(), std::move(issue)});
+        else { side.after_main(); issue(); }
+    };
+    auto issue_late_copies = [&]() { for (auto& c : late) { SideStream::wait_event(c.ev); c.issue(); } late.clear(); };
     struct SeqJoin { SeqExpandJob& j; ~SeqJoin() { seq_expand_finish(j); } } seq_join{seq_job};
     // Round 6: where that table would be too large for the host's caches (more than 8 M unitigs: a mixed-species job) the entries cross as
     // STRETCHES of consecutive text-order numbers (kernels_paths.inc) — 8 bytes per stretch instead of 4 per entry — and the host writes
@@ -1106,35 +1118,38 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
     out->k = k;
     out->n_kmers = 2 * (u64)N;
     out->n_unitigs = U;
+    late_by_host = late_copies() == 2 || (late_copies() == 1 && final_total + (u64)U * 28 + n_links * sizeof(Link) >= ((u64)256 << 20));
     launch(U, FinalMetaFunctor{order2.ptr(), coff.ptr(), clen.ptr(), depth.ptr(), lcnt.ptr(), number_len.ptr(), d_seq_begin, d_depth,
                                d_seq_len, lcount.ptr(), host_numbers ? number_only.ptr() : nullptr, d_seed_index, order.ptr(), number_len_text.ptr(), uorient.ptr()});
     if (host_numbers) {      // the number table first: the host threads start on the entries while the rest is still crossing
         number_block = PinnedPool::get().alloc((size_t)U * 4);
-        side.after_main();
-        copy_d2h_async(number_block.p, number_only.ptr(), (size_t)U * 4, side.stream());
         remap_job.path = (int32_t*)out->path_block.p; remap_job.n_ent = n_ent;
         if (host_stretch) { remap_job.rec_val = (const int32_t*)rec_val_block.p; remap_job.rec_pos = (const u32*)rec_pos_block.p; remap_job.n_rec = n_stretch; }
         remap_job.number = (const u32*)number_block.p; remap_job.n_unitigs = U;
         remap_job.ent_limit = host_stretch ? (u64)stretch_split_wave * remap_block() : ~0ULL;
-        remap_job.landed = side.mark();
+        const u32* d_number_only = number_only.ptr();
+        const int remap_threads = (int)(host_stretch ? 2 * upload_threads() : upload_threads());      // (writing the stretches out is bound by the host's memory, not by its cores' arithmetic: twice the packing threads — configs[4] writes 4.8 GB)
+        late_copy([&, d_number_only, remap_threads]() {
+            copy_d2h_async(number_block.p, d_number_only, (size_t)U * 4, side.stream());
+            remap_job.landed = side.mark();
 #ifndef AC_EMU
-        AC_HIP_CHECK(hipGetDevice(&remap_job.dev));
-        // (writing the stretches out is bound by the host's memory, not by its cores' arithmetic: twice the packing threads — configs[4] writes 4.8 GB)
-        path_remap_start(remap_job, (int)(host_stretch ? 2 * upload_threads() : upload_threads()));
+            AC_HIP_CHECK(hipGetDevice(&remap_job.dev));
+            path_remap_start(remap_job, remap_threads);
 #endif
+        });
     }
     if (want_graph) {
         out->meta_block = PinnedPool::get().alloc((size_t)U * 24);
-        side.after_main();
-        copy_d2h_async(out->meta_block.p, meta.ptr(), (size_t)U * 24, side.stream());
+        const u8* d_meta = meta.ptr();
+        late_copy([&, d_meta]() { copy_d2h_async(out->meta_block.p, d_meta, (size_t)U * 24, side.stream()); });
     }
     exclusive_scan_u64(lcount.ptr(), loff.ptr(), (u64)U + 1);
     DBuf<Link> links_out(n_links);      // (n_links: counted by LinkOrderFunctor, read with the candidate count)
     launch(U, LinkOutFunctor{order2.ptr(), L, number_len.ptr(), loff.ptr(), links_out.ptr()});
     if (want_graph) {
         out->links_block = PinnedPool::get().alloc(n_links * sizeof(Link));
-        side.after_main();
-        copy_d2h_async(out->links_block.p, links_out.ptr(), n_links * sizeof(Link), side.stream());
+        const Link* d_links_out = links_out.ptr();
+        late_copy([&, d_links_out]() { copy_d2h_async(out->links_block.p, d_links_out, n_links * sizeof(Link), side.stream()); });
     }
     if (host_numbers) {      // the device only checks that every path spells its sequence's length (the sums), it stores nothing ...
         const u64 RB = remap_block();
@@ -1151,8 +1166,8 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
                 const u64 cnt = std::min<u64>(per_chunk, n_waves - w);
                 launch_full(cnt * 64, RemapFunctor{ent_val.ptr(), number_len_text.ptr(), path_off.ptr(), n_seqs, n_ent, sums.ptr(), w, (u32)RB, nullptr, true});
                 const u64 b = w * RB, e2 = std::min<u64>((w + cnt) * RB, n_ent);
-                side.after_main();
-                copy_d2h_async((int32_t*)out->path_block.p + b, ent_val.ptr() + b, (e2 - b) * 4, side.stream());      // (the one copy stream: behind the unitig records and the links)
+                const int32_t* d_ent = ent_val.ptr();
+                late_copy([&, d_ent, b, e2]() { copy_d2h_async((int32_t*)out->path_block.p + b, d_ent + b, (e2 - b) * 4, side.stream()); });      // (the one copy stream: behind the unitig records and the links)
             }
         }
     } else {
@@ -1177,6 +1192,7 @@ template <int W> void GraphBuilder::Impl::tail(FinalGraph* out, bool want_graph,
             }
         }
     }
+    issue_late_copies();      // (every kernel of the build is enqueued: from here on this thread only waits)
     lap(&tm->finalize);
 
     std::vector<u64> h_sums(n_seqs);

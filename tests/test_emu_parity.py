@@ -148,7 +148,7 @@ def test_high_diversity_table_growth(emu):
 
 
 KNOB_SETTINGS = [{"AC_TABLE_SHIFT": "0"}, {"AC_TABLE_SHIFT": "2"}, {"AC_MINKEY_VARIANT": "0"}, {"AC_MINKEY_VARIANT": "1"}, {"AC_MINKEY_VARIANT": "2"}, {"AC_MINKEY_VARIANT": "2", "AC_MINKEY_PREFIX_BASES": "2"}, {"AC_PATH_CHUNK": "64"}, {"AC_PATH_FILTER": "0"}, {"AC_EXPAND_REWRITE_ALWAYS": "1"}, {"AC_EXPAND_LEVEL_TABLE": "1"}, {"AC_SEED_RADIX_LIMIT": "0"}, {"AC_HOST_PACK": "0"}, {"AC_SEED_PREFIX_SORT": "0"}, {"AC_SEED_PREFIX_BITS": "3"}, {"AC_SEED_PREFIX_BITS": "12"}, {"AC_POS_CAP": "0"}, {"AC_POS_CAP": "3"}, {"AC_POS_CAP": "200", "AC_PATH_COPY": "1"}, {"AC_PATH_COPY": "1"}, {"AC_PATH_COPY": "1", "AC_RUN_PIECE": "150"}, {"AC_PATH_COPY": "1", "AC_PATH_FILTER": "0"}, {"AC_SEED_PREFIX_BITS": "3", "AC_SEED_MAX_GROUP": "2"}, {"AC_SEED_PREFIX_BITS": "6", "AC_SEED_MAX_GROUP": "1", "AC_SEED_RADIX_LIMIT": "1000000000"}, {"AC_SEED_PREFIX_SORT": "0", "AC_SEED_RADIX_LIMIT": "0"}, {"AC_RENUM_TWO_PASS": "1"}, {"AC_RENUM_MAX_GROUP": "1"}, {"AC_SORT_CHECKS": "1"}, {"AC_SORT_CHECKS": "1", "AC_RENUM_MAX_GROUP": "1"}, {"AC_RENUM_MAX_GROUP": "2"}, {"AC_DEGREE_FLAGS": "0"}, {"AC_DEGREE_REGION_CAP": "1"}, {"AC_DEGREE_REGION_CAP": "3"}, {"AC_UPLOAD_THREADS": "3"},
-                 {"AC_REMAP_BLOCK": "128"}, {"AC_HOST_REMAP": "1"}, {"AC_HOST_REMAP": "1", "AC_UPLOAD_THREADS": "3"}, {"AC_HOST_REMAP": "0"}, {"AC_HOST_REMAP": "2"}, {"AC_HOST_REMAP": "2", "AC_UPLOAD_THREADS": "2"}, {"AC_HOST_REMAP": "2", "AC_REMAP_BLOCK": "128", "AC_STRETCH_DEVICE_SHARE": "50"}, {"AC_HOST_REMAP": "2", "AC_STRETCH_DEVICE_SHARE": "0"}, {"AC_SEQ_CODES": "2"}, {"AC_SEQ_CODES": "0"}, {"AC_SEQ_CODES": "2", "AC_PACK_SCALAR": "1"}, {"AC_INSERT_ADAPT": "0", "AC_INSERT_GROWTH": "4"}, {"AC_INSERT_CHUNK": "256", "AC_INSERT_WAVES": "1024"}]
+                 {"AC_REMAP_BLOCK": "128"}, {"AC_HOST_REMAP": "1"}, {"AC_HOST_REMAP": "1", "AC_UPLOAD_THREADS": "3"}, {"AC_HOST_REMAP": "0"}, {"AC_HOST_REMAP": "2"}, {"AC_HOST_REMAP": "2", "AC_UPLOAD_THREADS": "2"}, {"AC_HOST_REMAP": "2", "AC_REMAP_BLOCK": "128", "AC_STRETCH_DEVICE_SHARE": "50"}, {"AC_HOST_REMAP": "2", "AC_STRETCH_DEVICE_SHARE": "0"}, {"AC_SEQ_CODES": "2"}, {"AC_SEQ_CODES": "0"}, {"AC_LATE_COPIES": "2"}, {"AC_LATE_COPIES": "2", "AC_HOST_REMAP": "2", "AC_REMAP_BLOCK": "128", "AC_SEQ_CODES": "2"}, {"AC_LATE_COPIES": "2", "AC_HOST_REMAP": "0"}, {"AC_SEQ_CODES": "2", "AC_PACK_SCALAR": "1"}, {"AC_INSERT_ADAPT": "0", "AC_INSERT_GROWTH": "4"}, {"AC_INSERT_CHUNK": "256", "AC_INSERT_WAVES": "1024"}]
 
 
 @pytest.mark.parametrize("knobs", KNOB_SETTINGS, ids=lambda d: ",".join(f"{a}={b}" for a, b in d.items()))

@@ -454,7 +454,7 @@ struct Knobs {
         k.expand_sparse_max = [&]() -> u32 { const char* e = getenv("AC_EXPAND_SPARSE_MAX"); int v = e ? atoi(e) : 256; return (u32)(v < 0 ? 0 : v); }();
         k.late_copies = [&]() -> int { const char* e = getenv("AC_LATE_COPIES"); return e ? atoi(e) : 1; }();
         k.seq_codes_transfer = [&]() -> int { const char* e = getenv("AC_SEQ_CODES"); return e ? atoi(e) : 1; }();
-        k.stretch_device_share = [&]() -> u32 { const char* e = getenv("AC_STRETCH_DEVICE_SHARE"); int v = e ? atoi(e) : 40; return (u32)(v < 0 ? 0 : v); }();
+        k.stretch_device_share = [&]() -> u32 { const char* e = getenv("AC_STRETCH_DEVICE_SHARE"); int v = e ? atoi(e) : 30; return (u32)(v < 0 ? 0 : v); }();
         k.expand_sparse_list = [&]() -> u32 { const char* e = getenv("AC_EXPAND_SPARSE_LIST"); int v = e ? atoi(e) : 0; return (u32)(v < 0 ? 0 : v); }();
         k.expand_sparse_batch = [&]() -> u32 { const char* e = getenv("AC_EXPAND_SPARSE_BATCH"); int v = e ? atoi(e) : 4096; return (u32)(v < 1 ? 1 : v); }();
         k.seq_writer_plain = [&]() -> bool { const char* e = getenv("AC_SEQ_WRITER"); return e && atoi(e) == 0; }();

@@ -170,7 +170,7 @@ def test_paths_cross_as_stretches(emu, monkeypatch):
     tm = g.timings()
     assert 0 < tm["path_stretches"] < tm["n_path_entries"], tm
     g.close()
-    # ... with the last share of the entries renumbered on the device instead (the default is 40 %; small blocks so that this input has several)
+    # ... with the last share of the entries renumbered on the device instead (the default is 30 %; small blocks so that this input has several)
     monkeypatch.setenv("AC_REMAP_BLOCK", "128")
     for share in ("0", "30", "55", "100"):
         monkeypatch.setenv("AC_STRETCH_DEVICE_SHARE", share)
